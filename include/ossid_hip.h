@@ -1,0 +1,117 @@
+/*
+ * include/ossid_hip.h -- C ABI of libossid_hip.so, the MI355X (gfx950) drop-in for OSSID's hot path.
+ *
+ * The reference (r-pad/OSSID_code) is pure Python and has no FFI of its own: each
+ * entry point below names the Python interface it stands behind (paths relative to
+ * /root/reference/python/ossid). INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory,
+ *     including workspaces (sizes from the *_workspace_bytes queries); nothing is allocated inside;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue work;
+ *   - return 0 on success, a negative errno-style code otherwise (OSSID_EINVAL bad argument,
+ *     OSSID_ELAUNCH a HIP launch error); no exceptions cross the boundary;
+ *   - thread-safe for distinct streams; no global mutable state;
+ *   - all arithmetic is IEEE binary32 with the operation order fixed by SPEC.md, so results are
+ *     bit-identical to oracle/zephyr_oracle.c.
+ */
+#ifndef OSSID_HIP_H
+#define OSSID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSSID_OK 0
+#define OSSID_EINVAL (-22)
+#define OSSID_ELAUNCH (-5)
+
+/* library / device probe: returns the ABI version (>0); arch_out_host (may be NULL, >=32 bytes)
+ * receives the gcnArchName of the current device, e.g. "gfx950:sramecc+:xnack-". */
+int ossid_abi_version(char* arch_out_host, int len);
+
+/* ---------------------------------------------------------------------------------------------
+ * Z0  networkInference preprocessing          utils/zephyr_utils.py:13-14
+ * cv2.GaussianBlur(img,(5,5),0) on u8 RGB [H,W,3] (blur=1) then /255 -> float, interleaved with
+ * depth [H,W] (metres, 0 = invalid) into the staged frame rgbd[H,W,4] = (r,g,b,depth).
+ * --------------------------------------------------------------------------------------------- */
+int ossid_zephyr_prep_frame_u8(const uint8_t* img_rgb, const float* depth, int H, int W, int blur,
+                               float* rgbd, void* stream);
+/* same, for callers that already hold the float image (the tensor getPointNetData receives,
+ * utils/zephyr_utils.py:14): img_rgb is float [H,W,3] in [0,1]. */
+int ossid_zephyr_prep_frame_f32(const float* img_rgb, const float* depth, int H, int W, float* rgbd,
+                                void* stream);
+
+/* model table: tab[M][12] = (point xyz, normal xyz, HSV of the model colour, 3 pad)
+ * from model_points / model_normals / model_colors [M,3] (utils/zephyr_utils.py:18-20). */
+int ossid_zephyr_prep_model(const float* points, const float* normals, const float* colors_rgb, int M,
+                            float* tab, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Z1  zephyr.utils.projectPointsUv(pose_hypos, model_points, meta_data)
+ *     call site utils/zephyr_utils.py:58; K2meta utils/__init__.py:148-156
+ * transforms [N,4,4] row-major float, points [M,3] -> uv [N,M,2] int32, uv[...,0]=x(col),
+ * uv[...,1]=y(row); (-1,-1) marks a point at or behind the camera plane.
+ * --------------------------------------------------------------------------------------------- */
+int ossid_zephyr_project_uv(const float* transforms, const float* points, int N, int M, float fx, float fy,
+                            float cx, float cy, int32_t* uv, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Z2  ScoreDataset.getPointNetData(data, return_uv_original)   call site utils/zephyr_utils.py:31
+ * (a) free-space-violation count per hypothesis, the input of the inconst_ratio_th filter
+ *     (scripts/online_learning.py:174,184,196; utils/zephyr_utils.py:42-43);
+ * (b) features of the hypotheses sel[0..Nsel) (sel NULL = identity):
+ *     point_x[Nsel][M][8] = (x, y, 0, dH, dS, dV, dD, cosN), uv_original[Nsel][M][2] (may be NULL).
+ * interp: 0 nearest pixel (default), 1 bilinear colour/depth.
+ * --------------------------------------------------------------------------------------------- */
+int ossid_zephyr_inconst_count(const float* rgbd, int H, int W, const float* transforms, int N,
+                               const float* tab, int M, float fx, float fy, float cx, float cy,
+                               float margin, int32_t* count, void* stream);
+int ossid_zephyr_featurize(const float* rgbd, int H, int W, const float* transforms, const int32_t* sel,
+                           int Nsel, const float* tab, int M, float fx, float fy, float cx, float cy,
+                           int interp, float* point_x, int32_t* uv_original, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Z3  zephyr.models.pointnet2.PointNet2SSG.forward({"point_x": ...})
+ *     ctor scripts/online_learning.py:212-227; call utils/zephyr_utils.py:34
+ * Stage entry points (pointnet2_ops: furthest_point_sample, ball_query) and the whole scorer.
+ * --------------------------------------------------------------------------------------------- */
+/* xyz [B][n][stride] (first 3 floats of each row) -> idx [B][npoint], new_xyz [B][npoint][3] */
+int ossid_pn2_fps(const float* xyz, int stride, int B, int n, int npoint, int32_t* idx, float* new_xyz,
+                  void* stream);
+/* idx [B][npoint][nsample], nsample must be 64 */
+int ossid_pn2_ball_query(const float* xyz, int stride, int B, int n, const float* new_xyz, int npoint,
+                         float radius, int nsample, int32_t* idx, void* stream);
+
+/* Packed weight blob (built on the host by ossid_code_amd.zephyr.pack_pn2_weights, uploaded once):
+ * float offsets into `blob` of the 12 layers' packed weights and biases, SPEC.md 4.3/4.4. */
+typedef struct ossid_pn2_weights {
+    const float* blob;
+    int64_t w_off[12];
+    int64_t b_off[12];
+    int64_t wxyz2_off; /* SA2 L1 xyz columns, [3][128] */
+    int32_t npoint1, npoint2; /* 512, 128 (npoint2 % 32 == 0, npoint1 % 32 == 0) */
+    float radius1, radius2;   /* 0.2, 0.4 */
+} ossid_pn2_weights;
+
+size_t ossid_pn2_workspace_bytes(int B, int M, int npoint1, int npoint2);
+
+/* point_x [B][M][8] -> scores [B]. workspace >= ossid_pn2_workspace_bytes(...), 256-byte aligned.
+ * dbg_* (all may be NULL) receive copies of stage results for parity tests:
+ * fps1 [B][np1] i32, ball1 [B][np1][64] i32, feat1 [B][np1][128], fps2 [B][np2] i32,
+ * ball2 [B][np2][64] i32, feat2 [B][np2][256], feat3 [B][1024]. */
+int ossid_pn2_score(const float* point_x, int B, int M, const ossid_pn2_weights* w, void* workspace,
+                    size_t workspace_bytes, float* scores, int32_t* dbg_fps1, int32_t* dbg_ball1,
+                    float* dbg_feat1, int32_t* dbg_fps2, int32_t* dbg_ball2, float* dbg_feat2,
+                    float* dbg_feat3, void* stream);
+
+/* Names of the kernels the scorer launches, for profile post-processing (static string). */
+const char* ossid_pn2_kernel_names(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSSID_HIP_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of libossid_hip.so (include/ossid_hip.h). There is no CPU fallback: if the library is
+missing, or a call returns a non-zero status, the caller gets an exception."""
+import ctypes as C
+import os
+
+import torch
+
+from ._build import LIB_PATH
+
+_lib = None
+
+OSSID_OK = 0
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class PN2Weights(C.Structure):
+    """struct ossid_pn2_weights (include/ossid_hip.h)."""
+    _fields_ = [("blob", _vp), ("w_off", C.c_int64 * 12), ("b_off", C.c_int64 * 12), ("wxyz2_off", C.c_int64),
+                ("npoint1", C.c_int32), ("npoint2", C.c_int32), ("radius1", _f), ("radius2", _f)]
+
+
+_PROTOS = {
+    "ossid_abi_version": (_i, [C.c_char_p, _i]),
+    "ossid_zephyr_prep_frame_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ossid_zephyr_prep_frame_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "ossid_zephyr_prep_model": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "ossid_zephyr_project_uv": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp]),
+    "ossid_zephyr_inconst_count": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp]),
+    "ossid_zephyr_featurize": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
+    "ossid_pn2_fps": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ossid_pn2_ball_query": (_i, [_vp, _i, _i, _i, _vp, _i, _f, _i, _vp, _vp]),
+    "ossid_pn2_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ossid_pn2_score": (_i, [_vp, _i, _i, C.POINTER(PN2Weights), _vp, _sz, _vp] + [_vp] * 7 + [_vp]),
+    "ossid_pn2_kernel_names": (C.c_char_p, []),
+}
+
+
+def exported_symbols():
+    """Names include/ossid_hip.h declares (kept in step by tests/test_abi.py)."""
+    return sorted(_PROTOS)
+
+
+def lib():
+    """The loaded library; raises if it has not been built (python -m ossid_code_amd._build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libossid_hip.so is missing (%s): build it with `python -m ossid_code_amd._build` or "
+                "__graft_entry__.build(); there is no CPU fallback for the OSSID hot path" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name, None)
+            if fn is None:
+                continue  # a later round's symbol not built yet; calling it raises in check()
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def fn(name):
+    f = getattr(lib(), name, None)
+    if f is None:
+        raise RuntimeError("libossid_hip.so does not export %s -- rebuild the library" % name)
+    return f
+
+
+def check(rc, what):
+    if rc != OSSID_OK:
+        raise RuntimeError("%s failed with status %d" % (what, rc))
+
+
+def ptr(t):
+    """Device (or host) address of a tensor / None."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("non-contiguous tensor passed across the C ABI")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("the OSSID hot path runs on the GPU only (got a %s tensor)" % t.device)

@@ -1,0 +1,764 @@
+// PointNet++ (SSG) hypothesis scorer for gfx950: furthest-point sampling, ball query, and the three
+// set-abstraction MLPs + FC head on the f32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Stands behind zephyr.models.pointnet2.PointNet2SSG.forward({"point_x": ...})
+// (ctor /root/reference/python/ossid/scripts/online_learning.py:212-227, call
+// utils/zephyr_utils.py:34); the algorithm is pointnet2_ops v3.0.0's, restated in SPEC.md 4 and
+// oracle/zephyr_oracle.c. Results are bit-identical to the oracle: each output is ONE fmaf chain
+// started from the folded bias, walking input channels in the canonical order (8-blocks
+// ascending, offsets 0,4,1,5,2,6,3,7) -- which is exactly what a chain of 32x32x2 f32 MFMAs
+// produces when lane half h supplies channel 8b+4h+i at step i: D = fma(a_k1,b_k1,fma(a_k0,b_k0,C)).
+//
+// MLP design (sa1/sa2/sa3/p2 kernels): samples sit on the MFMA N axis (lane&31), channels on M.
+// A layer's 32x32 accumulator tile IS the next layer's B operand (register r of lane half h holds
+// channel (r&3)+8(r>>2)+4h), so activations never leave the register file between layers: no LDS,
+// no barriers, 64-wide waves each carrying 32 samples. Weights are pre-packed on the host so one
+// coalesced 16-B load per lane feeds four MFMAs. The max-pool over a group's samples is a
+// butterfly reduce-scatter across the 32 lanes (16 shuffles per 32 channels).
+#include "common.h"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ v16f mfma(float a, float b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// accumulator tile initialised with the folded bias: register 4q+e of lane half h <- b[32mt+8q+4h+e]
+__device__ __forceinline__ v16f bias_tile(const float* __restrict__ b, int mt, int h) {
+    v16f acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 t = *(const float4*)(b + mt * 32 + 8 * q + 4 * h);
+        acc[4 * q + 0] = t.x;
+        acc[4 * q + 1] = t.y;
+        acc[4 * q + 2] = t.z;
+        acc[4 * q + 3] = t.w;
+    }
+    return acc;
+}
+
+__device__ __forceinline__ v16f relu16(v16f a) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = fmaxf(a[i], 0.0f);
+    return a;
+}
+
+__device__ __forceinline__ v16f max16(v16f a, v16f b) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = fmaxf(a[i], b[i]);
+    return a;
+}
+
+// Launder a (wave-uniform) pointer once per loop iteration: without it LICM hoists every weight load of a
+// fully unrolled layer out of the enclosing tile/centre loop -- the whole weight set -- and spills it.
+template <class T>
+__device__ __forceinline__ const T* opaque(const T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// four chained MFMAs: one packed weight quad against registers 4q..4q+3 of an activation tile
+__device__ __forceinline__ v16f mfma4(float4 a, const v16f& x, int q4, v16f acc) {
+    acc = mfma(a.x, x[q4 + 0], acc);
+    acc = mfma(a.y, x[q4 + 1], acc);
+    acc = mfma(a.z, x[q4 + 2], acc);
+    acc = mfma(a.w, x[q4 + 3], acc);
+    return acc;
+}
+
+// ---- weight streaming --------------------------------------------------------------------------------
+// A layer's packed weights are one linear sequence of "quads" (a float4 per lane = the A operands of four
+// chained MFMAs), ordered [m-tile][k-block]. hipcc left alone hoists every load of a fully unrolled
+// layer to the top and spills hundreds of registers, so the stream is cut into groups of G quads with
+// an explicit two-deep register pipeline: group g+1 is loaded while group g feeds the matrix core, and a
+// sched_barrier between groups keeps the compiler from re-merging them (G quads = 4G MFMAs = 256G cycles
+// of matrix work cover the L2 latency of the next group's loads).
+
+// Fully unrolled form for layers whose output tiles stay in registers (Y[t][mt] statically indexed).
+template <int KT, int MT, int NT, int G, class Epi>
+__device__ __forceinline__ void stream_layer(const float4* __restrict__ W4, const float* __restrict__ bias,
+                                             const v16f (&X)[NT][KT], int h, Epi&& epi) {
+    constexpr int QPM = KT * 4, TOTAL = MT * QPM, NG = TOTAL / G;
+    static_assert(TOTAL % G == 0, "group size must divide the quad count");
+    float4 cur[G], nxt[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) cur[i] = W4[(size_t)i * 64];
+    v16f acc[NT];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) nxt[i] = W4[(size_t)((g + 1) * G + i) * 64];
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int quad = g * G + i, mt = quad / QPM, kq = quad % QPM, kt = kq / 4, q = kq % 4;
+            if (kq == 0) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = bias_tile(bias, mt, h);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma4(cur[i], X[t][kt], 4 * q, acc[t]);
+            if (kq == QPM - 1) epi(mt, acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i) cur[i] = nxt[i];
+    }
+}
+
+// Rolled-over-m-tiles form for a group's LAST layer: each 32-channel output tile is consumed (max-pooled)
+// as soon as it is complete, so only one accumulator tile per column tile is live and mt may be dynamic.
+template <int KT, int NT, int G, class Epi>
+__device__ __forceinline__ void stream_layer_rolled(const float4* __restrict__ W4, const float* __restrict__ bias,
+                                                    const v16f (&X)[NT][KT], int h, int MT, Epi&& epi) {
+    constexpr int QPM = KT * 4, NG = QPM / G;
+    static_assert(QPM % G == 0, "group size must divide the quads per m-tile");
+    const int last = MT * QPM - 1;
+    float4 cur[G], nxt[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) cur[i] = W4[(size_t)i * 64];
+#pragma unroll 1
+    for (int mt = 0; mt < MT; ++mt) {
+        v16f acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = bias_tile(bias, mt, h);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                int nq = mt * QPM + (g + 1) * G + i;  // next group, possibly the next m-tile's first
+                nq = nq > last ? last : nq;
+                nxt[i] = W4[(size_t)nq * 64];
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int kq = g * G + i, kt = kq / 4, q = kq % 4;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma4(cur[i], X[t][kt], 4 * q, acc[t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < G; ++i) cur[i] = nxt[i];
+        }
+        epi(mt, acc);
+    }
+}
+
+// Max over the 32 columns (lanes of one half) of each of the 16 rows of an accumulator tile.
+// Returns, in lane i = lane&31, the maximum of register r(i) = 8*b4 + 4*b3 + 2*b2 + b1 (bits of i);
+// lanes i and i^1 hold the same value. 16 shuffles instead of 80.
+__device__ __forceinline__ float reduce_scatter_max(const v16f& v, int lane) {
+    float w[8], x[4], y[2], z;
+    const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float send = b4 ? v[j] : v[j + 8];
+        float keep = b4 ? v[j + 8] : v[j];
+        w[j] = fmaxf(keep, __shfl_xor(send, 16));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float send = b3 ? w[j] : w[j + 4];
+        float keep = b3 ? w[j + 4] : w[j];
+        x[j] = fmaxf(keep, __shfl_xor(send, 8));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float send = b2 ? x[j] : x[j + 2];
+        float keep = b2 ? x[j + 2] : x[j];
+        y[j] = fmaxf(keep, __shfl_xor(send, 4));
+    }
+    {
+        float send = b1 ? y[0] : y[1];
+        float keep = b1 ? y[1] : y[0];
+        z = fmaxf(keep, __shfl_xor(send, 2));
+    }
+    z = fmaxf(z, __shfl_xor(z, 1));
+    return z;
+}
+
+// channel (within a 32-row tile) that reduce_scatter_max leaves in this lane
+__device__ __forceinline__ int scatter_row(int lane) {
+    int i = lane & 31, h = lane >> 5;
+    int r = ((i >> 4) & 1) * 8 + ((i >> 3) & 1) * 4 + ((i >> 2) & 1) * 2 + ((i >> 1) & 1);
+    return (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+
+// ---- furthest point sampling: one workgroup per point set -----------------------------------------
+// LDS: pts[n] = (x,y,z,|p|^2), tmp[n] running min distance. One barrier per pick: the four waves'
+// (best, index) pairs go through a double-buffered 4-entry LDS slot.
+__global__ __launch_bounds__(256) void fps_kernel(const float* __restrict__ xyz, int stride, int n, int npoint,
+                                                  int* __restrict__ idx_out, float* __restrict__ new_xyz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* pts = (float4*)smem;
+    float* tmp = (float*)(pts + n);
+    __shared__ float rbest[2][4];
+    __shared__ int rbesti[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* base = xyz + (size_t)blockIdx.x * n * stride;
+    for (int k = tid; k < n; k += 256) {
+        float x = base[(size_t)k * stride], y = base[(size_t)k * stride + 1], z = base[(size_t)k * stride + 2];
+        pts[k] = make_float4(x, y, z, (x * x + y * y) + z * z);
+        tmp[k] = 1e10f;
+    }
+    __syncthreads();
+    int old = 0;
+    int* io = idx_out + (size_t)blockIdx.x * npoint;
+    float* xo = new_xyz + (size_t)blockIdx.x * npoint * 3;
+    if (tid == 0) {
+        io[0] = 0;
+        xo[0] = pts[0].x;
+        xo[1] = pts[0].y;
+        xo[2] = pts[0].z;
+    }
+    for (int j = 1; j < npoint; ++j) {
+        const float4 po = pts[old];
+        float best = -1.0f;
+        int besti = 0;
+        for (int k = tid; k < n; k += 256) {
+            float4 p = pts[k];
+            if (p.w <= 1e-3f) continue;
+            float dx = p.x - po.x, dy = p.y - po.y, dz = p.z - po.z;
+            float d = (dx * dx + dy * dy) + dz * dz;
+            float d2 = fminf(d, tmp[k]);
+            tmp[k] = d2;
+            if (d2 > best) {
+                best = d2;
+                besti = k;
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            float ob = __shfl_xor(best, m);
+            int oi = __shfl_xor(besti, m);
+            if (ob > best || (ob == best && oi < besti)) {
+                best = ob;
+                besti = oi;
+            }
+        }
+        const int buf = j & 1;
+        if (lane == 0) {
+            rbest[buf][wave] = best;
+            rbesti[buf][wave] = besti;
+        }
+        __syncthreads();
+        best = rbest[buf][0];
+        besti = rbesti[buf][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            float ob = rbest[buf][w];
+            int oi = rbesti[buf][w];
+            if (ob > best || (ob == best && oi < besti)) {
+                best = ob;
+                besti = oi;
+            }
+        }
+        old = besti;
+        if (tid == 0) {
+            io[j] = old;
+            float4 p = pts[old];
+            xo[3 * j] = p.x;
+            xo[3 * j + 1] = p.y;
+            xo[3 * j + 2] = p.z;
+        }
+    }
+}
+
+// ---- ball query: one wave per centre, 64 candidate points per ballot -------------------------------
+constexpr int BQ_CPB = 64;  // centres per workgroup
+__global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ xyz, int stride, int n,
+                                                         const float* __restrict__ new_xyz, int npoint, float r2,
+                                                         int* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* pts = (float4*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float* base = xyz + (size_t)b * n * stride;
+    for (int k = tid; k < n; k += 256)
+        pts[k] = make_float4(base[(size_t)k * stride], base[(size_t)k * stride + 1], base[(size_t)k * stride + 2], 0.f);
+    __syncthreads();
+    const int jend = min((int)(blockIdx.y + 1) * BQ_CPB, npoint);
+    for (int j = blockIdx.y * BQ_CPB + wave; j < jend; j += 4) {
+        const float* c = new_xyz + ((size_t)b * npoint + j) * 3;
+        const float cx = c[0], cy = c[1], cz = c[2];
+        int* o = idx + ((size_t)b * npoint + j) * 64;
+        int cnt = 0, first = -1;
+        for (int k0 = 0; k0 < n && cnt < 64; k0 += 64) {
+            const int k = k0 + lane;
+            bool hit = false;
+            if (k < n) {
+                float4 p = pts[k];
+                float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
+                float d2 = (dx * dx + dy * dy) + dz * dz;
+                hit = d2 < r2;
+            }
+            const unsigned long long bal = __ballot(hit);
+            if (bal) {
+                if (first < 0) first = k0 + __ffsll((long long)bal) - 1;
+                int slot = cnt + __popcll(bal & ((1ull << lane) - 1ull));
+                if (hit && slot < 64) o[slot] = k;
+                cnt += __popcll(bal);
+            }
+        }
+        if (first < 0) first = 0;
+        if (lane >= cnt) o[lane] = first;
+    }
+}
+
+// ---- SA1: gather (K=8) -> 64 -> 64 -> 128 -> max over the group's 64 samples -------------------------
+// One wave per centre; both 32-sample column tiles ride together so every weight quad feeds 8 MFMAs.
+constexpr int SA1_CPW = 4;  // centres per wave
+__global__ __launch_bounds__(256, 2) void sa1_kernel(const float* __restrict__ point_x, int M,
+                                                     const int* __restrict__ ball, const float* __restrict__ cxyz,
+                                                     int np, int total, const float* __restrict__ W1p,
+                                                     const float* __restrict__ b1, const float* __restrict__ W2p,
+                                                     const float* __restrict__ b2, const float* __restrict__ W3p,
+                                                     const float* __restrict__ b3, float* __restrict__ feat) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
+    const int row = scatter_row(lane);
+#pragma unroll 1
+    for (int cw = 0; cw < SA1_CPW; ++cw) {
+        const int centre = (blockIdx.x * 4 + wave) * SA1_CPW + cw;
+        if (centre >= total) break;
+        const int n = centre / np;
+        const float cx = cxyz[(size_t)centre * 3], cy = cxyz[(size_t)centre * 3 + 1], cz = cxyz[(size_t)centre * 3 + 2];
+        W1p = opaque(W1p), W2p = opaque(W2p), W3p = opaque(W3p);
+        b1 = opaque(b1), b2 = opaque(b2), b3 = opaque(b3);
+        float4 x[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int i = ball[(size_t)centre * 64 + t * 32 + c];
+            float4 r = *(const float4*)(point_x + ((size_t)n * M + i) * 8 + 4 * h);
+            if (h == 0) {
+                r.x = r.x - cx;
+                r.y = r.y - cy;
+                r.z = r.z - cz;
+            }
+            x[t] = r;
+        }
+        v16f Y1[2][2], Y2[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float4 a = ((const float4*)W1p)[mt * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                v16f acc = bias_tile(b1, mt, h);
+                acc = mfma(a.x, x[t].x, acc);
+                acc = mfma(a.y, x[t].y, acc);
+                acc = mfma(a.z, x[t].z, acc);
+                acc = mfma(a.w, x[t].w, acc);
+                Y1[t][mt] = relu16(acc);
+            }
+        }
+        stream_layer<2, 2, 2, 8>((const float4*)W2p + lane, b2, Y1, h, [&](int mt, v16f(&acc)[2]) {
+            Y2[0][mt] = relu16(acc[0]);
+            Y2[1][mt] = relu16(acc[1]);
+        });
+        float* out = feat + (size_t)centre * 128 + row;
+        stream_layer_rolled<2, 2, 8>((const float4*)W3p + lane, b3, Y2, h, 4, [&](int mt, v16f(&acc)[2]) {
+            float r = reduce_scatter_max(relu16(max16(acc[0], acc[1])), lane);
+            if ((lane & 1) == 0) out[mt * 32] = r;
+        });
+    }
+}
+
+// ---- P2: per-point part of SA2's first layer: p[pt][o] = chain(bias, W[:, :128] . feat1[pt]) ----------
+// (the grouped-xyz columns are applied per sample in sa2_kernel, continuing the same chain)
+__global__ __launch_bounds__(256, 2) void p2_kernel(const float* __restrict__ feat, int total_tiles,
+                                                    const float* __restrict__ Wp, const float* __restrict__ bias,
+                                                    float* __restrict__ P) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
+    const int tile0 = (blockIdx.x * 4 + wave) * 2;
+    if (tile0 >= total_tiles) return;
+    const bool two = tile0 + 1 < total_tiles;
+    v16f X[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int pt = (tile0 + ((t == 1 && two) ? 1 : 0)) * 32 + c;
+        const float* r = feat + (size_t)pt * 128 + 4 * h;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = *(const float4*)(r + kt * 32 + 8 * q);
+                X[t][kt][4 * q + 0] = v.x;
+                X[t][kt][4 * q + 1] = v.y;
+                X[t][kt][4 * q + 2] = v.z;
+                X[t][kt][4 * q + 3] = v.w;
+            }
+    }
+    float* o0 = P + (size_t)(tile0 * 32 + c) * 128 + 4 * h;
+    stream_layer_rolled<4, 2, 8>((const float4*)Wp + lane, bias, X, h, 4, [&](int mt, v16f(&acc)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t == 1 && !two) break;
+            float* o = o0 + (size_t)t * 32 * 128 + mt * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(float4*)(o + 8 * q) =
+                    make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+        }
+    });
+}
+
+// ---- SA2: (P gather + xyz columns) -> relu -> 128 -> 256 -> max over 64 samples ----------------------
+// One wave per centre, its two 32-sample column tiles one after the other (a tile holds 64 + 64
+// activation registers); the first tile's pooled maxima wait in the output row and are merged by the
+// same lane when the second tile is done.
+constexpr int SA2_CPW = 2;
+__global__ __launch_bounds__(256, 2) void sa2_kernel(const float* __restrict__ P, const float* __restrict__ xyz1,
+                                                     int np1, const int* __restrict__ ball,
+                                                     const float* __restrict__ cxyz, int np2, int total,
+                                                     const float* __restrict__ wxyz, const float* __restrict__ W2p,
+                                                     const float* __restrict__ b2, const float* __restrict__ W3p,
+                                                     const float* __restrict__ b3, float* __restrict__ feat) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
+    const int row = scatter_row(lane);
+#pragma unroll 1
+    for (int cw = 0; cw < SA2_CPW; ++cw) {
+        const int centre = (blockIdx.x * 4 + wave) * SA2_CPW + cw;
+        if (centre >= total) break;
+        const int n = centre / np2;
+        const float cx = cxyz[(size_t)centre * 3], cy = cxyz[(size_t)centre * 3 + 1], cz = cxyz[(size_t)centre * 3 + 2];
+        float* out = feat + (size_t)centre * 256 + row;
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+            wxyz = opaque(wxyz), W2p = opaque(W2p), W3p = opaque(W3p), b2 = opaque(b2), b3 = opaque(b3);
+            const int i = ball[(size_t)centre * 64 + t * 32 + c];
+            const size_t pt = (size_t)n * np1 + i;
+            const float dx = xyz1[pt * 3] - cx, dy = xyz1[pt * 3 + 1] - cy, dz = xyz1[pt * 3 + 2] - cz;
+            v16f X1[1][4], Y2[1][4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int off = kt * 32 + 8 * q + 4 * h;
+                    float4 p = *(const float4*)(P + pt * 128 + off);
+                    float4 wx = *(const float4*)(wxyz + off), wy = *(const float4*)(wxyz + 128 + off),
+                           wz = *(const float4*)(wxyz + 256 + off);
+                    X1[0][kt][4 * q + 0] = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, p.x))), 0.0f);
+                    X1[0][kt][4 * q + 1] = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, p.y))), 0.0f);
+                    X1[0][kt][4 * q + 2] = fmaxf(fmaf(wz.z, dz, fmaf(wy.z, dy, fmaf(wx.z, dx, p.z))), 0.0f);
+                    X1[0][kt][4 * q + 3] = fmaxf(fmaf(wz.w, dz, fmaf(wy.w, dy, fmaf(wx.w, dx, p.w))), 0.0f);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            stream_layer<4, 4, 1, 8>((const float4*)W2p + lane, b2, X1, h,
+                                     [&](int mt, v16f(&acc)[1]) { Y2[0][mt] = relu16(acc[0]); });
+            stream_layer_rolled<4, 1, 8>((const float4*)W3p + lane, b3, Y2, h, 8, [&](int mt, v16f(&acc)[1]) {
+                float r = reduce_scatter_max(relu16(acc[0]), lane);
+                if ((lane & 1) == 0) {
+                    if (t == 1) r = fmaxf(r, out[mt * 32]);
+                    out[mt * 32] = r;
+                }
+            });
+        }
+    }
+}
+
+// ---- SA3 (GroupAll): (feat2, xyz2) K=264 -> 256 -> 512 -> 1024 -> max over all np2 points -----------
+// One workgroup per hypothesis, one 32-point column tile per wave at a time, one wave per SIMD
+// (the 256->512 layer keeps 128 + 256 accumulator registers live).
+__global__ __launch_bounds__(256, 1) void sa3_kernel(const float* __restrict__ feat2, const float* __restrict__ xyz2,
+                                                     int np2, const float* __restrict__ W1p,
+                                                     const float* __restrict__ b1, const float* __restrict__ W2p,
+                                                     const float* __restrict__ b2, const float* __restrict__ W3p,
+                                                     const float* __restrict__ b3, float* __restrict__ feat3) {
+    __shared__ float red[4][1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int row = scatter_row(lane);
+    const int n = blockIdx.x;
+    for (int i = tid; i < 4096; i += 256) (&red[0][0])[i] = -INFINITY;
+    __syncthreads();
+    const int ntiles = np2 / 32;
+#pragma unroll 1
+    for (int t = wave; t < ntiles; t += 4) {
+        W1p = opaque(W1p), W2p = opaque(W2p), W3p = opaque(W3p);
+        b1 = opaque(b1), b2 = opaque(b2), b3 = opaque(b3);
+        const size_t pt = (size_t)n * np2 + t * 32 + c;
+        const float* r = feat2 + pt * 256 + 4 * h;
+        v16f Y1[1][8], Y2[1][16];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) Y1[0][mt] = bias_tile(b1, mt, h);
+        // first layer, k-outer: one activation quad (this lane's 4 channels of block kb) against the
+        // eight output tiles; weights [8][33][64][4]. Two-deep pipeline over kb like stream_layer.
+        const float4* W4 = (const float4*)W1p + lane;
+        float4 bc = *(const float4*)(r), bn;
+        float4 ac[8], an[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) ac[mt] = W4[(size_t)(mt * 33) * 64];
+#pragma unroll 1
+        for (int kb = 0; kb < 33; ++kb) {
+            const int kn = kb + 1 < 33 ? kb + 1 : 32;
+            if (kn < 32) {
+                bn = *(const float4*)(r + 8 * kn);
+            } else {  // the (x, y, z, 0 | 0, 0, 0, 0) block
+                bn = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (h == 0) {
+                    bn.x = xyz2[pt * 3];
+                    bn.y = xyz2[pt * 3 + 1];
+                    bn.z = xyz2[pt * 3 + 2];
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) an[mt] = W4[(size_t)(mt * 33 + kn) * 64];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                Y1[0][mt] = mfma(ac[mt].x, bc.x, Y1[0][mt]);
+                Y1[0][mt] = mfma(ac[mt].y, bc.y, Y1[0][mt]);
+                Y1[0][mt] = mfma(ac[mt].z, bc.z, Y1[0][mt]);
+                Y1[0][mt] = mfma(ac[mt].w, bc.w, Y1[0][mt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bc = bn;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) ac[mt] = an[mt];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) Y1[0][mt] = relu16(Y1[0][mt]);
+        stream_layer<8, 16, 1, 4>((const float4*)W2p + lane, b2, Y1, h,
+                                  [&](int mt, v16f(&acc)[1]) { Y2[0][mt] = relu16(acc[0]); });
+        stream_layer_rolled<16, 1, 8>((const float4*)W3p + lane, b3, Y2, h, 32, [&](int mt, v16f(&acc)[1]) {
+            float v = reduce_scatter_max(relu16(acc[0]), lane);
+            if ((lane & 1) == 0) {
+                float* s = &red[wave][mt * 32 + row];
+                *s = fmaxf(*s, v);
+            }
+        });
+    }
+    __syncthreads();
+    for (int o = tid; o < 1024; o += 256)
+        feat3[(size_t)n * 1024 + o] = fmaxf(fmaxf(red[0][o], red[1][o]), fmaxf(red[2][o], red[3][o]));
+}
+
+// ---- FC head 1024 -> 512 -> 256 -> 1, eight hypotheses per workgroup ---------------------------------
+// Weights are stored transposed [k][cout] so a wave's loads are contiguous; activations sit in LDS.
+constexpr int FC_HB = 8;
+__device__ __forceinline__ int canon(int e) { return (e >> 1) + 4 * (e & 1); }  // 0,4,1,5,2,6,3,7
+
+__global__ __launch_bounds__(256) void fc_head_kernel(const float* __restrict__ feat3, int B,
+                                                      const float* __restrict__ Wt1, const float* __restrict__ bb1,
+                                                      const float* __restrict__ Wt2, const float* __restrict__ bb2,
+                                                      const float* __restrict__ W3, const float* __restrict__ bb3,
+                                                      float* __restrict__ scores) {
+    __shared__ float x[FC_HB][1024];
+    __shared__ float h1[FC_HB][512];
+    __shared__ float h2[FC_HB][256];
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * FC_HB;
+    for (int i = tid; i < FC_HB * 1024; i += 256) {
+        int hb = i >> 10, k = i & 1023;
+        x[hb][k] = (b0 + hb < B) ? feat3[(size_t)(b0 + hb) * 1024 + k] : 0.0f;
+    }
+    __syncthreads();
+    {
+        float acc[2][FC_HB];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int hb = 0; hb < FC_HB; ++hb) acc[j][hb] = bb1[tid + 256 * j];
+        for (int kb = 0; kb < 1024; kb += 8)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = kb + canon(e);
+                const float w0 = Wt1[(size_t)k * 512 + tid], w1 = Wt1[(size_t)k * 512 + tid + 256];
+#pragma unroll
+                for (int hb = 0; hb < FC_HB; ++hb) {
+                    const float xv = x[hb][k];
+                    acc[0][hb] = fmaf(w0, xv, acc[0][hb]);
+                    acc[1][hb] = fmaf(w1, xv, acc[1][hb]);
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int hb = 0; hb < FC_HB; ++hb) h1[hb][tid + 256 * j] = fmaxf(acc[j][hb], 0.0f);
+    }
+    __syncthreads();
+    {
+        float acc[FC_HB];
+#pragma unroll
+        for (int hb = 0; hb < FC_HB; ++hb) acc[hb] = bb2[tid];
+        for (int kb = 0; kb < 512; kb += 8)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = kb + canon(e);
+                const float w = Wt2[(size_t)k * 256 + tid];
+#pragma unroll
+                for (int hb = 0; hb < FC_HB; ++hb) acc[hb] = fmaf(w, h1[hb][k], acc[hb]);
+            }
+#pragma unroll
+        for (int hb = 0; hb < FC_HB; ++hb) h2[hb][tid] = fmaxf(acc[hb], 0.0f);
+    }
+    __syncthreads();
+    if (tid < FC_HB && b0 + tid < B) {
+        float acc = bb3[0];
+        for (int kb = 0; kb < 256; kb += 8)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = kb + canon(e);
+                acc = fmaf(W3[k], h2[tid][k], acc);
+            }
+        scores[b0 + tid] = acc;
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Workspace {
+    int* fps1;
+    float* xyz1;
+    int* ball1;
+    float* feat1;
+    float* p2;
+    int* fps2;
+    float* xyz2;
+    int* ball2;
+    float* feat2;
+    float* feat3;
+    size_t bytes;
+};
+
+Workspace carve(char* base, int B, int M, int np1, int np2) {
+    (void)M;
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        char* p = base ? base + off : nullptr;
+        off += align256(n);
+        return p;
+    };
+    w.fps1 = (int*)take((size_t)B * np1 * 4);
+    w.xyz1 = (float*)take((size_t)B * np1 * 12);
+    w.ball1 = (int*)take((size_t)B * np1 * 64 * 4);
+    w.feat1 = (float*)take((size_t)B * np1 * 128 * 4);
+    w.p2 = (float*)take((size_t)B * np1 * 128 * 4);
+    w.fps2 = (int*)take((size_t)B * np2 * 4);
+    w.xyz2 = (float*)take((size_t)B * np2 * 12);
+    w.ball2 = (int*)take((size_t)B * np2 * 64 * 4);
+    w.feat2 = (float*)take((size_t)B * np2 * 256 * 4);
+    w.feat3 = (float*)take((size_t)B * 1024 * 4);
+    w.bytes = off;
+    return w;
+}
+
+int launch_fps(const float* xyz, int stride, int B, int n, int npoint, int* idx, float* new_xyz, hipStream_t s) {
+    size_t lds = (size_t)n * 20;
+    if (lds > 160 * 1024 - 1024) return OSSID_EINVAL;
+    if (lds > 48 * 1024)
+        if (hipFuncSetAttribute((const void*)fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return OSSID_ELAUNCH;
+    hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(256), lds, s, xyz, stride, n, npoint, idx, new_xyz);
+    return ossid_launch_status();
+}
+
+int launch_ball(const float* xyz, int stride, int B, int n, const float* new_xyz, int npoint, float radius, int* idx,
+                hipStream_t s) {
+    size_t lds = (size_t)n * 16;
+    if (lds > 160 * 1024 - 1024) return OSSID_EINVAL;
+    if (lds > 48 * 1024)
+        if (hipFuncSetAttribute((const void*)ball_query_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return OSSID_ELAUNCH;
+    const float r2 = radius * radius;
+    hipLaunchKernelGGL(ball_query_kernel, dim3(B, (npoint + BQ_CPB - 1) / BQ_CPB), dim3(256), lds, s, xyz, stride, n,
+                       new_xyz, npoint, r2, idx);
+    return ossid_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int ossid_pn2_fps(const float* xyz, int stride, int B, int n, int npoint, int32_t* idx, float* new_xyz,
+                  void* stream) {
+    if (B < 0 || n <= 0 || npoint <= 0 || stride < 3) return OSSID_EINVAL;
+    if (B == 0) return OSSID_OK;
+    if (!xyz || !idx || !new_xyz) return OSSID_EINVAL;
+    return launch_fps(xyz, stride, B, n, npoint, idx, new_xyz, (hipStream_t)stream);
+}
+
+int ossid_pn2_ball_query(const float* xyz, int stride, int B, int n, const float* new_xyz, int npoint, float radius,
+                         int nsample, int32_t* idx, void* stream) {
+    if (B < 0 || n <= 0 || npoint <= 0 || stride < 3 || nsample != 64) return OSSID_EINVAL;
+    if (B == 0) return OSSID_OK;
+    if (!xyz || !idx || !new_xyz) return OSSID_EINVAL;
+    return launch_ball(xyz, stride, B, n, new_xyz, npoint, radius, idx, (hipStream_t)stream);
+}
+
+size_t ossid_pn2_workspace_bytes(int B, int M, int npoint1, int npoint2) {
+    if (B <= 0) return 256;
+    return carve(nullptr, B, M, npoint1, npoint2).bytes;
+}
+
+const char* ossid_pn2_kernel_names(void) {
+    return "fps_kernel,ball_query_kernel,sa1_kernel,p2_kernel,sa2_kernel,sa3_kernel,fc_head_kernel";
+}
+
+int ossid_pn2_score(const float* point_x, int B, int M, const ossid_pn2_weights* w, void* workspace,
+                    size_t workspace_bytes, float* scores, int32_t* dbg_fps1, int32_t* dbg_ball1, float* dbg_feat1,
+                    int32_t* dbg_fps2, int32_t* dbg_ball2, float* dbg_feat2, float* dbg_feat3, void* stream) {
+    if (B < 0 || !w) return OSSID_EINVAL;
+    if (B == 0) return OSSID_OK;
+    const int np1 = w->npoint1, np2 = w->npoint2;
+    if (!point_x || !scores || !workspace || !w->blob) return OSSID_EINVAL;
+    if (np1 <= 0 || np2 <= 0 || np1 % 32 || np2 % 32 || M < np1 || np1 < np2) return OSSID_EINVAL;
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)point_x & 15)) return OSSID_EINVAL;
+    Workspace ws = carve((char*)workspace, B, M, np1, np2);
+    if (ws.bytes > workspace_bytes) return OSSID_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const float* blob = w->blob;
+    auto W = [&](int i) { return blob + w->w_off[i]; };
+    auto Bv = [&](int i) { return blob + w->b_off[i]; };
+    int rc;
+
+    // SA1
+    if ((rc = launch_fps(point_x, 8, B, M, np1, ws.fps1, ws.xyz1, s))) return rc;
+    if ((rc = launch_ball(point_x, 8, B, M, ws.xyz1, np1, w->radius1, ws.ball1, s))) return rc;
+    {
+        const int total = B * np1;
+        const int grid = (total + 4 * SA1_CPW - 1) / (4 * SA1_CPW);
+        hipLaunchKernelGGL(sa1_kernel, dim3(grid), dim3(256), 0, s, point_x, M, ws.ball1, ws.xyz1, np1, total, W(0),
+                           Bv(0), W(1), Bv(1), W(2), Bv(2), ws.feat1);
+        if ((rc = ossid_launch_status())) return rc;
+    }
+    // SA2
+    {
+        const int tiles = B * np1 / 32;
+        hipLaunchKernelGGL(p2_kernel, dim3((tiles + 7) / 8), dim3(256), 0, s, ws.feat1, tiles, W(3), Bv(3), ws.p2);
+        if ((rc = ossid_launch_status())) return rc;
+    }
+    if ((rc = launch_fps(ws.xyz1, 3, B, np1, np2, ws.fps2, ws.xyz2, s))) return rc;
+    if ((rc = launch_ball(ws.xyz1, 3, B, np1, ws.xyz2, np2, w->radius2, ws.ball2, s))) return rc;
+    {
+        const int total = B * np2;
+        const int grid = (total + 4 * SA2_CPW - 1) / (4 * SA2_CPW);
+        hipLaunchKernelGGL(sa2_kernel, dim3(grid), dim3(256), 0, s, ws.p2, ws.xyz1, np1, ws.ball2, ws.xyz2, np2,
+                           total, blob + w->wxyz2_off, W(4), Bv(4), W(5), Bv(5), ws.feat2);
+        if ((rc = ossid_launch_status())) return rc;
+    }
+    // SA3 + FC head
+    hipLaunchKernelGGL(sa3_kernel, dim3(B), dim3(256), 0, s, ws.feat2, ws.xyz2, np2, W(6), Bv(6), W(7), Bv(7), W(8),
+                       Bv(8), ws.feat3);
+    if ((rc = ossid_launch_status())) return rc;
+    hipLaunchKernelGGL(fc_head_kernel, dim3((B + FC_HB - 1) / FC_HB), dim3(256), 0, s, ws.feat3, B, W(9), Bv(9),
+                       W(10), Bv(10), W(11), Bv(11), scores);
+    if ((rc = ossid_launch_status())) return rc;
+
+    auto cp = [&](void* dst, const void* src, size_t n) {
+        if (dst && hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = OSSID_ELAUNCH;
+    };
+    cp(dbg_fps1, ws.fps1, (size_t)B * np1 * 4);
+    cp(dbg_ball1, ws.ball1, (size_t)B * np1 * 64 * 4);
+    cp(dbg_feat1, ws.feat1, (size_t)B * np1 * 128 * 4);
+    cp(dbg_fps2, ws.fps2, (size_t)B * np2 * 4);
+    cp(dbg_ball2, ws.ball2, (size_t)B * np2 * 64 * 4);
+    cp(dbg_feat2, ws.feat2, (size_t)B * np2 * 256 * 4);
+    cp(dbg_feat3, ws.feat3, (size_t)B * 1024 * 4);
+    return rc;
+}
+
+}  // extern "C"
