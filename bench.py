@@ -1,0 +1,193 @@
+"""bench.py -- OSSID hot-path benchmark on MI355X (contract: see the task statement / DESIGN.md section 6).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one frame of Zephyr hypothesis scoring, BASELINE.json configs[1]: 1000 pose hypotheses x 2048 model
+points against a synthetic 640x480 RGB-D frame -- stage the frame (5x5 blur, /255, RGB-D interleave), build the
+model table, project + gather + featurize every (hypothesis, point), and score with PointNet2SSG; inputs are
+already resident in HBM when the timed region starts, scores stay on the device (one sync after the K steps).
+Frames shard across ranks with no data-path collective ("weak" scaling): every rank scores its own frame.
+
+The JSON line also carries
+  roofline      the dominant kernel's achieved rate (HIP events recorded around it inside the timed steps),
+  cpu_baseline  the CPU oracle (oracle/, a port of the same algorithm: kind "port") timed on the host cores on a
+                bounded sample of the same workload, rank 0 / N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_HYP, N_PTS, IMG_H, IMG_W = 1000, 2048, 480, 640
+PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md, Chip-level parameters
+PEAK_HBM_GBS = 8000.0
+
+# algorithmic flops per hypothesis of each MFMA stage (2 x MACs)
+SA1_FLOPS = 2.0 * 512 * 64 * (8 * 64 + 64 * 64 + 64 * 128)
+P2_FLOPS = 2.0 * 512 * 128 * 128
+SA2_FLOPS = 2.0 * 128 * 64 * (3 * 128 + 128 * 128 + 128 * 256)
+SA3_FLOPS = 2.0 * 128 * (259 * 256 + 256 * 512 + 512 * 1024)
+FC_FLOPS = 2.0 * (1024 * 512 + 512 * 256 + 256)
+STAGE_FLOPS = {"sa1": SA1_FLOPS, "p2": P2_FLOPS, "sa2": SA2_FLOPS, "sa3": SA3_FLOPS, "fc": FC_FLOPS}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample", type=int, default=192, help="hypotheses in the CPU-oracle sample")
+    return p.parse_args()
+
+
+class Args:
+    dataset, no_valid_proj, no_valid_depth, inconst_ratio_th, extra_bottleneck_dim = \
+        "HSVD_diff_uv_norm", True, True, 100, 0
+
+
+def cpu_baseline(d, model, sample):
+    """The oracle on the host cores, same workload, `sample` hypotheses (about 10-30 s of CPU work)."""
+    from oracle import zephyr_oracle as ozr
+    from ossid_code_amd.zephyr.pointnet2 import fold_pn2
+    # the GPU box hands one GPU a 16-core CPU share; use at most that many OpenMP threads (and say how many)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    cores = ozr.set_threads(min(avail, 16))
+    w = fold_pn2(model)
+    T = d["pose_hypos"][:sample].astype(np.float32)
+    t0 = time.time()
+    rgbd = ozr.pack_rgbd(ozr.u8_to_unit(ozr.blur5_u8(d["img"])), d["depth"])
+    tab = ozr.prep_model(d["model_points"], d["model_normals"], d["model_colors"])
+    px, uv = ozr.featurize(rgbd, T, tab, d["cam_K"])
+    t1 = time.time()
+    scores = ozr.pn2_score(px, w)
+    t2 = time.time()
+    return {"value": sample / (t2 - t0), "unit": "hyp/s", "cores": int(cores), "kind": "port",
+            "sample": "%d of the %d hypotheses of the same frame (x %d points): blur+featurize %.2f s, PointNet2SSG "
+                      "%.2f s; C/OpenMP oracle, AVX2 fmaf chains" % (sample, N_HYP, N_PTS, t1 - t0, t2 - t1)}, scores
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py measures the GPU path; no GPU is visible"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from ossid_code_amd import _build, _lib, synth, zephyr
+    if rank == 0:
+        _build.build_lib()
+    if dist is not None:
+        dist.barrier()
+
+    # every rank gets its own frame + hypothesis set (frames shard across GPUs)
+    d = synth.make_scoring_inputs(N=N_HYP, M=N_PTS, seed=42 + rank, H=IMG_H, W=IMG_W)
+    model = synth.random_pn2_state(zephyr.PointNet2SSG(8, Args(), num_class=1), 0).eval()
+
+    base, base_scores = None, None
+    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+        base, base_scores = cpu_baseline(d, model, a.cpu_sample)
+
+    model = model.to(dev)
+    img = torch.from_numpy(d["img"]).to(dev)
+    depth = torch.from_numpy(d["depth"]).to(dev)
+    T = torch.from_numpy(d["pose_hypos"].astype(np.float32)).to(dev)
+    pts, nrm, col = (torch.from_numpy(d[k].astype(np.float32)).to(dev) for k in
+                     ("model_points", "model_normals", "model_colors"))
+    K = d["cam_K"]
+    cam = tuple(float(np.float32(v)) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
+    names = _lib.StageEvents.names()
+    # one set of HIP events per timed step: they are recorded on the launch stream inside the timed region
+    # (a record is an enqueue, no sync) and read back after the region's final synchronize.
+    ev_sets = [_lib.StageEvents() for _ in range(a.steps)]
+    feat_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def step(i=None):
+        rgbd = zephyr.stage_frame(img, depth, dev, blur=True)
+        tab = zephyr.stage_model(pts, nrm, col, dev)
+        if i is not None:
+            feat_evs[i][0].record()
+        px, uv = zephyr.featurize(rgbd, T, tab, cam, want_uv=True)
+        if i is not None:
+            feat_evs[i][1].record()
+        scores = model.score(px, stage_events=None if i is None else ev_sets[i])
+        return scores, scores.argmax()
+
+    for _ in range(a.warmup):
+        scores, top = step()
+    torch.cuda.synchronize()
+
+    # timed region: EXACTLY K steps between barrier+synchronize pairs
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        scores, top = step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations of those same K steps
+    stage_ms = np.mean([e.elapsed_ms() for e in ev_sets], axis=0)
+    feat_ms = float(np.mean([s0.elapsed_time(s1) for s0, s1 in feat_evs]))
+    for e in ev_sets:
+        e.close()
+
+    if rank == 0:
+        top1 = int(top.item())
+        if base_scores is not None:   # the GPU scores of the sampled hypotheses are the oracle's, bit for bit
+            got = scores[: len(base_scores)].cpu().numpy()
+            assert np.array_equal(got, base_scores), "GPU scores differ from the CPU oracle"
+        dom = max(STAGE_FLOPS, key=lambda k: stage_ms[names.index(k)])
+        dom_ms = float(stage_ms[names.index(dom)])
+        achieved = STAGE_FLOPS[dom] * N_HYP / (dom_ms * 1e-3) / 1e12
+        feat_bytes = N_HYP * N_PTS * (32 + 8) + IMG_H * IMG_W * 16 + N_PTS * 48 + N_HYP * 64
+        out = {
+            "metric": "hypotheses scored/sec", "value": a.gpus * a.steps * N_HYP / elapsed, "unit": "hyp/s",
+            "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "zephyr_score: %d hypotheses x %d model points, %dx%d RGB-D frame, "
+                                   "HSVD_diff_uv_norm features (D=8) + PointNet2SSG (SA 512/0.2/64 [8,64,64,128], "
+                                   "SA 128/0.4/64 [131,128,128,256], SA all [259,256,512,1024], FC 512-256-1); "
+                                   "BASELINE.json configs[1]" % (N_HYP, N_PTS, IMG_W, IMG_H),
+                       "frames_per_step_per_gpu": 1, "parallelism": "frames sharded, %d rank(s)" % a.gpus,
+                       "top1": top1},
+            "roofline": {"bound": "mfma", "kernel": dom + "_kernel", "achieved": achieved,
+                         "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
+                         "traffic": None, "avg_launch_ms": dom_ms,
+                         "flops_per_launch": STAGE_FLOPS[dom] * N_HYP},
+            "stage_ms": {n: round(float(v), 4) for n, v in zip(names, stage_ms)},
+            "featurize": {"bound": "hbm", "avg_launch_ms": feat_ms, "achieved": feat_bytes / (feat_ms * 1e-3) / 1e9,
+                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": feat_bytes / (feat_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                          "bytes_per_launch": feat_bytes},
+            "cpu_baseline": base,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

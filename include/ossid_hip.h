@@ -106,7 +106,20 @@ size_t ossid_pn2_workspace_bytes(int B, int M, int npoint1, int npoint2);
 int ossid_pn2_score(const float* point_x, int B, int M, const ossid_pn2_weights* w, void* workspace,
                     size_t workspace_bytes, float* scores, int32_t* dbg_fps1, int32_t* dbg_ball1,
                     float* dbg_feat1, int32_t* dbg_fps2, int32_t* dbg_ball2, float* dbg_feat2,
-                    float* dbg_feat3, void* stream);
+                    float* dbg_feat3, void* const* stage_events_host, void* stream);
+
+/* Kernel order of ossid_pn2_score; with stage_events_host != NULL (an array of OSSID_PN2_NSTAGES+1 hipEvent_t made
+ * by ossid_event_create) event[i] is recorded on `stream` before stage i and event[NSTAGES] after the last, so a
+ * caller can time each kernel of the launch it is actually measuring (bench.py's roofline leg). */
+#define OSSID_PN2_NSTAGES 9
+/* "fps1,ball1,sa1,p2,fps2,ball2,sa2,sa3,fc" */
+const char* ossid_pn2_stage_names(void);
+
+int ossid_event_create(void** event_out_host);
+int ossid_event_destroy(void* event);
+int ossid_event_record(void* event, void* stream);
+/* waits for `stop`, then *ms_out_host = elapsed(start, stop) */
+int ossid_event_elapsed_ms(void* start, void* stop, float* ms_out_host);
 
 /* Names of the kernels the scorer launches, for profile post-processing (static string). */
 const char* ossid_pn2_kernel_names(void);

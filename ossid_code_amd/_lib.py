@@ -31,7 +31,12 @@ _PROTOS = {
     "ossid_pn2_fps": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ossid_pn2_ball_query": (_i, [_vp, _i, _i, _i, _vp, _i, _f, _i, _vp, _vp]),
     "ossid_pn2_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "ossid_pn2_score": (_i, [_vp, _i, _i, C.POINTER(PN2Weights), _vp, _sz, _vp] + [_vp] * 7 + [_vp]),
+    "ossid_pn2_score": (_i, [_vp, _i, _i, C.POINTER(PN2Weights), _vp, _sz, _vp] + [_vp] * 7 + [_vp, _vp]),
+    "ossid_pn2_stage_names": (C.c_char_p, []),
+    "ossid_event_create": (_i, [C.POINTER(_vp)]),
+    "ossid_event_destroy": (_i, [_vp]),
+    "ossid_event_record": (_i, [_vp, _vp]),
+    "ossid_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(_f)]),
     "ossid_pn2_kernel_names": (C.c_char_p, []),
 }
 
@@ -88,3 +93,37 @@ def require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise RuntimeError("the OSSID hot path runs on the GPU only (got a %s tensor)" % t.device)
+
+
+PN2_NSTAGES = 9
+
+
+class StageEvents:
+    """OSSID_PN2_NSTAGES+1 HIP events for ossid_pn2_score's stage_events_host argument."""
+
+    def __init__(self):
+        self.n = PN2_NSTAGES + 1
+        self.arr = (_vp * self.n)()
+        for i in range(self.n):
+            e = _vp()
+            check(fn("ossid_event_create")(C.byref(e)), "ossid_event_create")
+            self.arr[i] = e.value
+
+    def elapsed_ms(self):
+        """Per-stage milliseconds of the last recorded call (waits for it to finish)."""
+        out = []
+        for i in range(self.n - 1):
+            ms = _f()
+            check(fn("ossid_event_elapsed_ms")(self.arr[i], self.arr[i + 1], C.byref(ms)), "ossid_event_elapsed_ms")
+            out.append(ms.value)
+        return out
+
+    def close(self):
+        for i in range(self.n):
+            if self.arr[i]:
+                fn("ossid_event_destroy")(self.arr[i])
+                self.arr[i] = None
+
+    @staticmethod
+    def names():
+        return fn("ossid_pn2_stage_names")().decode().split(",")

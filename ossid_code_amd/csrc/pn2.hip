@@ -694,13 +694,33 @@ size_t ossid_pn2_workspace_bytes(int B, int M, int npoint1, int npoint2) {
     return carve(nullptr, B, M, npoint1, npoint2).bytes;
 }
 
+const char* ossid_pn2_stage_names(void) { return "fps1,ball1,sa1,p2,fps2,ball2,sa2,sa3,fc"; }
+
+int ossid_event_create(void** event_out_host) {
+    if (!event_out_host) return OSSID_EINVAL;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return OSSID_ELAUNCH;
+    *event_out_host = (void*)e;
+    return OSSID_OK;
+}
+int ossid_event_destroy(void* event) { return hipEventDestroy((hipEvent_t)event) == hipSuccess ? OSSID_OK : OSSID_ELAUNCH; }
+int ossid_event_record(void* event, void* stream) {
+    return hipEventRecord((hipEvent_t)event, (hipStream_t)stream) == hipSuccess ? OSSID_OK : OSSID_ELAUNCH;
+}
+int ossid_event_elapsed_ms(void* start, void* stop, float* ms_out_host) {
+    if (!ms_out_host) return OSSID_EINVAL;
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return OSSID_ELAUNCH;
+    return hipEventElapsedTime(ms_out_host, (hipEvent_t)start, (hipEvent_t)stop) == hipSuccess ? OSSID_OK : OSSID_ELAUNCH;
+}
+
 const char* ossid_pn2_kernel_names(void) {
     return "fps_kernel,ball_query_kernel,sa1_kernel,p2_kernel,sa2_kernel,sa3_kernel,fc_head_kernel";
 }
 
 int ossid_pn2_score(const float* point_x, int B, int M, const ossid_pn2_weights* w, void* workspace,
                     size_t workspace_bytes, float* scores, int32_t* dbg_fps1, int32_t* dbg_ball1, float* dbg_feat1,
-                    int32_t* dbg_fps2, int32_t* dbg_ball2, float* dbg_feat2, float* dbg_feat3, void* stream) {
+                    int32_t* dbg_fps2, int32_t* dbg_ball2, float* dbg_feat2, float* dbg_feat3,
+                    void* const* stage_events_host, void* stream) {
     if (B < 0 || !w) return OSSID_EINVAL;
     if (B == 0) return OSSID_OK;
     const int np1 = w->npoint1, np2 = w->npoint2;
@@ -714,10 +734,18 @@ int ossid_pn2_score(const float* point_x, int B, int M, const ossid_pn2_weights*
     auto W = [&](int i) { return blob + w->w_off[i]; };
     auto Bv = [&](int i) { return blob + w->b_off[i]; };
     int rc;
+    int stage = 0;
+    auto mark = [&]() {
+        if (stage_events_host && hipEventRecord((hipEvent_t)stage_events_host[stage], s) != hipSuccess) rc = OSSID_ELAUNCH;
+        ++stage;
+    };
 
     // SA1
+    mark();
     if ((rc = launch_fps(point_x, 8, B, M, np1, ws.fps1, ws.xyz1, s))) return rc;
+    mark();
     if ((rc = launch_ball(point_x, 8, B, M, ws.xyz1, np1, w->radius1, ws.ball1, s))) return rc;
+    mark();
     {
         const int total = B * np1;
         const int grid = (total + 4 * SA1_CPW - 1) / (4 * SA1_CPW);
@@ -726,13 +754,17 @@ int ossid_pn2_score(const float* point_x, int B, int M, const ossid_pn2_weights*
         if ((rc = ossid_launch_status())) return rc;
     }
     // SA2
+    mark();
     {
         const int tiles = B * np1 / 32;
         hipLaunchKernelGGL(p2_kernel, dim3((tiles + 7) / 8), dim3(256), 0, s, ws.feat1, tiles, W(3), Bv(3), ws.p2);
         if ((rc = ossid_launch_status())) return rc;
     }
+    mark();
     if ((rc = launch_fps(ws.xyz1, 3, B, np1, np2, ws.fps2, ws.xyz2, s))) return rc;
+    mark();
     if ((rc = launch_ball(ws.xyz1, 3, B, np1, ws.xyz2, np2, w->radius2, ws.ball2, s))) return rc;
+    mark();
     {
         const int total = B * np2;
         const int grid = (total + 4 * SA2_CPW - 1) / (4 * SA2_CPW);
@@ -741,12 +773,15 @@ int ossid_pn2_score(const float* point_x, int B, int M, const ossid_pn2_weights*
         if ((rc = ossid_launch_status())) return rc;
     }
     // SA3 + FC head
+    mark();
     hipLaunchKernelGGL(sa3_kernel, dim3(B), dim3(256), 0, s, ws.feat2, ws.xyz2, np2, W(6), Bv(6), W(7), Bv(7), W(8),
                        Bv(8), ws.feat3);
     if ((rc = ossid_launch_status())) return rc;
+    mark();
     hipLaunchKernelGGL(fc_head_kernel, dim3((B + FC_HB - 1) / FC_HB), dim3(256), 0, s, ws.feat3, B, W(9), Bv(9),
                        W(10), Bv(10), W(11), Bv(11), scores);
     if ((rc = ossid_launch_status())) return rc;
+    mark();
 
     auto cp = [&](void* dst, const void* src, size_t n) {
         if (dst && hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = OSSID_ELAUNCH;

@@ -168,7 +168,7 @@ class PointNet2SSG(nn.Module):
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self._ws
 
-    def score(self, point_x, debug=False):
+    def score(self, point_x, debug=False, stage_events=None):
         """point_x [B, M, 8] float32 on the GPU -> scores [B] (and the stage tensors when debug)."""
         _lib.require_cuda(point_x)
         if self.training:
@@ -202,7 +202,7 @@ class PointNet2SSG(nn.Module):
                 if dbg is not None:
                     dargs = [dbg[k][b0:b0 + nb].data_ptr() for k in ("fps1", "ball1", "feat1", "fps2", "ball2", "feat2", "feat3")]
                 rc = f(point_x[b0:b0 + nb].data_ptr(), nb, M, w, ws.data_ptr(), nbytes, scores[b0:b0 + nb].data_ptr(),
-                       *dargs, _lib.stream())
+                       *dargs, None if stage_events is None else stage_events.arr, _lib.stream())
                 _lib.check(rc, "ossid_pn2_score")
         return (scores, dbg) if debug else scores
 
