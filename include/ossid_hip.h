@@ -124,6 +124,36 @@ int ossid_event_elapsed_ms(void* start, void* stop, float* ms_out_host);
 /* Names of the kernels the scorer launches, for profile post-processing (static string). */
 const char* ossid_pn2_kernel_names(void);
 
+/* =============================================================================================
+ * DTOID ops (paths under /root/reference/python/ossid/models/dtoid)
+ * ============================================================================================= */
+
+/* D5  conv2d_dw_group(x, kernel, padding=1)      network.py:186-192 (backbone) and :365-371 (head)
+ * F.conv2d(x.view(1,B*C,H,W), k.view(B*C,1,3,3), groups=B*C, padding=1): per-plane 3x3 cross-correlation with a
+ * data-dependent kernel. planes = B*C; x, out, dout, dx [planes][H][W]; k, dk [planes][3][3].
+ * _bwd_x: gradient w.r.t. x; _bwd_k: gradient w.r.t. the kernel (gradients flow to both operands). */
+int ossid_dw_xcorr_fwd(const float* x, const float* k, int planes, int H, int W, float* out, void* stream);
+int ossid_dw_xcorr_bwd_x(const float* dout, const float* k, int planes, int H, int W, float* dx, void* stream);
+int ossid_dw_xcorr_bwd_k(const float* x, const float* dout, int planes, int H, int W, float* dk, void* stream);
+
+/* D12  torchvision.ops.nms(boxes, scores, iou_threshold)      network.py:563, models/dtoid/utils.py:33
+ * boxes [n][4] (x1,y1,x2,y2) ALREADY sorted by descending score (network.py:555 feeds it the top-k order);
+ * keep [n] receives the indices of the survivors in that order, *num_keep their count. n <= 16384. */
+size_t ossid_nms_workspace_bytes(int n);
+int ossid_nms(const float* boxes, int n, float iou_threshold, void* workspace, size_t workspace_bytes,
+              int32_t* keep, int32_t* num_keep, void* stream);
+
+/* D10  BBoxTransform.forward + ClipBoxes.forward      network.py:42-70, :78-88
+ * anchors [A][4] (shared by all rows), deltas [rows][A][4] -> boxes [rows][A][4]; std (.1,.1,.2,.2), mean 0. */
+int ossid_decode_clip_boxes(const float* anchors, const float* deltas, int rows, int A, float img_w, float img_h,
+                            float* boxes, void* stream);
+
+/* D16  torch.optim.Adam(lr, weight_decay, amsgrad=True).step()      scripts/online_learning.py:258-263, :672
+ * one launch over flat float buffers of n elements (n % 4 == 0); `step` is the 1-based update count. */
+int ossid_amsgrad_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
+                       size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,270 @@
+// DTOID device ops for gfx950 that are not plain dense convolutions:
+//   - per-sample depthwise cross-correlation with a data-dependent 3x3 kernel (forward + both backward passes),
+//     the op behind conv2d_dw_group (/root/reference/python/ossid/models/dtoid/network.py:186-192, :365-371),
+//     which the reference runs as a groups=B*C grouped convolution;
+//   - greedy IoU NMS, the op behind torchvision.ops.nms (network.py:563, models/dtoid/utils.py:33);
+//   - anchor box decode + clip (BBoxTransform / ClipBoxes, network.py:42-70, :78-88);
+//   - the AMSGrad-Adam update of online_learning.py:258-263 as ONE launch over a flat parameter buffer.
+// All of them are HBM-bound elementwise / stencil / reduction kernels: coalesced 4-byte lanes over rows, LDS halo
+// tiles for the stencil, wave reductions for the kernel-gradient sums.
+#include "common.h"
+
+namespace {
+
+// ---- depthwise 3x3 cross-correlation, zero padding 1 -------------------------------------------------------------
+// out[p][y][x] = sum_{i,j} in[p][y+i-1][x+j-1] * k[p][i][j]      (flip = 0; the forward pass)
+// with flip = 1 the kernel is applied rotated by 180 degrees, which turns the same routine into the gradient w.r.t.
+// the input: dx = dout (*) rot180(k).
+constexpr int DW_TX = 64, DW_TY = 4;
+__global__ __launch_bounds__(256) void dw_xcorr_kernel(const float* __restrict__ in, const float* __restrict__ k, int H,
+                                                       int W, int flip, float* __restrict__ out) {
+    __shared__ float tile[(DW_TY + 2) * (DW_TX + 2)];
+    const int p = blockIdx.z;
+    const int x0 = blockIdx.x * DW_TX - 1, y0 = blockIdx.y * DW_TY - 1;
+    const float* src = in + (size_t)p * H * W;
+    for (int i = threadIdx.x; i < (DW_TY + 2) * (DW_TX + 2); i += 256) {
+        int lx = i % (DW_TX + 2), ly = i / (DW_TX + 2);
+        int gx = x0 + lx, gy = y0 + ly;
+        tile[i] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? src[(size_t)gy * W + gx] : 0.0f;
+    }
+    float w[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[i] = k[(size_t)p * 9 + (flip ? 8 - i : i)];
+    __syncthreads();
+    const int tx = threadIdx.x % DW_TX, ty = threadIdx.x / DW_TX;
+    const int x = blockIdx.x * DW_TX + tx, y = blockIdx.y * DW_TY + ty;
+    if (x >= W || y >= H) return;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc = fmaf(tile[(ty + i) * (DW_TX + 2) + tx + j], w[3 * i + j], acc);
+    out[(size_t)p * H * W + (size_t)y * W + x] = acc;
+}
+
+// dk[p][i][j] = sum_{y,x} dout[p][y][x] * in[p][y+i-1][x+j-1]: one workgroup per plane, nine running sums per
+// lane, then a 64-lane butterfly and a 4-entry LDS combine (fixed order, so the result is reproducible).
+__global__ __launch_bounds__(256) void dw_xcorr_bwd_k_kernel(const float* __restrict__ in,
+                                                             const float* __restrict__ dout, int H, int W,
+                                                             float* __restrict__ dk) {
+    __shared__ float red[4][9];
+    const int p = blockIdx.x;
+    const float* a = in + (size_t)p * H * W;
+    const float* g = dout + (size_t)p * H * W;
+    float s[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s[i] = 0.0f;
+    for (int idx = threadIdx.x; idx < H * W; idx += 256) {
+        const int y = idx / W, x = idx - y * W;
+        const float gv = g[idx];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int yy = y + i - 1;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int xx = x + j - 1;
+                const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? a[(size_t)yy * W + xx] : 0.0f;
+                s[3 * i + j] = fmaf(gv, v, s[3 * i + j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s[i] += __shfl_xor(s[i], m);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) red[threadIdx.x >> 6][i] = s[i];
+    __syncthreads();
+    if (threadIdx.x < 9)
+        dk[(size_t)p * 9 + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---- NMS ---------------------------------------------------------------------------------------------------------
+// boxes [n][4] (x1,y1,x2,y2) sorted by descending score. Pass 1: 64x64 blocks of the upper triangle -> bitmask of
+// "j is suppressed by i" (IoU > thr). Pass 2: one wave walks the boxes in order, OR-ing the masks of the kept ones.
+__device__ __forceinline__ float iou(const float4 a, const float4 b) {
+    float iw = fminf(a.z, b.z) - fmaxf(a.x, b.x), ih = fminf(a.w, b.w) - fmaxf(a.y, b.y);
+    iw = fmaxf(iw, 0.0f);
+    ih = fmaxf(ih, 0.0f);
+    float inter = iw * ih;
+    float ua = ((a.z - a.x) * (a.w - a.y) + (b.z - b.x) * (b.w - b.y)) - inter;
+    return inter / ua;
+}
+
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ boxes, int n, float thr,
+                                                      unsigned long long* __restrict__ mask, int words) {
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb) return;
+    __shared__ float4 cbox[64];
+    const int ci = cb * 64 + threadIdx.x;
+    if (ci < n) cbox[threadIdx.x] = boxes[ci];
+    __syncthreads();
+    const int i = rb * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float4 bi = boxes[i];
+    unsigned long long bits = 0;
+    const int jn = min(64, n - cb * 64);
+    for (int j = (rb == cb) ? threadIdx.x + 1 : 0; j < jn; ++j)
+        if (iou(bi, cbox[j]) > thr) bits |= 1ull << j;
+    mask[(size_t)i * words + cb] = bits;
+}
+
+__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int words,
+                                                      int* __restrict__ keep, int* __restrict__ nkeep) {
+    extern __shared__ unsigned long long remv[];
+    for (int w = threadIdx.x; w < words; w += 64) remv[w] = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        const bool dead = (remv[i >> 6] >> (i & 63)) & 1ull;   // same word for every lane: wave-uniform
+        if (!dead) {
+            if (threadIdx.x == 0) keep[cnt] = i;
+            ++cnt;
+            for (int w = (i >> 6) + threadIdx.x; w < words; w += 64) remv[w] |= mask[(size_t)i * words + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *nkeep = cnt;
+}
+
+// ---- anchor decode + clip ------------------------------------------------------------------------------------------
+// anchors [A][4] shared by every batch row, deltas [R][A][4] -> boxes [R][A][4]; std (.1,.1,.2,.2), mean 0.
+__global__ __launch_bounds__(256) void decode_clip_kernel(const float4* __restrict__ anchors,
+                                                          const float4* __restrict__ deltas, int A, size_t total,
+                                                          float img_w, float img_h, float4* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float4 a = anchors[i % A], d = deltas[i];
+    const float w = a.z - a.x, h = a.w - a.y;
+    const float cx = a.x + 0.5f * w, cy = a.y + 0.5f * h;
+    const float dx = d.x * 0.1f, dy = d.y * 0.1f, dw = d.z * 0.2f, dh = d.w * 0.2f;
+    const float pcx = cx + dx * w, pcy = cy + dy * h;
+    const float pw = expf(dw) * w, ph = expf(dh) * h;
+    float4 o;
+    o.x = fmaxf(pcx - 0.5f * pw, 0.0f);
+    o.y = fmaxf(pcy - 0.5f * ph, 0.0f);
+    o.z = fminf(pcx + 0.5f * pw, img_w);
+    o.w = fminf(pcy + 0.5f * ph, img_h);
+    out[i] = o;
+}
+
+// ---- AMSGrad Adam over a flat buffer (torch.optim.Adam(amsgrad=True, weight_decay) semantics) --------------------
+__global__ __launch_bounds__(256) void amsgrad_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                      float4* __restrict__ m, float4* __restrict__ v,
+                                                      float4* __restrict__ vmax, size_t n4, float lr, float b1,
+                                                      float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const float step = lr / bc1;
+    for (; i < n4; i += stride) {
+        float4 P = p[i], G = g[i], M = m[i], V = v[i], X = vmax[i];
+        float* pp = (float*)&P;
+        float* gg = (float*)&G;
+        float* mm = (float*)&M;
+        float* vv = (float*)&V;
+        float* xx = (float*)&X;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float gr = gg[c] + wd * pp[c];
+            mm[c] = b1 * mm[c] + (1.0f - b1) * gr;
+            vv[c] = b2 * vv[c] + (1.0f - b2) * gr * gr;
+            xx[c] = fmaxf(xx[c], vv[c]);
+            const float denom = sqrtf(xx[c]) / bc2_sqrt + eps;
+            pp[c] = pp[c] - step * (mm[c] / denom);
+        }
+        p[i] = P;
+        m[i] = M;
+        v[i] = V;
+        vmax[i] = X;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ossid_dw_xcorr_fwd(const float* x, const float* k, int planes, int H, int W, float* out, void* stream) {
+    if (planes < 0 || H <= 0 || W <= 0 || planes > 65535 * 16) return OSSID_EINVAL;
+    if (planes == 0) return OSSID_OK;
+    if (!x || !k || !out) return OSSID_EINVAL;
+    for (int p0 = 0; p0 < planes; p0 += 65535) {
+        const int np = planes - p0 < 65535 ? planes - p0 : 65535;
+        dim3 grid((W + DW_TX - 1) / DW_TX, (H + DW_TY - 1) / DW_TY, np);
+        hipLaunchKernelGGL(dw_xcorr_kernel, grid, dim3(256), 0, (hipStream_t)stream, x + (size_t)p0 * H * W,
+                           k + (size_t)p0 * 9, H, W, 0, out + (size_t)p0 * H * W);
+    }
+    return ossid_launch_status();
+}
+
+int ossid_dw_xcorr_bwd_x(const float* dout, const float* k, int planes, int H, int W, float* dx, void* stream) {
+    if (planes < 0 || H <= 0 || W <= 0 || planes > 65535 * 16) return OSSID_EINVAL;
+    if (planes == 0) return OSSID_OK;
+    if (!dout || !k || !dx) return OSSID_EINVAL;
+    for (int p0 = 0; p0 < planes; p0 += 65535) {
+        const int np = planes - p0 < 65535 ? planes - p0 : 65535;
+        dim3 grid((W + DW_TX - 1) / DW_TX, (H + DW_TY - 1) / DW_TY, np);
+        hipLaunchKernelGGL(dw_xcorr_kernel, grid, dim3(256), 0, (hipStream_t)stream, dout + (size_t)p0 * H * W,
+                           k + (size_t)p0 * 9, H, W, 1, dx + (size_t)p0 * H * W);
+    }
+    return ossid_launch_status();
+}
+
+int ossid_dw_xcorr_bwd_k(const float* x, const float* dout, int planes, int H, int W, float* dk, void* stream) {
+    if (planes < 0 || H <= 0 || W <= 0) return OSSID_EINVAL;
+    if (planes == 0) return OSSID_OK;
+    if (!x || !dout || !dk) return OSSID_EINVAL;
+    hipLaunchKernelGGL(dw_xcorr_bwd_k_kernel, dim3(planes), dim3(256), 0, (hipStream_t)stream, x, dout, H, W, dk);
+    return ossid_launch_status();
+}
+
+size_t ossid_nms_workspace_bytes(int n) {
+    const size_t words = (size_t)(n + 63) / 64;
+    return (size_t)n * words * 8 + 256;
+}
+
+int ossid_nms(const float* boxes, int n, float iou_threshold, void* workspace, size_t workspace_bytes, int32_t* keep,
+              int32_t* num_keep, void* stream) {
+    if (n < 0 || n > 16384 || !num_keep) return OSSID_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) return hipMemsetAsync(num_keep, 0, 4, s) == hipSuccess ? OSSID_OK : OSSID_ELAUNCH;
+    if (!boxes || !keep || !workspace || workspace_bytes < ossid_nms_workspace_bytes(n)) return OSSID_EINVAL;
+    const int words = (n + 63) / 64;
+    unsigned long long* mask = (unsigned long long*)workspace;
+    if (hipMemsetAsync(mask, 0, (size_t)n * words * 8, s) != hipSuccess) return OSSID_ELAUNCH;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words), dim3(64), 0, s, (const float4*)boxes, n, iou_threshold,
+                       mask, words);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)words * 8, s, mask, n, words, keep, num_keep);
+    return ossid_launch_status();
+}
+
+int ossid_decode_clip_boxes(const float* anchors, const float* deltas, int rows, int A, float img_w, float img_h,
+                            float* boxes, void* stream) {
+    if (rows < 0 || A <= 0) return OSSID_EINVAL;
+    if (rows == 0) return OSSID_OK;
+    if (!anchors || !deltas || !boxes) return OSSID_EINVAL;
+    const size_t total = (size_t)rows * A;
+    hipLaunchKernelGGL(decode_clip_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)anchors, (const float4*)deltas, A, total, img_w, img_h, (float4*)boxes);
+    return ossid_launch_status();
+}
+
+int ossid_amsgrad_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
+                       size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                       void* stream) {
+    if (step < 1 || (n & 3)) return OSSID_EINVAL;   // flat buffers are padded to a multiple of 4 floats
+    if (n == 0) return OSSID_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !max_exp_avg_sq) return OSSID_EINVAL;
+    const double bc1d = 1.0 - pow((double)beta1, (double)step), bc2d = 1.0 - pow((double)beta2, (double)step);
+    const float bc1 = (float)bc1d;
+    const size_t n4 = n / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(amsgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)param,
+                       (const float4*)grad, (float4*)exp_avg, (float4*)exp_avg_sq, (float4*)max_exp_avg_sq, n4, lr,
+                       beta1, beta2, eps, weight_decay, bc1, (float)sqrt(bc2d));
+    return ossid_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+"""Detection losses of the DTOID finetune step (reference: models/dtoid/loss.py:10-37 calc_iou, :46-175
+DetectionLoss.forward -- focal classification loss (alpha .25, gamma 2) with IoU anchor assignment (< 0.4 negative,
+>= 0.5 positive, in between ignored) and smooth-L1 box regression (beta 1/9) on the positives).
+
+The reference walks the batch in a Python loop with data-dependent branches (host syncs per sample); this is the same
+arithmetic as whole-batch tensor expressions, so the loss stays on the device and is graph-capturable."""
+import torch
+import torch.nn as nn
+
+
+def calc_iou(a, b):
+    """pair-wise IoU of boxes a [n1,4] and b [n2,4] -> [n1,n2]"""
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    iw = (torch.min(a[:, None, 2], b[None, :, 2]) - torch.max(a[:, None, 0], b[None, :, 0])).clamp(min=0)
+    ih = (torch.min(a[:, None, 3], b[None, :, 3]) - torch.max(a[:, None, 1], b[None, :, 1])).clamp(min=0)
+    inter = iw * ih
+    union = ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]))[:, None] + area_b[None] - inter
+    return inter / union.clamp(min=1e-8)
+
+
+class DetectionLoss(nn.Module):
+    def __init__(self, alpha=0.25, gamma=2.0):
+        super().__init__()
+        self.alpha, self.gamma = alpha, gamma
+
+    def forward(self, classifications, regressions, anchors, annotations):
+        """classifications [B,A,C] probabilities, regressions [B,A,4], anchors [1,A,4], annotations [B,G,5]
+        (x1,y1,x2,y2,label; label -1 marks padding). Returns (cls_loss [1], reg_loss [1])."""
+        alpha, gamma = self.alpha, self.gamma
+        B, A, C = classifications.shape
+        dev = classifications.device
+        annotations = annotations.to(dev)
+        anchor = anchors[0]
+        aw, ah = anchor[:, 2] - anchor[:, 0], anchor[:, 3] - anchor[:, 1]
+        acx, acy = anchor[:, 0] + 0.5 * aw, anchor[:, 1] + 0.5 * ah
+
+        p = classifications.clamp(1e-4, 1.0 - 1e-4)
+        valid = annotations[:, :, 4] != -1                                  # [B,G]
+        has_gt = valid.any(1)                                               # [B]
+        # IoU of every anchor with every (valid) annotation: padded rows can never win the max
+        g = annotations[:, None, :, :4]                                     # [B,1,G,4]
+        a4 = anchor[None, :, None, :]                                       # [1,A,1,4]
+        iw = (torch.min(a4[..., 2], g[..., 2]) - torch.max(a4[..., 0], g[..., 0])).clamp(min=0)
+        ih = (torch.min(a4[..., 3], g[..., 3]) - torch.max(a4[..., 1], g[..., 1])).clamp(min=0)
+        union = (aw * ah)[None, :, None] + ((g[..., 2] - g[..., 0]) * (g[..., 3] - g[..., 1])) - iw * ih
+        iou = (iw * ih) / union.clamp(min=1e-8)                             # [B,A,G]
+        iou = torch.where(valid[:, None, :], iou, torch.full_like(iou, -1.0))
+        iou_max, iou_arg = iou.max(2)                                       # [B,A]
+        assigned = torch.gather(annotations, 1, iou_arg[:, :, None].expand(-1, -1, 5))       # [B,A,5]
+        positive = (iou_max >= 0.5) & has_gt[:, None]
+        negative = (iou_max < 0.4) | ~has_gt[:, None]                       # no annotation: everything is background
+        npos = positive.sum(1)
+
+        onehot = torch.zeros_like(p).scatter_(2, assigned[:, :, 4:5].long().clamp(0, C - 1), 1.0)
+        targets = torch.where(positive[:, :, None], onehot, torch.zeros_like(p))
+        counted = (positive | negative)[:, :, None]
+        is_pos = targets == 1.0
+        focal = torch.where(is_pos, alpha * (1.0 - p) ** gamma, (1.0 - alpha) * p ** gamma)
+        bce = -torch.where(is_pos, torch.log(p), torch.log(1.0 - p))
+        cls = torch.where(counted, focal * bce, torch.zeros_like(p)).sum((1, 2))
+        cls = cls / torch.where(has_gt, npos.float().clamp(min=1.0), torch.ones_like(cls))
+
+        gw = (assigned[:, :, 2] - assigned[:, :, 0])
+        gh = (assigned[:, :, 3] - assigned[:, :, 1])
+        gcx, gcy = assigned[:, :, 0] + 0.5 * gw, assigned[:, :, 1] + 0.5 * gh
+        gw, gh = gw.clamp(min=1), gh.clamp(min=1)
+        t = torch.stack([(gcx - acx) / aw, (gcy - acy) / ah, torch.log(gw / aw), torch.log(gh / ah)], 2)
+        t = t / t.new_tensor([0.1, 0.1, 0.2, 0.2])
+        diff = (t - regressions).abs()
+        sl1 = torch.where(diff <= 1.0 / 9.0, 0.5 * 9.0 * diff * diff, diff - 0.5 / 9.0)
+        reg = torch.where(positive[:, :, None], sl1, torch.zeros_like(sl1)).sum((1, 2))
+        reg = reg / (4.0 * npos.float()).clamp(min=1.0)                      # mean over the positives' 4 coordinates
+        return cls.mean(0, keepdim=True), reg.mean(0, keepdim=True)

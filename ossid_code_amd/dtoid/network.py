@@ -1,0 +1,284 @@
+"""DTOID network with the reference's module tree, call signatures and outputs
+(/root/reference/python/ossid/models/dtoid/network.py: ImageFeatExtract :160-192, TemplateFeatExtractGlobal :195-239,
+TemplateFeatExtract :242-279, CorrelationModel :282-371, ClassificationModel :96-128, RegressionModel :131-157,
+Network :373-581). Attribute names are the reference's, so its state_dict keys load unchanged.
+
+What is different is how it runs on MI355X:
+  - the per-sample depthwise correlation (conv2d_dw_group) is a hand-written HIP stencil with both gradients
+    (csrc/dtoid.hip) instead of a groups=B*C grouped convolution;
+  - backbones are written out (backbones.py), no torchvision, no weight download;
+  - forward_all_templates keeps everything on the device: anchors cached, box decode+clip and NMS in HIP, the
+    template-index bookkeeping is an arange instead of an O(n_t^2) torch.cat loop, and the per-template
+    segmentation maps are only gathered for the boxes that survive NMS.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .anchors import Anchors
+from .backbones import SqueezeNet11, densenet121_features
+
+PRIOR = 0.01
+
+
+class BBoxTransform(nn.Module):
+    """anchors + regression deltas -> boxes (network.py:30-70); differentiable torch form used by the train path."""
+
+    def __init__(self, mean=None, std=None):
+        super().__init__()
+        self.mean = torch.zeros(4) if mean is None else mean
+        self.std = torch.tensor([0.1, 0.1, 0.2, 0.2]) if std is None else std
+
+    def forward(self, boxes, deltas):
+        mean, std = self.mean.to(deltas), self.std.to(deltas)
+        w, h = boxes[..., 2] - boxes[..., 0], boxes[..., 3] - boxes[..., 1]
+        cx, cy = boxes[..., 0] + 0.5 * w, boxes[..., 1] + 0.5 * h
+        d = deltas * std + mean
+        pcx, pcy = cx + d[..., 0] * w, cy + d[..., 1] * h
+        pw, ph = torch.exp(d[..., 2]) * w, torch.exp(d[..., 3]) * h
+        return torch.stack([pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph], dim=2)
+
+
+class ClipBoxes(nn.Module):
+    """clamp boxes to the image, in place like the reference (network.py:74-88)."""
+
+    def forward(self, boxes, img):
+        height, width = img.shape[2], img.shape[3]
+        boxes[:, :, 0].clamp_(min=0)
+        boxes[:, :, 1].clamp_(min=0)
+        boxes[:, :, 2].clamp_(max=width)
+        boxes[:, :, 3].clamp_(max=height)
+        return boxes
+
+
+def _head_trunk(mod, cin, feature_size):
+    mod.conv1 = nn.Conv2d(cin, feature_size, kernel_size=3, padding=1)
+    mod.act1 = nn.ELU()
+    mod.conv2 = nn.Conv2d(feature_size, feature_size, kernel_size=3, padding=1)
+    mod.act2 = nn.ELU()
+    mod.conv3 = nn.Conv2d(feature_size, feature_size, kernel_size=3, padding=1)
+    mod.act3 = nn.ELU()
+    mod.conv4 = nn.Conv2d(feature_size, feature_size, kernel_size=3, padding=1)
+    mod.act4 = nn.ELU()
+
+
+def _run_trunk(mod, x):
+    for i in (1, 2, 3, 4):
+        x = getattr(mod, "act%d" % i)(getattr(mod, "conv%d" % i)(x))
+    return mod.output(x)
+
+
+class ClassificationModel(nn.Module):
+    def __init__(self, num_features_in, num_anchors=3, num_classes=2, prior=0.01, feature_size=256):
+        super().__init__()
+        self.num_anchors, self.num_classes = num_anchors, num_classes
+        _head_trunk(self, num_features_in, feature_size)
+        self.output = nn.Conv2d(feature_size, num_anchors * num_classes, kernel_size=3, padding=1)
+        self.output_act = nn.Sigmoid()
+
+    def forward(self, x):
+        out = self.output_act(_run_trunk(self, x))                       # [B, A*C, h, w]
+        B = x.shape[0]
+        flat = out.permute(0, 2, 3, 1).reshape(B, -1, self.num_classes)   # cell-major, anchor, class
+        return flat, out
+
+
+class RegressionModel(nn.Module):
+    def __init__(self, num_features_in, num_anchors=3, feature_size=256):
+        super().__init__()
+        _head_trunk(self, num_features_in, feature_size)
+        self.output = nn.Conv2d(feature_size, num_anchors * 4, kernel_size=3, padding=1)
+
+    def forward(self, x):
+        out = _run_trunk(self, x)
+        return out.permute(0, 2, 3, 1).reshape(out.shape[0], -1, 4)
+
+
+class ImageFeatExtract(nn.Module):
+    """DenseNet-121 trunk whose stem output is modulated by the global template feature (network.py:160-192)."""
+
+    def __init__(self):
+        super().__init__()
+        dense = densenet121_features()
+        dense.transition3.pool = nn.AvgPool2d(kernel_size=2, stride=1, padding=0)
+        children = list(dense.children())
+        self.backdense_0 = nn.Sequential(*children[:1])
+        self.backdense_1 = nn.Sequential(*children[1:5])
+        self.backdense_2 = nn.Sequential(*children[5:])
+        self.c1 = nn.Conv2d(1024, 640, 1)
+        self.n1 = nn.BatchNorm2d(640, affine=True)
+
+    def forward(self, image, template_feat):
+        x0 = self.backdense_0(image)
+        x0 = x0 + ops.dw_xcorr(x0, template_feat)
+        x2 = self.backdense_2(self.backdense_1(x0))
+        return self.n1(F.elu(self.c1(x2)))
+
+
+def _squeezenet_trunk(mod):
+    """4-channel stem + the two slices of SqueezeNet-1.1's feature stack, sharing the Fire modules with
+    mod.backbone exactly as the reference does (so both key families exist in the state_dict)."""
+    mod.backbone = SqueezeNet11()
+    feats = list(mod.backbone.features)
+    stem = nn.Conv2d(4, 64, kernel_size=3, stride=2)
+    with torch.no_grad():
+        stem.weight[:, :3] = feats[0].weight
+        stem.bias.copy_(feats[0].bias)
+    mod.backbone_0 = nn.Sequential(stem)
+    mod.backbone_1 = nn.Sequential(*feats[1:5])
+    mod.backbone_2 = nn.Sequential(*feats[5:])
+    mod.norm_1 = nn.BatchNorm2d(128, affine=True)
+    mod.norm_2 = nn.BatchNorm2d(512, affine=True)
+
+
+def _squeezenet_features(mod, img):
+    x1 = mod.backbone_1(mod.backbone_0(img))
+    x2 = mod.backbone_2(x1)
+    x1n, x2n = mod.norm_1(x1), mod.norm_2(x2)
+    x1d = F.interpolate(x1n, size=x2.size(3), mode="bilinear", align_corners=False)
+    return torch.cat([x2n, x1d], dim=1)
+
+
+class TemplateFeatExtractGlobal(nn.Module):
+    """object-attention branch: template -> [B,64,3,3] depthwise kernels (network.py:195-239)"""
+
+    def __init__(self, output_dim=1024):
+        super().__init__()
+        _squeezenet_trunk(self)
+        self.final_conv_1 = nn.Conv2d(640, 128, 3)
+        self.final_conv_2 = nn.Conv2d(128, 64, 3)
+        self.final_norm_1 = nn.BatchNorm2d(128, affine=True)
+        self.final_norm_2 = nn.BatchNorm2d(64, affine=True)
+
+    def forward(self, img):
+        xf = _squeezenet_features(self, img)
+        xf = self.final_norm_1(F.elu(self.final_conv_1(xf)))
+        return self.final_norm_2(F.elu(self.final_conv_2(xf)))
+
+
+class TemplateFeatExtract(nn.Module):
+    """pose-specific branch: template -> [B,640,7,7] (network.py:242-279)"""
+
+    def __init__(self, output_dim=1024):
+        super().__init__()
+        _squeezenet_trunk(self)
+
+    def forward(self, img):
+        return _squeezenet_features(self, img)
+
+
+class CorrelationModel(nn.Module):
+    def __init__(self, img_size=(480, 480), input_dim=1024):
+        super().__init__()
+        self.img_size = img_size
+        self.c1 = nn.Conv2d(input_dim, input_dim, 3, padding=0)
+        self.n1 = nn.BatchNorm2d(input_dim, affine=True)
+        self.c2 = nn.Conv2d(input_dim, input_dim, 3, padding=0)
+        self.n2 = nn.BatchNorm2d(input_dim, affine=True)
+        for name in ("dot", "dot3x3", "sub"):
+            setattr(self, "corr_conv_" + name, nn.Conv2d(input_dim, 256, 3, padding=1))
+            setattr(self, "norm_corr_" + name, nn.BatchNorm2d(256, affine=True))
+        self.cf = nn.Conv2d(768, 512, 3, padding=1)
+        self.nf = nn.BatchNorm2d(512, affine=True)
+        cin = 512
+        for i, cout in enumerate((256, 128, 64, 32, 16), 1):
+            setattr(self, "s%d" % i, nn.Conv2d(cin, cout, 3, padding=1))
+            setattr(self, "ns%d" % i, nn.BatchNorm2d(cout, affine=True))
+            cin = cout
+        self.seg_final = nn.Conv2d(16, 1, 3, padding=1)
+        self.corr_conv_heatmap = nn.Conv2d(512, 1, 1)
+
+    def _cab(self, conv, norm, x):
+        return norm(F.elu(conv(x)))
+
+    def forward(self, image_feat, template_feat, test=False):
+        t2 = self._cab(self.c2, self.n2, self._cab(self.c1, self.n1, template_feat))       # 7x7 -> 5x5 -> 3x3
+        dot3x3 = ops.dw_xcorr(image_feat, t2)
+        avg = F.avg_pool2d(template_feat, 7)
+        parts = [self._cab(self.corr_conv_dot, self.norm_corr_dot, image_feat * avg),
+                 self._cab(self.corr_conv_sub, self.norm_corr_sub, image_feat - avg),
+                 self._cab(self.corr_conv_dot3x3, self.norm_corr_dot3x3, dot3x3)]
+        x2 = self._cab(self.cf, self.nf, torch.cat(parts, dim=1))
+        heat_map = torch.sigmoid(self.corr_conv_heatmap(x2))
+        s = x2
+        for i in (1, 2, 3):
+            s = F.interpolate(self._cab(getattr(self, "s%d" % i), getattr(self, "ns%d" % i), s), scale_factor=2,
+                              mode="nearest")
+        s = F.interpolate(self._cab(self.s4, self.ns4, s), size=self.img_size, mode="nearest")
+        segmentation = self.seg_final(self._cab(self.s5, self.ns5, s))
+        return x2, heat_map, segmentation
+
+
+class Network(nn.Module):
+    def __init__(self, img_size=(480, 480), heatmap_size=(29, 29), template_size=124):
+        super().__init__()
+        self.img_size, self.heatmap_size = img_size, heatmap_size
+        self.template_feature_extractor_global = TemplateFeatExtractGlobal()
+        self.image_feature_extractor = ImageFeatExtract()
+        self.template_feature_extractor = TemplateFeatExtract()
+        self.correlation_model = CorrelationModel(self.img_size, 640)
+        self.anchors = Anchors(pyramid_levels=[4], ratios=[0.5, 1, 2], sizes=[30], scales=[1, 2, 3, 4, 5, 6, 7, 8])
+        self.classification = ClassificationModel(512, num_anchors=24)
+        self.regression = RegressionModel(512, num_anchors=24)
+        bias = -math.log((1.0 - PRIOR) / PRIOR)
+        for conv, b in ((self.classification.output, bias), (self.regression.output, 0.0),
+                        (self.correlation_model.corr_conv_heatmap, bias), (self.correlation_model.seg_final, bias)):
+            conv.weight.data.fill_(0)
+            conv.bias.data.fill_(b)
+        self.regressBoxes = BBoxTransform()
+        self.clipBoxes = ClipBoxes()
+
+    def load(self, path):
+        ckpt = torch.load(path, map_location="cpu")
+        self.load_state_dict(ckpt["state_dict"])
+
+    def freeze_bn(self):
+        for layer in self.modules():
+            if isinstance(layer, nn.BatchNorm2d):
+                layer.eval()
+
+    def compute_template_local(self, img):
+        return self.template_feature_extractor(img)
+
+    def compute_template_global(self, img):
+        return self.template_feature_extractor_global(img)
+
+    def forward(self, image, template, template_mask, global_template, global_template_mask):
+        """(B,3,H,W), (B,3,h,w), (B,1,h,w), (B,3,h,w), (B,1,h,w) ->
+        classifications [B,A,2], regression [B,A,4], anchors [1,A,4], heat_map [B,1,hh,hw], segmentation [B,1,H,W]"""
+        g = self.template_feature_extractor_global(torch.cat([global_template, global_template_mask], dim=1))
+        features = self.image_feature_extractor(image, g)
+        local = self.template_feature_extractor(torch.cat([template, template_mask], dim=1))
+        xcors, heat_map, segmentation = self.correlation_model(features, local)
+        anchors = self.anchors([[xcors.size(2), xcors.size(3)]], device=xcors.device)
+        classifications, _ = self.classification(xcors)
+        return classifications, self.regression(xcors), anchors, heat_map, segmentation
+
+    def forward_all_templates(self, image, template_features, template_features_global, topk=1):
+        """image [1,3,H,W]; template_features: list of [n_i,640,7,7] chunks; template_features_global: [[1,64,3,3]]
+        -> [max_score [k], anchors_pred [k,4], obj_indices [k,1], seg_pred [k,H,W], heatmap_pred [k,hh,hw]]"""
+        with torch.no_grad():
+            features = self.image_feature_extractor(image, template_features_global[0])
+            cls_out, reg_out, seg_out, heat_out = [], [], [], []
+            for chunk in template_features:
+                xc, heat, seg = self.correlation_model(features.expand(chunk.size(0), -1, -1, -1), chunk, True)
+                cls_out.append(self.classification(xc)[0])
+                reg_out.append(self.regression(xc))
+                seg_out.append(seg)
+                heat_out.append(heat)
+            cls_all, reg_all = torch.cat(cls_out, 0), torch.cat(reg_out, 0)       # [n_t, A, 2], [n_t, A, 4]
+            seg_all, heat_all = torch.cat(seg_out, 0), torch.cat(heat_out, 0)     # [n_t, 1, H, W], [n_t, 1, hh, hw]
+            n_t, A = reg_all.shape[0], reg_all.shape[1]
+            anchors = self.anchors([[xc.size(2), xc.size(3)]], device=xc.device)
+            boxes = ops.decode_clip_boxes(anchors, reg_all, image.shape[3], image.shape[2]).view(-1, 4)
+            k = min(1000, n_t * A)
+            max_score, max_id = torch.topk(cls_all.reshape(-1, 2)[:, 1], k)      # class 1 = object
+            anchors_pred = boxes[max_id]
+            obj_indices = (max_id // A).to(torch.float32)[:, None]                # which local template fired
+            keep = ops.nms(anchors_pred, max_score, 0.5)[:topk]
+            max_score, anchors_pred, obj_indices = max_score[keep], anchors_pred[keep], obj_indices[keep]
+            tid = obj_indices.reshape(-1).long()
+            return [max_score, anchors_pred, obj_indices, seg_all[:, 0][tid], heat_all[:, 0][tid]]

@@ -1,0 +1,69 @@
+"""world_size-2 gloo tests (CPU): the data-parallel gradient averaging of the finetune step and the frame sharding
+of the scoring path -- the N>1 logic of bench.py / finetune.GradSync, exercised without GPUs."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from ossid_code_amd.dtoid import finetune
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                     # replicas start DIFFERENT on purpose
+    net = torch.nn.Sequential(torch.nn.Linear(13, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    flat = finetune.FlatParams(net, unused_filter=lambda n: False)
+    sync = finetune.GradSync(flat, bucket_mb=1e-4)    # tiny buckets: several all-reduces in flight
+    assert len(sync.bounds) > 1
+    sync.broadcast_params(0)
+    x = torch.randn(5, 13, generator=torch.Generator().manual_seed(7 + rank))   # each rank its own shard
+    flat.zero_grad()
+    net(x).square().mean().backward()
+    local = flat.grad.clone()
+    sync.sync()
+    q.put((rank, flat.param.clone(), local, flat.grad.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_sync_averages_over_ranks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, p0, l0, g0), (_, p1, l1, g1) = res
+    assert torch.equal(p0, p1)                                   # broadcast made the replicas identical
+    assert torch.allclose(g0, (l0 + l1) / 2, rtol=1e-6, atol=1e-7)   # mean of the per-rank gradients
+    assert torch.equal(g0, g1)                                   # and identical on both ranks
+
+
+def test_frame_sharding_is_a_partition():
+    """bench.py gives rank r the frames r, r+N, ...; together the ranks cover every frame exactly once."""
+    from ossid_code_amd.parallel import shard_frames
+    for n_frames in (0, 1, 7, 8, 100):
+        for world in (1, 2, 8):
+            parts = [shard_frames(n_frames, r, world) for r in range(world)]
+            flat = sorted(i for p in parts for i in p)
+            assert flat == list(range(n_frames))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
