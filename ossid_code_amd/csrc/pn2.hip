@@ -267,6 +267,113 @@ __global__ __launch_bounds__(256) void fps_kernel(const float* __restrict__ xyz,
     }
 }
 
+// ---- furthest point sampling, register-resident form -------------------------------------------------
+// Thread t owns the CONTIGUOUS indices [t*P, t*P+P): coordinates and running distances live in registers, so a
+// pick costs P distance updates per lane (VALU), one DPP max-scan across the wave, one ballot and one LDS hand-off
+// between the four waves. Because lower lanes (and lower waves) own lower indices, "first maximum in index order"
+// -- pointnet2's tie rule -- is simply the lowest lane holding the maximum: no (value, index) pair reduction.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max(float v) {
+    // lanes with no source lane keep `old` = -2 (below every candidate: distances are >= 0, the sentinel is -1)
+    int src = __float_as_int(v);
+    int moved = __builtin_amdgcn_update_dpp(__float_as_int(-2.0f), src, CTRL, ROW_MASK, 0xf, false);
+    return fmaxf(v, __int_as_float(moved));
+}
+
+// inclusive max-scan of a wave64 (gfx9 DPP: row_shr 1,2,4,8 then row_bcast 15 / 31); lane 63 ends with the maximum
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = dpp_max<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_max<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_max<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_max<0x118, 0xf>(v);   // row_shr:8
+    v = dpp_max<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_max<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void fps_reg_kernel(const float* __restrict__ xyz, int stride, int n, int npoint,
+                                                      int* __restrict__ idx_out, float* __restrict__ new_xyz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* pts = (float4*)smem;   // read-only copy for the "current point" broadcast
+    __shared__ float rbest[2][4];
+    __shared__ int rbesti[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* base = xyz + (size_t)blockIdx.x * n * stride;
+    float px[P], py[P], pz[P], tmp[P];
+    bool live[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int k = tid * P + j;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (k < n) {
+            x = base[(size_t)k * stride];
+            y = base[(size_t)k * stride + 1];
+            z = base[(size_t)k * stride + 2];
+            pts[k] = make_float4(x, y, z, 0.f);
+        }
+        px[j] = x, py[j] = y, pz[j] = z;
+        tmp[j] = 1e10f;
+        live[j] = (k < n) && (((x * x + y * y) + z * z) > 1e-3f);
+    }
+    __syncthreads();
+    int old = 0;
+    int* io = idx_out + (size_t)blockIdx.x * npoint;
+    float* xo = new_xyz + (size_t)blockIdx.x * npoint * 3;
+    if (tid == 0) {
+        io[0] = 0;
+        xo[0] = pts[0].x;
+        xo[1] = pts[0].y;
+        xo[2] = pts[0].z;
+    }
+    for (int jj = 1; jj < npoint; ++jj) {
+        const float4 po = pts[old];
+        float best = -1.0f;
+        int besti = 0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const float dx = px[j] - po.x, dy = py[j] - po.y, dz = pz[j] - po.z;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            const float d2 = fminf(d, tmp[j]);
+            if (live[j]) {
+                tmp[j] = d2;
+                if (d2 > best) {
+                    best = d2;
+                    besti = tid * P + j;
+                }
+            }
+        }
+        const float wmax = wave_max_dpp(best);
+        const unsigned long long who = __ballot(best == wmax);
+        const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1);
+        const int widx = __builtin_amdgcn_readlane(besti, src);
+        const int buf = jj & 1;
+        if (lane == 0) {
+            rbest[buf][wave] = wmax;
+            rbesti[buf][wave] = widx;
+        }
+        __syncthreads();
+        float b = rbest[buf][0];
+        int bi = rbesti[buf][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float ob = rbest[buf][w];
+            if (ob > b) {   // strict: an equal maximum in a later wave has a higher index
+                b = ob;
+                bi = rbesti[buf][w];
+            }
+        }
+        old = (b > -1.0f) ? bi : 0;   // nothing selectable (all points at the origin): pointnet2 keeps index 0
+        if (tid == 0) {
+            io[jj] = old;
+            const float4 p = pts[old];
+            xo[3 * jj] = p.x;
+            xo[3 * jj + 1] = p.y;
+            xo[3 * jj + 2] = p.z;
+        }
+    }
+}
+
 // ---- ball query: one wave per centre, 64 candidate points per ballot -------------------------------
 constexpr int BQ_CPB = 64;  // centres per workgroup
 __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ xyz, int stride, int n,
@@ -644,7 +751,18 @@ Workspace carve(char* base, int B, int M, int np1, int np2) {
     return w;
 }
 
+template <int P>
+int launch_fps_reg(const float* xyz, int stride, int B, int n, int npoint, int* idx, float* new_xyz, hipStream_t s) {
+    hipLaunchKernelGGL(fps_reg_kernel<P>, dim3(B), dim3(256), (size_t)n * 16, s, xyz, stride, n, npoint, idx, new_xyz);
+    return ossid_launch_status();
+}
+
 int launch_fps(const float* xyz, int stride, int B, int n, int npoint, int* idx, float* new_xyz, hipStream_t s) {
+    if (n <= 256 * 2) return launch_fps_reg<2>(xyz, stride, B, n, npoint, idx, new_xyz, s);
+    if (n <= 256 * 4) return launch_fps_reg<4>(xyz, stride, B, n, npoint, idx, new_xyz, s);
+    if (n <= 256 * 8) return launch_fps_reg<8>(xyz, stride, B, n, npoint, idx, new_xyz, s);
+    if (n <= 256 * 12) return launch_fps_reg<12>(xyz, stride, B, n, npoint, idx, new_xyz, s);
+    // larger sets: points and running distances in LDS
     size_t lds = (size_t)n * 20;
     if (lds > 160 * 1024 - 1024) return OSSID_EINVAL;
     if (lds > 48 * 1024)
@@ -714,7 +832,7 @@ int ossid_event_elapsed_ms(void* start, void* stop, float* ms_out_host) {
 }
 
 const char* ossid_pn2_kernel_names(void) {
-    return "fps_kernel,ball_query_kernel,sa1_kernel,p2_kernel,sa2_kernel,sa3_kernel,fc_head_kernel";
+    return "fps_reg_kernel,fps_kernel,ball_query_kernel,sa1_kernel,p2_kernel,sa2_kernel,sa3_kernel,fc_head_kernel";
 }
 
 int ossid_pn2_score(const float* point_x, int B, int M, const ossid_pn2_weights* w, void* workspace,

@@ -1,0 +1,77 @@
+"""DTOID timing on one MI355X (not the headline bench; its numbers go to profiles/ and DESIGN.md):
+  forward   forward_all_templates semantics, 1 image x n_t local templates, images/s
+  finetune  DtoidNet.forward + loss + backward + fused AMSGrad step at batch B (cfg-4 per-GPU share), steps/s
+  convs     the head's dominant 3x3 convolution shapes alone (MIOpen fp32 baseline for the hand-written MFMA conv)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def timeit(fn, warm=2, reps=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nt", type=int, default=21)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--what", default="forward,finetune,convs")
+    a = ap.parse_args()
+    from ossid_code_amd import dtoid
+    from ossid_code_amd.dtoid import finetune
+    from test_dtoid_gpu import _batch
+    torch.manual_seed(0)
+    cfg = dtoid.DtoidConfig()
+    out = {}
+    if "convs" in a.what:
+        shapes = [("corr 640->256 3x3", 640, 256, 3), ("cf 768->512 3x3", 768, 512, 3), ("cls/reg 512->256 3x3", 512, 256, 3),
+                  ("trunk 256->256 3x3", 256, 256, 3), ("c1 tmpl 640->640 3x3 7x7", 640, 640, 3)]
+        for name, ci, co, k in shapes:
+            for B in (a.nt, a.batch):
+                hw = (7, 7) if "7x7" in name else (29, 39)
+                x = torch.randn(B, ci, *hw, device="cuda")
+                w = torch.randn(co, ci, k, k, device="cuda")
+                pad = 0 if "7x7" in name else 1
+                t = timeit(lambda: F.conv2d(x, w, padding=pad))
+                oh, ow = (hw[0] - 2, hw[1] - 2) if pad == 0 else hw
+                fl = 2.0 * B * oh * ow * co * ci * k * k
+                out["conv %s B=%d" % (name, B)] = {"ms": t * 1e3, "TFLOPs": fl / t / 1e12}
+    if "forward" in a.what:
+        m = dtoid.DtoidNet(cfg).cuda().eval()
+        b = _batch(cfg, 1, "cuda")
+        test = {"img": b["img"], "obj_id": torch.tensor([1]), "limg": torch.rand(1, a.nt, 3, 124, 124).cuda(),
+                "lmask": (torch.rand(1, a.nt, 1, 124, 124) > 0.5).float().cuda()}
+        t = timeit(lambda: m.forwardTestTime(test))
+        out["forward n_t=%d" % a.nt] = {"ms": t * 1e3, "imgs_per_s": 1.0 / t,
+                                        "TFLOPs": (39.7e9 + 46.0e9 * a.nt) / t / 1e12}
+    if "finetune" in a.what:
+        m = dtoid.DtoidNet(cfg).cuda().train()
+        flat = finetune.FlatParams(m)
+        opt = finetune.FusedAMSGrad(flat)
+        b = _batch(cfg, a.batch, "cuda")
+        t = timeit(lambda: finetune.finetune_step(m, b, opt), warm=2, reps=3)
+        out["finetune B=%d" % a.batch] = {"ms": t * 1e3, "samples_per_s": a.batch / t, "TFLOPs": 258e9 * a.batch / t / 1e12}
+        t2 = timeit(lambda: opt.step(), warm=1, reps=5)
+        out["amsgrad_step"] = {"ms": t2 * 1e3, "GBps": flat.n_used * 4 * 9 / t2 / 1e9}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
