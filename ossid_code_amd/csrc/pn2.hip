@@ -51,12 +51,18 @@ __device__ __forceinline__ v16f max16(v16f a, v16f b) {
     return a;
 }
 
-// Launder a (wave-uniform) pointer once per loop iteration: without it LICM hoists every weight load of a
-// fully unrolled layer out of the enclosing tile/centre loop -- the whole weight set -- and spills it.
+// Launder the weight pointers once per loop iteration: without it LICM hoists every weight load of a fully
+// unrolled layer out of the enclosing tile/centre loop -- the whole weight set -- and spills it. The laundering is an
+// opaque ZERO added to the pointer (an SGPR the compiler cannot see through), so the pointer keeps its global
+// address space (laundering the pointer itself degrades every load to flat_load).
+__device__ __forceinline__ int opaque_zero() {
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
+}
 template <class T>
 __device__ __forceinline__ const T* opaque(const T* p) {
-    asm volatile("" : "+s"(p));
-    return p;
+    return p + opaque_zero();
 }
 
 // four chained MFMAs: one packed weight quad against registers 4q..4q+3 of an activation tile
@@ -92,6 +98,7 @@ __device__ __forceinline__ void stream_layer(const float4* __restrict__ W4, cons
 #pragma unroll
             for (int i = 0; i < G; ++i) nxt[i] = W4[(size_t)((g + 1) * G + i) * 64];
         }
+        __builtin_amdgcn_sched_barrier(0);   // the prefetch stays AHEAD of this group's MFMAs
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int quad = g * G + i, mt = quad / QPM, kq = quad % QPM, kt = kq / 4, q = kq % 4;
@@ -133,11 +140,84 @@ __device__ __forceinline__ void stream_layer_rolled(const float4* __restrict__ W
                 nq = nq > last ? last : nq;
                 nxt[i] = W4[(size_t)nq * 64];
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 const int kq = g * G + i, kt = kq / 4, q = kq % 4;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = mfma4(cur[i], X[t][kt], 4 * q, acc[t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < G; ++i) cur[i] = nxt[i];
+        }
+        epi(mt, acc);
+    }
+}
+
+// ---- a module's LAST layer, operands swapped ---------------------------------------------------------------
+// D = A.B is symmetric in how lanes index the two non-k dimensions, so feeding the activation register as the A
+// operand and the packed weight as the B operand yields the TRANSPOSED tile: rows (registers) = the 32 samples,
+// columns (lane&31) = 32 output channels -- from the same packed weights and with the same per-element fmaf chain
+// (fma(a,b,c) == fma(b,a,c)), hence bit-identical values. In this orientation the max-pool over samples is an
+// in-register max over the 16 accumulator registers plus ONE exchange between the two lane halves, and each lane
+// ends up owning one channel: a coalesced 128-byte store instead of a 16-shuffle butterfly per 32 channels.
+__device__ __forceinline__ v16f mfma4_swapped(const v16f& x, int q4, float4 w, v16f acc) {
+    acc = mfma(x[q4 + 0], w.x, acc);
+    acc = mfma(x[q4 + 1], w.y, acc);
+    acc = mfma(x[q4 + 2], w.z, acc);
+    acc = mfma(x[q4 + 3], w.w, acc);
+    return acc;
+}
+
+__device__ __forceinline__ v16f splat16(float v) {
+    v16f a;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = v;
+    return a;
+}
+
+// max over the 32 samples of a swapped tile (16 registers x 2 lane halves), ReLU folded in (it commutes with max);
+// every lane returns the pooled value of channel lane&31
+__device__ __forceinline__ float pool_swapped(const v16f& a) {
+    float m0 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+    float m1 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]));
+    float m2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11]));
+    float m3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
+    float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    return fmaxf(m, 0.0f);
+}
+
+template <int KT, int NT, int G, class Epi>
+__device__ __forceinline__ void stream_last_layer(const float4* __restrict__ W4, const float* __restrict__ bias,
+                                                  const v16f (&X)[NT][KT], int c, int MT, Epi&& epi) {
+    constexpr int QPM = KT * 4, NG = QPM / G;
+    static_assert(QPM % G == 0, "group size must divide the quads per m-tile");
+    const int last = MT * QPM - 1;
+    float4 cur[G], nxt[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) cur[i] = W4[(size_t)i * 64];
+#pragma unroll 1
+    for (int mt = 0; mt < MT; ++mt) {
+        v16f acc[NT];
+        const float bv = bias[mt * 32 + c];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = splat16(bv);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                int nq = mt * QPM + (g + 1) * G + i;
+                nq = nq > last ? last : nq;
+                nxt[i] = W4[(size_t)nq * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int kq = g * G + i, kt = kq / 4, q = kq % 4;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma4_swapped(X[t][kt], 4 * q, cur[i], acc[t]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -417,13 +497,32 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
 
 // ---- SA1: gather (K=8) -> 64 -> 64 -> 128 -> max over the group's 64 samples -------------------------
 // One wave per centre; both 32-sample column tiles ride together so every weight quad feeds 8 MFMAs.
-constexpr int SA1_CPW = 4;  // centres per wave
+constexpr int SA1_CPW = 8;  // centres per wave
+// LDS image of the three layers (floats): W1p 512 | W2p 4096 | W3p 8192 | b1 64 | b2 64 | b3 128  = 52 224 B.
+// The probe in tools/probes/mfma_probe.hip shows why: a chained f32 MFMA stream fed with A operands from L2 tops out
+// at 62 % of the matrix peak at two waves per SIMD (the vector-memory path, not the matrix core, sets the pace),
+// the same stream fed from LDS reaches 90-94 %.
+constexpr int SA1_W1 = 0, SA1_W2 = 512, SA1_W3 = 512 + 4096, SA1_B1 = SA1_W3 + 8192, SA1_B2 = SA1_B1 + 64,
+              SA1_B3 = SA1_B2 + 64, SA1_LDS_FLOATS = SA1_B3 + 128;
+
+__device__ __forceinline__ void stage_lds(float* dst, const float* __restrict__ src, int nfloats) {
+    for (int i = threadIdx.x * 4; i < nfloats; i += blockDim.x * 4) *(float4*)(dst + i) = *(const float4*)(src + i);
+}
+
 __global__ __launch_bounds__(256, 2) void sa1_kernel(const float* __restrict__ point_x, int M,
                                                      const int* __restrict__ ball, const float* __restrict__ cxyz,
                                                      int np, int total, const float* __restrict__ W1p,
                                                      const float* __restrict__ b1, const float* __restrict__ W2p,
                                                      const float* __restrict__ b2, const float* __restrict__ W3p,
                                                      const float* __restrict__ b3, float* __restrict__ feat) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    stage_lds(wl + SA1_W1, W1p, 512);
+    stage_lds(wl + SA1_W2, W2p, 4096);
+    stage_lds(wl + SA1_W3, W3p, 8192);
+    stage_lds(wl + SA1_B1, b1, 64);
+    stage_lds(wl + SA1_B2, b2, 64);
+    stage_lds(wl + SA1_B3, b3, 128);
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
     const int row = scatter_row(lane);
 #pragma unroll 1
@@ -432,13 +531,17 @@ __global__ __launch_bounds__(256, 2) void sa1_kernel(const float* __restrict__ p
         if (centre >= total) break;
         const int n = centre / np;
         const float cx = cxyz[(size_t)centre * 3], cy = cxyz[(size_t)centre * 3 + 1], cz = cxyz[(size_t)centre * 3 + 2];
-        W1p = opaque(W1p), W2p = opaque(W2p), W3p = opaque(W3p);
-        b1 = opaque(b1), b2 = opaque(b2), b3 = opaque(b3);
+        const float* w = wl + opaque_zero();   // per-iteration laundering (see opaque_zero)
         float4 x[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+#ifdef OSSID_ABL_NOGATHER
+            float4 r = make_float4(lane * 1e-3f + t, 0.1f * cw, 0.2f, 0.3f);
+            (void)n;
+#else
             int i = ball[(size_t)centre * 64 + t * 32 + c];
             float4 r = *(const float4*)(point_x + ((size_t)n * M + i) * 8 + 4 * h);
+#endif
             if (h == 0) {
                 r.x = r.x - cx;
                 r.y = r.y - cy;
@@ -449,10 +552,10 @@ __global__ __launch_bounds__(256, 2) void sa1_kernel(const float* __restrict__ p
         v16f Y1[2][2], Y2[2][2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            float4 a = ((const float4*)W1p)[mt * 64 + lane];
+            float4 a = ((const float4*)(w + SA1_W1))[mt * 64 + lane];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                v16f acc = bias_tile(b1, mt, h);
+                v16f acc = bias_tile(w + SA1_B1, mt, h);
                 acc = mfma(a.x, x[t].x, acc);
                 acc = mfma(a.y, x[t].y, acc);
                 acc = mfma(a.z, x[t].z, acc);
@@ -460,15 +563,21 @@ __global__ __launch_bounds__(256, 2) void sa1_kernel(const float* __restrict__ p
                 Y1[t][mt] = relu16(acc);
             }
         }
-        stream_layer<2, 2, 2, 8>((const float4*)W2p + lane, b2, Y1, h, [&](int mt, v16f(&acc)[2]) {
+        stream_layer<2, 2, 2, 4>((const float4*)(w + SA1_W2) + lane, w + SA1_B2, Y1, h, [&](int mt, v16f(&acc)[2]) {
             Y2[0][mt] = relu16(acc[0]);
             Y2[1][mt] = relu16(acc[1]);
         });
-        float* out = feat + (size_t)centre * 128 + row;
-        stream_layer_rolled<2, 2, 8>((const float4*)W3p + lane, b3, Y2, h, 4, [&](int mt, v16f(&acc)[2]) {
-            float r = reduce_scatter_max(relu16(max16(acc[0], acc[1])), lane);
-            if ((lane & 1) == 0) out[mt * 32] = r;
-        });
+        float* out = feat + (size_t)centre * 128 + c;
+        stream_last_layer<2, 2, 4>((const float4*)(w + SA1_W3) + lane, w + SA1_B3, Y2, c, 4,
+                                   [&](int mt, v16f(&acc)[2]) {
+#ifdef OSSID_ABL_NOEPI
+                                       asm volatile("" ::"v"(acc[0]), "v"(acc[1]));
+                                       if (mt == 77) out[0] = acc[0][0];
+#else
+                                       const float r = pool_swapped(max16(acc[0], acc[1]));
+                                       if (h == 0) out[mt * 32] = r;
+#endif
+                                   });
     }
 }
 
@@ -515,25 +624,36 @@ __global__ __launch_bounds__(256, 2) void p2_kernel(const float* __restrict__ fe
 // One wave per centre, its two 32-sample column tiles one after the other (a tile holds 64 + 64
 // activation registers); the first tile's pooled maxima wait in the output row and are merged by the
 // same lane when the second tile is done.
-constexpr int SA2_CPW = 2;
-__global__ __launch_bounds__(256, 2) void sa2_kernel(const float* __restrict__ P, const float* __restrict__ xyz1,
-                                                     int np1, const int* __restrict__ ball,
-                                                     const float* __restrict__ cxyz, int np2, int total,
-                                                     const float* __restrict__ wxyz, const float* __restrict__ W2p,
-                                                     const float* __restrict__ b2, const float* __restrict__ W3p,
-                                                     const float* __restrict__ b3, float* __restrict__ feat) {
+constexpr int SA2_CPW = 8;
+constexpr int SA2_THREADS = 512;                       // 8 waves = the whole CU at two waves per SIMD
+constexpr int SA2_W3 = 0, SA2_B3 = 32768, SA2_B2 = SA2_B3 + 256, SA2_WX = SA2_B2 + 128,
+              SA2_LDS_FLOATS = SA2_WX + 384;          // W3p 128 KB | b3 | b2 | wxyz  = 134 144 B
+__global__ __launch_bounds__(SA2_THREADS, 2) void sa2_kernel(const float* __restrict__ P, const float* __restrict__ xyz1,
+                                                             int np1, const int* __restrict__ ball,
+                                                             const float* __restrict__ cxyz, int np2, int total,
+                                                             const float* __restrict__ wxyz,
+                                                             const float* __restrict__ W2p, const float* __restrict__ b2,
+                                                             const float* __restrict__ W3p, const float* __restrict__ b3,
+                                                             float* __restrict__ feat) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    stage_lds(wl + SA2_W3, W3p, 32768);
+    stage_lds(wl + SA2_B3, b3, 256);
+    stage_lds(wl + SA2_B2, b2, 128);
+    stage_lds(wl + SA2_WX, wxyz, 384);
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
     const int row = scatter_row(lane);
 #pragma unroll 1
     for (int cw = 0; cw < SA2_CPW; ++cw) {
-        const int centre = (blockIdx.x * 4 + wave) * SA2_CPW + cw;
+        const int centre = (blockIdx.x * (SA2_THREADS / 64) + wave) * SA2_CPW + cw;
         if (centre >= total) break;
         const int n = centre / np2;
         const float cx = cxyz[(size_t)centre * 3], cy = cxyz[(size_t)centre * 3 + 1], cz = cxyz[(size_t)centre * 3 + 2];
-        float* out = feat + (size_t)centre * 256 + row;
+        float* out = feat + (size_t)centre * 256 + c;
 #pragma unroll 1
         for (int t = 0; t < 2; ++t) {
-            wxyz = opaque(wxyz), W2p = opaque(W2p), W3p = opaque(W3p), b2 = opaque(b2), b3 = opaque(b3);
+            const float* w = wl + opaque_zero();
+            W2p = opaque(W2p);
             const int i = ball[(size_t)centre * 64 + t * 32 + c];
             const size_t pt = (size_t)n * np1 + i;
             const float dx = xyz1[pt * 3] - cx, dy = xyz1[pt * 3 + 1] - cy, dz = xyz1[pt * 3 + 2] - cz;
@@ -544,23 +664,25 @@ __global__ __launch_bounds__(256, 2) void sa2_kernel(const float* __restrict__ P
                 for (int q = 0; q < 4; ++q) {
                     const int off = kt * 32 + 8 * q + 4 * h;
                     float4 p = *(const float4*)(P + pt * 128 + off);
-                    float4 wx = *(const float4*)(wxyz + off), wy = *(const float4*)(wxyz + 128 + off),
-                           wz = *(const float4*)(wxyz + 256 + off);
+                    float4 wx = *(const float4*)(w + SA2_WX + off), wy = *(const float4*)(w + SA2_WX + 128 + off),
+                           wz = *(const float4*)(w + SA2_WX + 256 + off);
                     X1[0][kt][4 * q + 0] = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, p.x))), 0.0f);
                     X1[0][kt][4 * q + 1] = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, p.y))), 0.0f);
                     X1[0][kt][4 * q + 2] = fmaxf(fmaf(wz.z, dz, fmaf(wy.z, dy, fmaf(wx.z, dx, p.z))), 0.0f);
                     X1[0][kt][4 * q + 3] = fmaxf(fmaf(wz.w, dz, fmaf(wy.w, dy, fmaf(wx.w, dx, p.w))), 0.0f);
                 }
             __builtin_amdgcn_sched_barrier(0);
-            stream_layer<4, 4, 1, 8>((const float4*)W2p + lane, b2, X1, h,
+            // middle layer: weights streamed from L2 (64 KB more would not fit beside W3 in the 160 KB of LDS)
+            stream_layer<4, 4, 1, 8>((const float4*)W2p + lane, w + SA2_B2, X1, h,
                                      [&](int mt, v16f(&acc)[1]) { Y2[0][mt] = relu16(acc[0]); });
-            stream_layer_rolled<4, 1, 8>((const float4*)W3p + lane, b3, Y2, h, 8, [&](int mt, v16f(&acc)[1]) {
-                float r = reduce_scatter_max(relu16(acc[0]), lane);
-                if ((lane & 1) == 0) {
-                    if (t == 1) r = fmaxf(r, out[mt * 32]);
-                    out[mt * 32] = r;
-                }
-            });
+            stream_last_layer<4, 1, 4>((const float4*)(w + SA2_W3) + lane, w + SA2_B3, Y2, c, 8,
+                                       [&](int mt, v16f(&acc)[1]) {
+                                           float r = pool_swapped(acc[0]);
+                                           if (h == 0) {
+                                               if (t == 1) r = fmaxf(r, out[mt * 32]);
+                                               out[mt * 32] = r;
+                                           }
+                                       });
         }
     }
 }
@@ -611,6 +733,7 @@ __global__ __launch_bounds__(256, 1) void sa3_kernel(const float* __restrict__ f
             }
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) an[mt] = W4[(size_t)(mt * 33 + kn) * 64];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
                 Y1[0][mt] = mfma(ac[mt].x, bc.x, Y1[0][mt]);
@@ -627,11 +750,11 @@ __global__ __launch_bounds__(256, 1) void sa3_kernel(const float* __restrict__ f
         for (int mt = 0; mt < 8; ++mt) Y1[0][mt] = relu16(Y1[0][mt]);
         stream_layer<8, 16, 1, 4>((const float4*)W2p + lane, b2, Y1, h,
                                   [&](int mt, v16f(&acc)[1]) { Y2[0][mt] = relu16(acc[0]); });
-        stream_layer_rolled<16, 1, 8>((const float4*)W3p + lane, b3, Y2, h, 32, [&](int mt, v16f(&acc)[1]) {
-            float v = reduce_scatter_max(relu16(acc[0]), lane);
-            if ((lane & 1) == 0) {
-                float* s = &red[wave][mt * 32 + row];
-                *s = fmaxf(*s, v);
+        stream_last_layer<16, 1, 8>((const float4*)W3p + lane, b3, Y2, c, 32, [&](int mt, v16f(&acc)[1]) {
+            const float v = pool_swapped(acc[0]);
+            if (h == 0) {
+                float* sl = &red[wave][mt * 32 + c];
+                *sl = fmaxf(*sl, v);
             }
         });
     }
@@ -867,7 +990,10 @@ int ossid_pn2_score(const float* point_x, int B, int M, const ossid_pn2_weights*
     {
         const int total = B * np1;
         const int grid = (total + 4 * SA1_CPW - 1) / (4 * SA1_CPW);
-        hipLaunchKernelGGL(sa1_kernel, dim3(grid), dim3(256), 0, s, point_x, M, ws.ball1, ws.xyz1, np1, total, W(0),
+        if (hipFuncSetAttribute((const void*)sa1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SA1_LDS_FLOATS * 4) != hipSuccess)
+            return OSSID_ELAUNCH;
+        hipLaunchKernelGGL(sa1_kernel, dim3(grid), dim3(256), SA1_LDS_FLOATS * 4, s, point_x, M, ws.ball1, ws.xyz1, np1, total, W(0),
                            Bv(0), W(1), Bv(1), W(2), Bv(2), ws.feat1);
         if ((rc = ossid_launch_status())) return rc;
     }
@@ -885,8 +1011,12 @@ int ossid_pn2_score(const float* point_x, int B, int M, const ossid_pn2_weights*
     mark();
     {
         const int total = B * np2;
-        const int grid = (total + 4 * SA2_CPW - 1) / (4 * SA2_CPW);
-        hipLaunchKernelGGL(sa2_kernel, dim3(grid), dim3(256), 0, s, ws.p2, ws.xyz1, np1, ws.ball2, ws.xyz2, np2,
+        const int per_wg = (SA2_THREADS / 64) * SA2_CPW;
+        const int grid = (total + per_wg - 1) / per_wg;
+        if (hipFuncSetAttribute((const void*)sa2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SA2_LDS_FLOATS * 4) != hipSuccess)
+            return OSSID_ELAUNCH;
+        hipLaunchKernelGGL(sa2_kernel, dim3(grid), dim3(SA2_THREADS), SA2_LDS_FLOATS * 4, s, ws.p2, ws.xyz1, np1, ws.ball2, ws.xyz2, np2,
                            total, blob + w->wxyz2_off, W(4), Bv(4), W(5), Bv(5), ws.feat2);
         if ((rc = ossid_launch_status())) return rc;
     }
