@@ -132,9 +132,21 @@ const char* ossid_pn2_kernel_names(void);
  * F.conv2d(x.view(1,B*C,H,W), k.view(B*C,1,3,3), groups=B*C, padding=1): per-plane 3x3 cross-correlation with a
  * data-dependent kernel. planes = B*C; x, out, dout, dx [planes][H][W]; k, dk [planes][3][3].
  * _bwd_x: gradient w.r.t. x; _bwd_k: gradient w.r.t. the kernel (gradients flow to both operands). */
-int ossid_dw_xcorr_fwd(const float* x, const float* k, int planes, int H, int W, float* out, void* stream);
+int ossid_dw_xcorr_fwd(const float* x, int x_planes, const float* k, int planes, int H, int W, float* out,
+                       void* stream);   /* x_planes = planes, or C when ONE image [C][H][W] is shared by all B kernels */
 int ossid_dw_xcorr_bwd_x(const float* dout, const float* k, int planes, int H, int W, float* dx, void* stream);
 int ossid_dw_xcorr_bwd_k(const float* x, const float* dout, int planes, int H, int W, float* dk, void* stream);
+
+/* D6-D8  the dense 3x3 convolutions of the head at test time      network.py:102-110, :135-143, :288-326
+ * (nn.Conv2d(k=3, stride 1, padding 1) -> optional F.elu -> optional BatchNorm2d(eval)), channels-last:
+ * x [B][H][W][Cin] (Cin % 16 == 0), out [B][H][W][Cout] (Cout % 4 == 0), exact f32 on the matrix cores.
+ * wpk = ossid_conv3x3_pack_weights(w [Cout][Cin][3][3]); bias / bn_scale / bn_shift [Cout] may be NULL;
+ * act 0 = none, 1 = ELU(alpha 1); out = (act(conv + bias)) * bn_scale + bn_shift. */
+size_t ossid_conv3x3_packed_floats(int Cout, int Cin);
+int ossid_conv3x3_pack_weights(const float* w, int Cout, int Cin, float* wpk, void* stream);
+int ossid_conv3x3_nhwc_fwd(const float* x, const float* wpk, const float* bias, const float* bn_scale,
+                           const float* bn_shift, float* out, int B, int H, int W, int Cin, int Cout, int act,
+                           void* stream);
 
 /* D12  torchvision.ops.nms(boxes, scores, iou_threshold)      network.py:563, models/dtoid/utils.py:33
  * boxes [n][4] (x1,y1,x2,y2) ALREADY sorted by descending score (network.py:555 feeds it the top-k order);

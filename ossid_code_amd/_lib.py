@@ -38,9 +38,12 @@ _PROTOS = {
     "ossid_event_record": (_i, [_vp, _vp]),
     "ossid_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(_f)]),
     "ossid_pn2_kernel_names": (C.c_char_p, []),
-    "ossid_dw_xcorr_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ossid_dw_xcorr_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "ossid_dw_xcorr_bwd_x": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ossid_dw_xcorr_bwd_k": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ossid_conv3x3_packed_floats": (_sz, [_i, _i]),
+    "ossid_conv3x3_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
+    "ossid_conv3x3_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ossid_nms_workspace_bytes": (_sz, [_i]),
     "ossid_nms": (_i, [_vp, _i, _f, _vp, _sz, _vp, _vp, _vp]),
     "ossid_decode_clip_boxes": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),

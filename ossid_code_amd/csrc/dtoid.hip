@@ -17,11 +17,13 @@ namespace {
 // the input: dx = dout (*) rot180(k).
 constexpr int DW_TX = 64, DW_TY = 4;
 __global__ __launch_bounds__(256) void dw_xcorr_kernel(const float* __restrict__ in, const float* __restrict__ k, int H,
-                                                       int W, int flip, float* __restrict__ out) {
+                                                       int W, int flip, float* __restrict__ out, int in_planes,
+                                                       int plane0) {
     __shared__ float tile[(DW_TY + 2) * (DW_TX + 2)];
     const int p = blockIdx.z;
     const int x0 = blockIdx.x * DW_TX - 1, y0 = blockIdx.y * DW_TY - 1;
-    const float* src = in + (size_t)p * H * W;
+    // in_planes < planes: the input is ONE image [C,H,W] shared by every template (test time, network.py:512)
+    const float* src = in + (size_t)((plane0 + p) % in_planes) * H * W;
     for (int i = threadIdx.x; i < (DW_TY + 2) * (DW_TX + 2); i += 256) {
         int lx = i % (DW_TX + 2), ly = i / (DW_TX + 2);
         int gx = x0 + lx, gy = y0 + ly;
@@ -185,15 +187,18 @@ __global__ __launch_bounds__(256) void amsgrad_kernel(float4* __restrict__ p, co
 
 extern "C" {
 
-int ossid_dw_xcorr_fwd(const float* x, const float* k, int planes, int H, int W, float* out, void* stream) {
-    if (planes < 0 || H <= 0 || W <= 0 || planes > 65535 * 16) return OSSID_EINVAL;
+int ossid_dw_xcorr_fwd(const float* x, int x_planes, const float* k, int planes, int H, int W, float* out,
+                       void* stream) {
+    if (planes < 0 || H <= 0 || W <= 0 || planes > 65535 * 16 || x_planes <= 0 || x_planes > planes ||
+        (planes && planes % x_planes))
+        return OSSID_EINVAL;
     if (planes == 0) return OSSID_OK;
     if (!x || !k || !out) return OSSID_EINVAL;
     for (int p0 = 0; p0 < planes; p0 += 65535) {
         const int np = planes - p0 < 65535 ? planes - p0 : 65535;
         dim3 grid((W + DW_TX - 1) / DW_TX, (H + DW_TY - 1) / DW_TY, np);
-        hipLaunchKernelGGL(dw_xcorr_kernel, grid, dim3(256), 0, (hipStream_t)stream, x + (size_t)p0 * H * W,
-                           k + (size_t)p0 * 9, H, W, 0, out + (size_t)p0 * H * W);
+        hipLaunchKernelGGL(dw_xcorr_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, k + (size_t)p0 * 9, H, W, 0,
+                           out + (size_t)p0 * H * W, x_planes, p0);
     }
     return ossid_launch_status();
 }
@@ -205,8 +210,8 @@ int ossid_dw_xcorr_bwd_x(const float* dout, const float* k, int planes, int H, i
     for (int p0 = 0; p0 < planes; p0 += 65535) {
         const int np = planes - p0 < 65535 ? planes - p0 : 65535;
         dim3 grid((W + DW_TX - 1) / DW_TX, (H + DW_TY - 1) / DW_TY, np);
-        hipLaunchKernelGGL(dw_xcorr_kernel, grid, dim3(256), 0, (hipStream_t)stream, dout + (size_t)p0 * H * W,
-                           k + (size_t)p0 * 9, H, W, 1, dx + (size_t)p0 * H * W);
+        hipLaunchKernelGGL(dw_xcorr_kernel, grid, dim3(256), 0, (hipStream_t)stream, dout, k + (size_t)p0 * 9, H, W, 1,
+                           dx + (size_t)p0 * H * W, planes, p0);
     }
     return ossid_launch_status();
 }

@@ -212,7 +212,61 @@ class CorrelationModel(nn.Module):
         return x2, heat_map, segmentation
 
 
+class FusedHead:
+    """Test-time execution plan of the correlation / detection head on the hand-written MFMA convolution
+    (csrc/conv.hip): every 3x3 stride-1 conv runs channels-last with its ELU and eval-mode BatchNorm folded into the
+    epilogue. Built from (and re-built whenever they change) the parameters of the nn.Modules, which stay the single
+    source of truth -- training and state_dict handling never see this object."""
+
+    def __init__(self, corr, cls, reg):
+        P = ops.PackedConv3x3
+        self.corr = corr
+        self.dot = P(corr.corr_conv_dot, corr.norm_corr_dot, act=True)
+        self.sub = P(corr.corr_conv_sub, corr.norm_corr_sub, act=True)
+        self.dot3 = P(corr.corr_conv_dot3x3, corr.norm_corr_dot3x3, act=True)
+        self.cf = P(corr.cf, corr.nf, act=True)
+        self.seg = [P(getattr(corr, "s%d" % i), getattr(corr, "ns%d" % i), act=True) for i in (1, 2, 3, 4, 5)]
+        self.cls = [P(getattr(cls, "conv%d" % i), act=True) for i in (1, 2, 3, 4)] + [P(cls.output)]
+        self.reg = [P(getattr(reg, "conv%d" % i), act=True) for i in (1, 2, 3, 4)] + [P(reg.output)]
+        self.num_classes = cls.num_classes
+
+    @staticmethod
+    def version_key(*mods):
+        return tuple(int(t._version) for m in mods for t in list(m.parameters()) + list(m.buffers())) + \
+            tuple(t.data_ptr() for m in mods for t in m.parameters())
+
+    def correlation(self, image_feat, template_feat):
+        corr = self.corr
+        t2 = corr._cab(corr.c2, corr.n2, corr._cab(corr.c1, corr.n1, template_feat))
+        dot3x3 = ops.dw_xcorr(image_feat, t2)
+        avg = F.avg_pool2d(template_feat, 7)
+        x = torch.cat([self.dot(image_feat * avg), self.sub(image_feat - avg), self.dot3(dot3x3)], dim=1)
+        x2 = self.cf(x)
+        heat_map = torch.sigmoid(corr.corr_conv_heatmap(x2))
+        s = x2
+        for i in range(3):
+            s = F.interpolate(self.seg[i](s), scale_factor=2, mode="nearest")
+        s = F.interpolate(self.seg[3](s), size=corr.img_size, mode="nearest")
+        return x2, heat_map, corr.seg_final(self.seg[4](s))
+
+    @staticmethod
+    def _trunk(convs, x):
+        for cv in convs:
+            x = cv(x)
+        return x
+
+    def classification(self, x2):
+        out = torch.sigmoid(self._trunk(self.cls, x2))
+        return out.permute(0, 2, 3, 1).reshape(x2.shape[0], -1, self.num_classes)
+
+    def regression(self, x2):
+        out = self._trunk(self.reg, x2)
+        return out.permute(0, 2, 3, 1).reshape(x2.shape[0], -1, 4)
+
+
 class Network(nn.Module):
+    use_fused_head = True     # test-time head on csrc/conv.hip; False = the nn.Module path (MIOpen convolutions)
+
     def __init__(self, img_size=(480, 480), heatmap_size=(29, 29), template_size=124):
         super().__init__()
         self.img_size, self.heatmap_size = img_size, heatmap_size
@@ -230,6 +284,15 @@ class Network(nn.Module):
             conv.bias.data.fill_(b)
         self.regressBoxes = BBoxTransform()
         self.clipBoxes = ClipBoxes()
+
+    def _fused_head(self):
+        mods = (self.correlation_model, self.classification, self.regression)
+        key = FusedHead.version_key(*mods)
+        cached = self.__dict__.get("_fused_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, FusedHead(*mods))
+            self.__dict__["_fused_cache"] = cached
+        return cached[1]
 
     def load(self, path):
         ckpt = torch.load(path, map_location="cpu")
@@ -262,11 +325,17 @@ class Network(nn.Module):
         -> [max_score [k], anchors_pred [k,4], obj_indices [k,1], seg_pred [k,H,W], heatmap_pred [k,hh,hw]]"""
         with torch.no_grad():
             features = self.image_feature_extractor(image, template_features_global[0])
+            fused = self._fused_head() if (self.use_fused_head and features.is_cuda and not self.training) else None
             cls_out, reg_out, seg_out, heat_out = [], [], [], []
             for chunk in template_features:
-                xc, heat, seg = self.correlation_model(features.expand(chunk.size(0), -1, -1, -1), chunk, True)
-                cls_out.append(self.classification(xc)[0])
-                reg_out.append(self.regression(xc))
+                if fused is not None:
+                    xc, heat, seg = fused.correlation(features, chunk)
+                    cls_out.append(fused.classification(xc))
+                    reg_out.append(fused.regression(xc))
+                else:
+                    xc, heat, seg = self.correlation_model(features.expand(chunk.size(0), -1, -1, -1), chunk, True)
+                    cls_out.append(self.classification(xc)[0])
+                    reg_out.append(self.regression(xc))
                 seg_out.append(seg)
                 heat_out.append(heat)
             cls_all, reg_all = torch.cat(cls_out, 0), torch.cat(reg_out, 0)       # [n_t, A, 2], [n_t, A, 4]

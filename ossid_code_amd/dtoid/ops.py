@@ -9,19 +9,22 @@ class _DwXcorr(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k):
         _lib.require_cuda(x, k)
-        B, C, H, W = x.shape
-        x = x.contiguous().float()
+        B, C, H, W = k.shape[0], x.shape[1], x.shape[2], x.shape[3]
+        x = x.contiguous().float()          # [B,C,H,W], or [1,C,H,W] shared by all B kernels
         k = k.contiguous().float()
-        out = torch.empty_like(x)
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(_lib.fn("ossid_dw_xcorr_fwd")(x.data_ptr(), k.data_ptr(), B * C, H, W, out.data_ptr(),
-                                                     _lib.stream()), "ossid_dw_xcorr_fwd")
+            _lib.check(_lib.fn("ossid_dw_xcorr_fwd")(x.data_ptr(), x.shape[0] * C, k.data_ptr(), B * C, H, W,
+                                                     out.data_ptr(), _lib.stream()), "ossid_dw_xcorr_fwd")
+        if x.shape[0] != B:
+            x = x.expand(B, -1, -1, -1)     # only materialised if a backward pass asks for it
         ctx.save_for_backward(x, k)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, k = ctx.saved_tensors
+        x = x.contiguous()
         B, C, H, W = x.shape
         dout = dout.contiguous()
         dx = dk = None
@@ -43,7 +46,12 @@ def dw_xcorr(x, kernel):
     if kernel.shape[-2:] != (3, 3):
         raise ValueError("dw_xcorr is built for 3x3 kernels")
     if x.shape[0] != kernel.shape[0]:
-        x = x.expand(kernel.shape[0], -1, -1, -1)
+        if x.shape[0] != 1:
+            raise ValueError("dw_xcorr: batch of x must be 1 or equal the kernel's")
+        if x.requires_grad:
+            x = x.expand(kernel.shape[0], -1, -1, -1)
+        else:
+            x = x[:1]
     return _DwXcorr.apply(x, kernel)
 
 
@@ -76,3 +84,45 @@ def decode_clip_boxes(anchors, deltas, img_w, img_h):
         _lib.check(_lib.fn("ossid_decode_clip_boxes")(a.data_ptr(), d.data_ptr(), R, A, float(img_w), float(img_h),
                                                       out.data_ptr(), _lib.stream()), "ossid_decode_clip_boxes")
     return out
+
+
+class PackedConv3x3:
+    """Weights of one nn.Conv2d(k=3, stride 1, padding 1) in the MFMA operand layout of csrc/conv.hip, plus the fused
+    epilogue vectors (bias, and the eval-mode BatchNorm affine that follows the ELU in the reference head)."""
+
+    def __init__(self, conv, bn=None, act=False):
+        w = conv.weight.detach().float().contiguous()
+        _lib.require_cuda(w)
+        self.cout, self.cin = int(w.shape[0]), int(w.shape[1])
+        if tuple(w.shape[2:]) != (3, 3) or conv.stride != (1, 1) or conv.padding != (1, 1) or self.cin % 16 or self.cout % 4:
+            raise ValueError("PackedConv3x3 handles 3x3 / stride 1 / padding 1 with Cin % 16 == 0 and Cout % 4 == 0")
+        n = _lib.fn("ossid_conv3x3_packed_floats")(self.cout, self.cin)
+        self.wpk = torch.empty(n, dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(_lib.fn("ossid_conv3x3_pack_weights")(w.data_ptr(), self.cout, self.cin, self.wpk.data_ptr(),
+                                                             _lib.stream()), "ossid_conv3x3_pack_weights")
+        self.bias = None if conv.bias is None else conv.bias.detach().float().contiguous()
+        self.act = 1 if act else 0
+        self.scale = self.shift = None
+        if bn is not None:
+            inv = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+            self.scale = (bn.weight.detach().float() * inv).contiguous()
+            self.shift = (bn.bias.detach().float() - bn.running_mean.detach().float() * self.scale).contiguous()
+
+    def __call__(self, x):
+        """x: logical [B,Cin,H,W] tensor (any memory format; channels_last is consumed in place) -> logical
+        [B,Cout,H,W] tensor in channels_last memory format."""
+        _lib.require_cuda(x)
+        B, C, H, W = x.shape
+        if C != self.cin:
+            raise ValueError("expected %d input channels, got %d" % (self.cin, C))
+        x = x.float().contiguous(memory_format=torch.channels_last)
+        out = torch.empty((B, self.cout, H, W), dtype=torch.float32, device=x.device,
+                          memory_format=torch.channels_last)
+        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        with torch.cuda.device(x.device):
+            rc = _lib.fn("ossid_conv3x3_nhwc_fwd")(x.data_ptr(), self.wpk.data_ptr(), p(self.bias), p(self.scale),
+                                                   p(self.shift), out.data_ptr(), B, H, W, self.cin, self.cout, self.act,
+                                                   _lib.stream())
+        _lib.check(rc, "ossid_conv3x3_nhwc_fwd")
+        return out

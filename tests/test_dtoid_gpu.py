@@ -140,3 +140,80 @@ def test_full_network_shapes_and_finetune_step_480x640(hiplib):
     assert local[0].is_cuda and local[0].shape == (nt, 640, 7, 7) and glob[0].shape == (1, 64, 3, 3)
     res2 = m.forwardTestTime(test)                           # second frame: served from the device-resident cache
     assert torch.equal(res2["pred_bbox"], res["pred_bbox"])
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [
+    (3, 640, 256, 29, 39),     # correlation convs (WM=4, FLAT)
+    (21, 768, 512, 29, 39),    # fusion conv at n_t = 21 (NT=4)
+    (2, 512, 48, 29, 39),      # classification output: Cout not a multiple of 32 (WM=2)
+    (2, 256, 96, 29, 39),      # regression output: 3 channel tiles
+    (2, 256, 128, 58, 78),     # decoder s2
+    (1, 128, 64, 116, 156),    # decoder s3 (ROWSEG, WM=2)
+    (1, 32, 16, 480, 640),     # decoder s5 (ROWSEG, single channel tile)
+    (2, 16, 32, 5, 7),         # tiny image, one chunk
+    (1, 64, 32, 1, 1),         # degenerate spatial size
+])
+def test_conv3x3_mfma_matches_torch(hiplib, B, Cin, Cout, H, W):
+    """Hand-written implicit-GEMM convolution vs torch (float64 on the CPU as ground truth).
+    Tolerance: exact-f32 fmaf chains over up to 9*768 terms -> 2e-5 of the output scale."""
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1)
+    bn = torch.nn.BatchNorm2d(Cout).eval()
+    with torch.no_grad():
+        bn.running_mean.copy_(0.1 * torch.randn(Cout, generator=g))
+        bn.running_var.copy_(0.5 + torch.rand(Cout, generator=g))
+        bn.weight.copy_(1 + 0.2 * torch.randn(Cout, generator=g))
+        bn.bias.copy_(0.1 * torch.randn(Cout, generator=g))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    with torch.no_grad():
+        ref_plain = conv.double()(x.double())
+        ref_fused = bn.double()(torch.nn.functional.elu(ref_plain))
+    conv, bn = conv.float().cuda(), bn.float().cuda()
+    scale = float(ref_plain.abs().max())
+    got = ops.PackedConv3x3(conv)(x.cuda())
+    assert got.shape == (B, Cout, H, W) and got.is_contiguous(memory_format=torch.channels_last)
+    assert float((got.cpu().double() - ref_plain).abs().max()) <= 2e-5 * scale
+    got = ops.PackedConv3x3(conv, bn=bn, act=True)(x.cuda().contiguous(memory_format=torch.channels_last))
+    assert float((got.cpu().double() - ref_fused).abs().max()) <= 2e-5 * max(scale, float(ref_fused.abs().max()))
+
+
+def test_fused_head_matches_module_path(hiplib):
+    """The test-time head on the hand-written conv (fused ELU+BN epilogues, channels-last) vs the nn.Module path
+    (MIOpen convolutions), compared on the DENSE outputs (post-NMS lists of a random-weight network are ill-conditioned):
+    class probabilities / box deltas / heat maps / segmentation logits within 1e-4 of the output scale."""
+    torch.manual_seed(3)
+    net = dtoid.Network(img_size=(480, 640), heatmap_size=(29, 39)).cuda().eval()
+    with torch.no_grad():   # the zero-initialised output layers would make every output a constant
+        for conv in (net.classification.output, net.regression.output, net.correlation_model.seg_final,
+                     net.correlation_model.corr_conv_heatmap):
+            conv.weight.normal_(0, 0.05)
+    feat = torch.randn(1, 640, 29, 39, device="cuda")
+    tmpl = torch.randn(4, 640, 7, 7, device="cuda")
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max().clamp(min=1e-6))
+
+    with torch.no_grad():
+        x2r, heatr, segr = net.correlation_model(feat.expand(4, -1, -1, -1), tmpl, True)
+        clsr, regr = net.classification(x2r)[0], net.regression(x2r)
+        fused = net._fused_head()
+        x2, heat, seg = fused.correlation(feat, tmpl)
+        cls, reg = fused.classification(x2), fused.regression(x2)
+    assert x2.shape == x2r.shape and seg.shape == (4, 1, 480, 640) and cls.shape == (4, 27144, 2)
+    for name, a, b in (("x2", x2, x2r), ("heat", heat, heatr), ("seg", seg, segr), ("cls", cls, clsr), ("reg", reg, regr)):
+        assert rel(a, b) < 1e-4, (name, rel(a, b))
+    # weights changed (a finetune step) -> the packed plan is rebuilt
+    with torch.no_grad():
+        net.classification.conv1.weight.mul_(1.5)
+        cls2r = net.classification(x2r)[0]
+        cls2 = net._fused_head().classification(x2)
+    assert net._fused_head() is not fused and rel(cls2, cls2r) < 1e-4 and rel(cls2, cls) > 1e-3
+    # and the whole test-time call runs on it
+    img = torch.rand(1, 3, 480, 640, device="cuda")
+    tm = torch.rand(5, 4, 124, 124, device="cuda")
+    with torch.no_grad():
+        g = [net.compute_template_global(tm[:1])]
+        loc = [net.compute_template_local(tm[:3]), net.compute_template_local(tm[3:])]
+        out = net.forward_all_templates(img, loc, g, topk=50)
+    k = out[0].shape[0]
+    assert 1 <= k <= 50 and out[1].shape == (k, 4) and out[3].shape == (k, 480, 640) and out[4].shape == (k, 29, 39)

@@ -53,6 +53,13 @@ def main():
                 oh, ow = (hw[0] - 2, hw[1] - 2) if pad == 0 else hw
                 fl = 2.0 * B * oh * ow * co * ci * k * k
                 out["conv %s B=%d" % (name, B)] = {"ms": t * 1e3, "TFLOPs": fl / t / 1e12}
+                if pad == 1:
+                    from ossid_code_amd.dtoid import ops
+                    cv = torch.nn.Conv2d(ci, co, 3, padding=1).cuda()
+                    pk = ops.PackedConv3x3(cv)
+                    xl = x.contiguous(memory_format=torch.channels_last)
+                    t = timeit(lambda: pk(xl))
+                    out["conv %s B=%d" % (name, B)].update({"hip_ms": t * 1e3, "hip_TFLOPs": fl / t / 1e12})
     if "forward" in a.what:
         m = dtoid.DtoidNet(cfg).cuda().eval()
         b = _batch(cfg, 1, "cuda")
