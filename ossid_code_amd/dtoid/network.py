@@ -266,6 +266,7 @@ class FusedHead:
 
 class Network(nn.Module):
     use_fused_head = True     # test-time head on csrc/conv.hip; False = the nn.Module path (MIOpen convolutions)
+    use_graph = True          # replay the dense part of forward_all_templates from a captured hipGraph
 
     def __init__(self, img_size=(480, 480), heatmap_size=(29, 29), template_size=124):
         super().__init__()
@@ -320,28 +321,70 @@ class Network(nn.Module):
         classifications, _ = self.classification(xcors)
         return classifications, self.regression(xcors), anchors, heat_map, segmentation
 
+    def _dense_all_templates(self, image, template_features, template_global):
+        """Backbone once + head per template chunk -> dense (cls [n_t,A,2], reg [n_t,A,4], seg [n_t,1,H,W],
+        heat [n_t,1,hh,hw], feature-map shape). No host syncs, no data-dependent shapes: capturable in a hipGraph."""
+        features = self.image_feature_extractor(image, template_global)
+        fused = self._fused_head() if (self.use_fused_head and features.is_cuda and not self.training) else None
+        cls_out, reg_out, seg_out, heat_out = [], [], [], []
+        for chunk in template_features:
+            if fused is not None:
+                xc, heat, seg = fused.correlation(features, chunk)
+                cls_out.append(fused.classification(xc))
+                reg_out.append(fused.regression(xc))
+            else:
+                xc, heat, seg = self.correlation_model(features.expand(chunk.size(0), -1, -1, -1), chunk, True)
+                cls_out.append(self.classification(xc)[0])
+                reg_out.append(self.regression(xc))
+            seg_out.append(seg)
+            heat_out.append(heat)
+        return (torch.cat(cls_out, 0), torch.cat(reg_out, 0), torch.cat(seg_out, 0), torch.cat(heat_out, 0),
+                (xc.size(2), xc.size(3)))
+
+    def _graphed_dense(self, image, template_features, template_global):
+        """The dense part replayed from a captured hipGraph (the B=1 backbone alone is ~500 launches and otherwise
+        host-bound). One graph per (image shape, chunk sizes, packed-head identity); inputs are copied into the
+        graph's static buffers, outputs are read from them."""
+        fused = self._fused_head() if self.use_fused_head else None
+        key = (tuple(image.shape), tuple(int(c.shape[0]) for c in template_features), id(fused), str(image.device))
+        cache = self.__dict__.setdefault("_graph_cache", {})
+        entry = cache.get(key)
+        if entry is None:
+            if len(cache) >= 4:
+                cache.clear()
+            s_img, s_tf = image.clone(), [c.clone() for c in template_features]
+            s_g = template_global.clone()
+            side = torch.cuda.Stream(device=image.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):           # warm-up off the capture: MIOpen picks its kernels here
+                for _ in range(2):
+                    self._dense_all_templates(s_img, s_tf, s_g)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._dense_all_templates(s_img, s_tf, s_g)
+            entry = (graph, s_img, s_tf, s_g, outs, fused)
+            cache[key] = entry
+        graph, s_img, s_tf, s_g, outs, _ = entry
+        s_img.copy_(image)
+        s_g.copy_(template_global)
+        for dst, src in zip(s_tf, template_features):
+            dst.copy_(src)
+        graph.replay()
+        return outs
+
     def forward_all_templates(self, image, template_features, template_features_global, topk=1):
         """image [1,3,H,W]; template_features: list of [n_i,640,7,7] chunks; template_features_global: [[1,64,3,3]]
         -> [max_score [k], anchors_pred [k,4], obj_indices [k,1], seg_pred [k,H,W], heatmap_pred [k,hh,hw]]"""
         with torch.no_grad():
-            features = self.image_feature_extractor(image, template_features_global[0])
-            fused = self._fused_head() if (self.use_fused_head and features.is_cuda and not self.training) else None
-            cls_out, reg_out, seg_out, heat_out = [], [], [], []
-            for chunk in template_features:
-                if fused is not None:
-                    xc, heat, seg = fused.correlation(features, chunk)
-                    cls_out.append(fused.classification(xc))
-                    reg_out.append(fused.regression(xc))
-                else:
-                    xc, heat, seg = self.correlation_model(features.expand(chunk.size(0), -1, -1, -1), chunk, True)
-                    cls_out.append(self.classification(xc)[0])
-                    reg_out.append(self.regression(xc))
-                seg_out.append(seg)
-                heat_out.append(heat)
-            cls_all, reg_all = torch.cat(cls_out, 0), torch.cat(reg_out, 0)       # [n_t, A, 2], [n_t, A, 4]
-            seg_all, heat_all = torch.cat(seg_out, 0), torch.cat(heat_out, 0)     # [n_t, 1, H, W], [n_t, 1, hh, hw]
+            if self.use_graph and image.is_cuda and not self.training:
+                cls_all, reg_all, seg_all, heat_all, fmap = self._graphed_dense(image, template_features,
+                                                                                template_features_global[0])
+            else:
+                cls_all, reg_all, seg_all, heat_all, fmap = self._dense_all_templates(image, template_features,
+                                                                                      template_features_global[0])
             n_t, A = reg_all.shape[0], reg_all.shape[1]
-            anchors = self.anchors([[xc.size(2), xc.size(3)]], device=xc.device)
+            anchors = self.anchors([list(fmap)], device=reg_all.device)
             boxes = ops.decode_clip_boxes(anchors, reg_all, image.shape[3], image.shape[2]).view(-1, 4)
             k = min(1000, n_t * A)
             max_score, max_id = torch.topk(cls_all.reshape(-1, 2)[:, 1], k)      # class 1 = object
