@@ -236,7 +236,14 @@ def main():
         if base_scores is not None:   # the GPU scores of the sampled hypotheses are the oracle's, bit for bit
             got = scores[: len(base_scores)].cpu().numpy()
             assert np.array_equal(got, base_scores), "GPU scores differ from the CPU oracle"
+        traffic = None
+        try:   # HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+        except Exception:
+            pmc = {}
         dom = max(STAGE_FLOPS, key=lambda k: stage_ms[names.index(k)])
+        if dom + "_kernel" in pmc:
+            traffic = pmc[dom + "_kernel"]["traffic_bytes"]
         dom_ms = float(stage_ms[names.index(dom)])
         achieved = STAGE_FLOPS[dom] * N_HYP / (dom_ms * 1e-3) / 1e12
         feat_bytes = N_HYP * N_PTS * (32 + 8) + IMG_H * IMG_W * 16 + N_PTS * 48 + N_HYP * 64
@@ -252,7 +259,7 @@ def main():
                        "top1": top1},
             "roofline": {"bound": "mfma", "kernel": dom + "_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
-                         "traffic": None, "avg_launch_ms": dom_ms,
+                         "traffic": traffic, "avg_launch_ms": dom_ms,
                          "flops_per_launch": STAGE_FLOPS[dom] * N_HYP},
             "stage_ms": {n: round(float(v), 4) for n, v in zip(names, stage_ms)},
             "featurize": {"bound": "hbm", "avg_launch_ms": feat_ms, "achieved": feat_bytes / (feat_ms * 1e-3) / 1e9,
