@@ -74,6 +74,13 @@ int ossid_zephyr_featurize(const float* rgbd, int H, int W, const float* transfo
                            int Nsel, const float* tab, int M, float fx, float fy, float cx, float cy,
                            int interp, float* point_x, int32_t* uv_original, void* stream);
 
+/* SURVEY 8f-2 (the step right before Z0): per-hypothesis ADD / ADI pose error
+ *   pp_err = [err_func(R, t, R_gt, t_gt, model_points) for mat in poses_all]       scripts/online_learning.py:452
+ * err_func = zephyr.utils.metrics.add (symmetric=0) or adi (symmetric=1); float64 like the numpy reference.
+ * transforms [N,4,4], transform_gt [4,4], points [M,3] (M*24 B <= 150 KB for ADI) -> err [N]. */
+int ossid_pose_errors(const double* transforms, const double* transform_gt, const double* points, int N, int M,
+                      int symmetric, double* err, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Z3  zephyr.models.pointnet2.PointNet2SSG.forward({"point_x": ...})
  *     ctor scripts/online_learning.py:212-227; call utils/zephyr_utils.py:34

@@ -28,6 +28,7 @@ _PROTOS = {
     "ossid_zephyr_project_uv": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp]),
     "ossid_zephyr_inconst_count": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp]),
     "ossid_zephyr_featurize": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
+    "ossid_pose_errors": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ossid_pn2_fps": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ossid_pn2_ball_query": (_i, [_vp, _i, _i, _i, _vp, _i, _f, _i, _vp, _vp]),
     "ossid_pn2_workspace_bytes": (_sz, [_i, _i, _i, _i]),

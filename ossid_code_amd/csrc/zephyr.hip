@@ -381,3 +381,83 @@ int ossid_zephyr_featurize(const float* rgbd, int H, int W, const float* transfo
 }
 
 }  // extern "C"
+
+// ---- per-hypothesis pose error (the step right before Z0) ------------------------------------------
+// Stands behind the list comprehension of scripts/online_learning.py:452,
+//   pp_err = [err_func(R, t, R_gt, t_gt, model_points) for mat in poses_all],  err_func = zephyr.utils.metrics.add / adi
+// (BOP definitions: ADD = mean_i |(R p_i + t) - (R_gt p_i + t_gt)|, ADI = mean_i min_j |(R p_i + t) - (R_gt p_j + t_gt)|).
+// float64 like the numpy reference. One workgroup per hypothesis; the ground-truth cloud is transformed once per
+// workgroup into LDS for ADI (M^2 distance evaluations per hypothesis), sums by wave butterfly + LDS combine.
+namespace {
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__device__ __forceinline__ void xform(const double* __restrict__ T, double x, double y, double z, double& ox, double& oy,
+                                      double& oz) {
+    ox = T[0] * x + T[1] * y + T[2] * z + T[3];
+    oy = T[4] * x + T[5] * y + T[6] * z + T[7];
+    oz = T[8] * x + T[9] * y + T[10] * z + T[11];
+}
+
+template <bool SYM>
+__global__ __launch_bounds__(256) void pose_error_kernel(const double* __restrict__ T, const double* __restrict__ Tgt,
+                                                         const double* __restrict__ pts, int M,
+                                                         double* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* gt = (double*)smem_raw;   // [M][3] ground-truth points (ADI only)
+    __shared__ double red[4];
+    const double* Tn = T + 16 * (size_t)blockIdx.x;
+    if (SYM) {
+        for (int j = threadIdx.x; j < M; j += 256)
+            xform(Tgt, pts[3 * j], pts[3 * j + 1], pts[3 * j + 2], gt[3 * j], gt[3 * j + 1], gt[3 * j + 2]);
+        __syncthreads();
+    }
+    double s = 0.0;
+    for (int i = threadIdx.x; i < M; i += 256) {
+        double ex, ey, ez;
+        xform(Tn, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], ex, ey, ez);
+        if (SYM) {
+            double best = 1e300;
+            for (int j = 0; j < M; ++j) {
+                const double dx = ex - gt[3 * j], dy = ey - gt[3 * j + 1], dz = ez - gt[3 * j + 2];
+                best = fmin(best, dx * dx + dy * dy + dz * dz);
+            }
+            s += sqrt(best);
+        } else {
+            double gx, gy, gz;
+            xform(Tgt, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], gx, gy, gz);
+            const double dx = ex - gx, dy = ey - gy, dz = ez - gz;
+            s += sqrt(dx * dx + dy * dy + dz * dz);
+        }
+    }
+    s = wave_sum_f64(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) err[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) / (double)M;
+}
+
+}  // namespace
+
+extern "C" int ossid_pose_errors(const double* transforms, const double* transform_gt, const double* points, int N, int M,
+                                 int symmetric, double* err, void* stream) {
+    if (N < 0 || M <= 0) return OSSID_EINVAL;
+    if (N == 0) return OSSID_OK;
+    if (!transforms || !transform_gt || !points || !err) return OSSID_EINVAL;
+    if (symmetric) {
+        const size_t lds = (size_t)M * 24;
+        if (lds > 150 * 1024) return OSSID_EINVAL;
+        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)pose_error_kernel<true>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return OSSID_ELAUNCH;
+        hipLaunchKernelGGL(pose_error_kernel<true>, dim3(N), dim3(256), lds, (hipStream_t)stream, transforms, transform_gt,
+                           points, M, err);
+    } else {
+        hipLaunchKernelGGL(pose_error_kernel<false>, dim3(N), dim3(256), 0, (hipStream_t)stream, transforms, transform_gt,
+                           points, M, err);
+    }
+    return ossid_launch_status();
+}

@@ -63,3 +63,19 @@ def filterHypoByMask(model_points, meta_data, pose_hypos, mask, th=0.5):
     inside = (x >= 0) & (x < w) & (y >= 0) & (y < h)
     hit = m[y.clamp(0, h - 1), x.clamp(0, w - 1)].to(torch.float64) * inside
     return (hit.sum(-1) / float(M) > th).cpu().numpy()
+
+
+def pose_errors(pose_hypos, pose_gt, model_points, symmetric=False):
+    """ADD (symmetric=False) or ADI (True) of every hypothesis against the ground-truth pose, float64 numpy [N]:
+    the device-side form of online_learning.py:452's per-hypothesis Python loop over zephyr.utils.metrics.add / adi."""
+    dev = _sd._dev()
+    T = _as_tensor(np.asarray(pose_hypos, dtype=np.float64)).to(dev).reshape(-1, 4, 4).contiguous()
+    G = _as_tensor(np.asarray(pose_gt, dtype=np.float64)).to(dev).reshape(4, 4).contiguous()
+    P = _as_tensor(np.asarray(model_points, dtype=np.float64)).to(dev).contiguous()
+    N, M = int(T.shape[0]), int(P.shape[0])
+    err = torch.empty(N, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _sd._lib.fn("ossid_pose_errors")(T.data_ptr(), G.data_ptr(), P.data_ptr(), N, M, int(bool(symmetric)),
+                                              err.data_ptr(), _sd._lib.stream())
+    _sd._lib.check(rc, "ossid_pose_errors")
+    return err.cpu().numpy()

@@ -254,3 +254,22 @@ def test_full_size_properties(z, ozr):
     assert px[..., :2].abs().max() <= 1 and (px[..., 2] == 0).all() and px[..., 3].min() >= 0 and px[..., 3].max() <= 0.5
     # (4) the ground-truth hypothesis has the smallest colour error of all 1000
     assert int(px[..., 3:6].abs().mean((1, 2)).argmin()) == 0
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_pose_errors_add_adi(z, symmetric):
+    """per-hypothesis ADD / ADI against a float64 numpy restatement of the BOP definitions."""
+    from ossid_code_amd.scoring import pose_errors
+    d = small_inputs(N=17, M=700)
+    T, gt, P = d["pose_hypos"], d["pose_hypos"][0], d["model_points"]
+    est = np.einsum("nij,mj->nmi", T[:, :3, :3], P) + T[:, None, :3, 3]
+    ref = P @ gt[:3, :3].T + gt[:3, 3]
+    if symmetric:
+        dist = np.linalg.norm(est[:, :, None, :] - ref[None, None, :, :], axis=-1).min(-1)
+    else:
+        dist = np.linalg.norm(est - ref[None], axis=-1)
+    want = dist.mean(1)
+    got = pose_errors(T, gt, P, symmetric=symmetric)
+    assert got.dtype == np.float64 and got.shape == (17,)
+    assert np.allclose(got, want, rtol=1e-10, atol=1e-13) and got[0] < 1e-12   # hypothesis 0 is the ground truth
+    assert pose_errors(T[:0], gt, P, symmetric=symmetric).shape == (0,)
