@@ -148,12 +148,14 @@ int ossid_dw_xcorr_bwd_k(const float* x, const float* dout, int planes, int H, i
  * (nn.Conv2d(k=3, stride 1, padding 1) -> optional F.elu -> optional BatchNorm2d(eval)), channels-last:
  * x [B][H][W][Cin] (Cin % 16 == 0), out [B][H][W][Cout] (Cout % 4 == 0), exact f32 on the matrix cores.
  * wpk = ossid_conv3x3_pack_weights(w [Cout][Cin][3][3]); bias / bn_scale / bn_shift [Cout] may be NULL;
- * act 0 = none, 1 = ELU(alpha 1); out = (act(conv + bias)) * bn_scale + bn_shift. */
+ * act 0 = none, 1 = ELU(alpha 1); out = (act(conv + bias)) * bn_scale + bn_shift.
+ * src_h/src_w > 0: x is [B][src_h][src_w][Cin] and is nearest-neighbour up-sampled to [H][W] on the fly
+ * (F.interpolate(mode="nearest") in front of the conv, network.py:354-357); 0 = no resampling. */
 size_t ossid_conv3x3_packed_floats(int Cout, int Cin);
 int ossid_conv3x3_pack_weights(const float* w, int Cout, int Cin, float* wpk, void* stream);
 int ossid_conv3x3_nhwc_fwd(const float* x, const float* wpk, const float* bias, const float* bn_scale,
                            const float* bn_shift, float* out, int B, int H, int W, int Cin, int Cout, int act,
-                           void* stream);
+                           int src_h, int src_w, void* stream);
 
 /* D12  torchvision.ops.nms(boxes, scores, iou_threshold)      network.py:563, models/dtoid/utils.py:33
  * boxes [n][4] (x1,y1,x2,y2) ALREADY sorted by descending score (network.py:555 feeds it the top-k order);

@@ -30,16 +30,16 @@ __device__ __forceinline__ v16f mfma(float a, float b, v16f c) {
 }
 
 constexpr int KC = 16;          // channels per LDS chunk
-constexpr int NLD = 8;          // float4 staged per thread per chunk (patch <= 512 positions)
 constexpr int GQ = 3;           // weight quads per prefetch group (one kernel row)
 
-template <int WM, int NT, bool ROWSEG>
+// NLD = float4 staged per thread per chunk (the patch has at most NLD*64 positions)
+template <int WM, int NT, bool ROWSEG, int NLD>
 __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restrict__ x, const float4* __restrict__ wpk,
                                                            const float* __restrict__ bias,
                                                            const float* __restrict__ bn_scale,
                                                            const float* __restrict__ bn_shift, float* __restrict__ out,
                                                            int H, int W, int Cin, int Cout, int n_cotiles, int act,
-                                                           int buf_pos) {
+                                                           int buf_pos, int Hs, int Ws, float scale_h, float scale_w) {
     constexpr int WN = 4 / WM;
     constexpr int BPX = WN * NT * 32;
     extern __shared__ __attribute__((aligned(16))) float4 patch[];   // [2][buf_pos][KC/4]
@@ -75,7 +75,11 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restri
         const int pr = pos / PW, pc = pos - pr * PW;
         const int yy = y_first - 1 + pr, xx = x_first - 1 + pc;
         const bool ok = pos < npos && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        goff[e] = ok ? (((b * H + yy) * W + xx) * Cin + 4 * j) : -1;
+        // fused nearest-neighbour upsample (F.interpolate(mode="nearest") in front of the conv, network.py:354-357):
+        // the conv reads its [H][W] input straight from the [Hs][Ws] source, index = min(floor(dst * in/out), in-1)
+        const int sy = (Hs == H) ? yy : min((int)floorf((float)yy * scale_h), Hs - 1);
+        const int sx = (Ws == W) ? xx : min((int)floorf((float)xx * scale_w), Ws - 1);
+        goff[e] = ok ? (((b * Hs + sy) * Ws + sx) * Cin + 4 * j) : -1;
         lidx[e] = pos < npos ? idx : -1;
     }
 
@@ -227,9 +231,9 @@ __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restri
     wpk[i] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <int WM, int NT, bool ROWSEG>
+template <int WM, int NT, bool ROWSEG, int NLD>
 int launch_conv(const float* x, const float4* wpk, const float* bias, const float* sc, const float* sh, float* out, int B,
-                int H, int W, int Cin, int Cout, int act, hipStream_t s) {
+                int H, int W, int Cin, int Cout, int act, int Hs, int Ws, hipStream_t s) {
     constexpr int WN = 4 / WM, BPX = WN * NT * 32;
     const int n_cotiles = (Cout + 31) / 32;
     int rows, PW, nblk;
@@ -246,13 +250,13 @@ int launch_conv(const float* x, const float4* wpk, const float* bias, const floa
     const int buf_pos = rows * PW;
     if (buf_pos * 4 > NLD * 256) return OSSID_EINVAL;
     const size_t lds = (size_t)2 * buf_pos * KC * 4;
-    auto kern = conv3x3_nhwc_kernel<WM, NT, ROWSEG>;
+    auto kern = conv3x3_nhwc_kernel<WM, NT, ROWSEG, NLD>;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return OSSID_ELAUNCH;
     dim3 grid(nblk, (n_cotiles + WM - 1) / WM, B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, wpk, bias, sc, sh, out, H, W, Cin, Cout, n_cotiles, act,
-                       buf_pos);
+                       buf_pos, Hs, Ws, (float)Hs / (float)H, (float)Ws / (float)W);
     return ossid_launch_status();
 }
 
@@ -272,26 +276,31 @@ int ossid_conv3x3_pack_weights(const float* w, int Cout, int Cin, float* wpk, vo
 
 int ossid_conv3x3_nhwc_fwd(const float* x, const float* wpk, const float* bias, const float* bn_scale,
                            const float* bn_shift, float* out, int B, int H, int W, int Cin, int Cout, int act,
-                           void* stream) {
+                           int src_h, int src_w, void* stream) {
     if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 16 || (Cout % 4) || B > 65535) return OSSID_EINVAL;
     if (B == 0) return OSSID_OK;
     if (!x || !wpk || !out || (act != 0 && act != 1)) return OSSID_EINVAL;
+    const int Hs = src_h > 0 ? src_h : H, Ws = src_w > 0 ? src_w : W;
+    if (Hs > H || Ws > W) return OSSID_EINVAL;   // only up-sampling is fused
     hipStream_t s = (hipStream_t)stream;
     const float4* w4 = (const float4*)wpk;
     const bool rowseg = W > 100;
     const int tiles = (Cout + 31) / 32;
-#define OSSID_CONV(WM_, NT_)                                                                                         \
-    (rowseg ? launch_conv<WM_, NT_, true>(x, w4, bias, bn_scale, bn_shift, out, B, H, W, Cin, Cout, act, s)          \
-            : launch_conv<WM_, NT_, false>(x, w4, bias, bn_scale, bn_shift, out, B, H, W, Cin, Cout, act, s))
+#define OSSID_CONV(WM_, NT_, NLDF_, NLDR_)                                                                           \
+    (rowseg ? launch_conv<WM_, NT_, true, NLDR_>(x, w4, bias, bn_scale, bn_shift, out, B, H, W, Cin, Cout, act, Hs,  \
+                                                 Ws, s)                                                              \
+            : launch_conv<WM_, NT_, false, NLDF_>(x, w4, bias, bn_scale, bn_shift, out, B, H, W, Cin, Cout, act, Hs, \
+                                                  Ws, s))
     // waves go to channel tiles while there are at least that many; the rest of the workgroup takes more pixels.
-    // 128 pixels per workgroup unless that leaves the 256 CUs with under ~3 workgroups each.
+    // 128 pixels per workgroup unless that leaves the 256 CUs with under ~3 workgroups each; layers with one or two
+    // channel tiles take 256 pixels so that each streamed weight quad still feeds two pixel tiles.
     const long px = (long)B * H * W;
     if (tiles >= 4) {
         const long blocks128 = (px + 127) / 128 * ((tiles + 3) / 4);
-        return blocks128 >= 768 ? OSSID_CONV(4, 4) : OSSID_CONV(4, 2);
+        return blocks128 >= 768 ? OSSID_CONV(4, 4, 8, 8) : OSSID_CONV(4, 2, 8, 8);
     }
-    if (tiles >= 2) return OSSID_CONV(2, 2);
-    return OSSID_CONV(1, 1);
+    if (tiles >= 2) return px >= 256L * 768 ? OSSID_CONV(2, 4, 13, 13) : OSSID_CONV(2, 2, 8, 8);
+    return px >= 256L * 768 ? OSSID_CONV(1, 2, 13, 13) : OSSID_CONV(1, 1, 8, 8);
 #undef OSSID_CONV
 }
 

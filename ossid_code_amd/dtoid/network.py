@@ -12,6 +12,7 @@ What is different is how it runs on MI355X:
     segmentation maps are only gathered for the boxes that survive NMS.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -243,11 +244,13 @@ class FusedHead:
         x = torch.cat([self.dot(image_feat * avg), self.sub(image_feat - avg), self.dot3(dot3x3)], dim=1)
         x2 = self.cf(x)
         heat_map = torch.sigmoid(corr.corr_conv_heatmap(x2))
-        s = x2
-        for i in range(3):
-            s = F.interpolate(self.seg[i](s), scale_factor=2, mode="nearest")
-        s = F.interpolate(self.seg[3](s), size=corr.img_size, mode="nearest")
-        return x2, heat_map, corr.seg_final(self.seg[4](s))
+        # decoder: each F.interpolate(mode="nearest") is folded into the NEXT conv's patch staging, so the up-sampled
+        # tensors (up to 21 x 32 x 480 x 640 floats) are never written or re-read
+        s = self.seg[0](x2)
+        for i in (1, 2, 3):
+            s = self.seg[i](s, size=(2 * s.shape[2], 2 * s.shape[3]))
+        s = self.seg[4](s, size=corr.img_size)
+        return x2, heat_map, corr.seg_final(s)
 
     @staticmethod
     def _trunk(convs, x):
@@ -266,7 +269,8 @@ class FusedHead:
 
 class Network(nn.Module):
     use_fused_head = True     # test-time head on csrc/conv.hip; False = the nn.Module path (MIOpen convolutions)
-    use_graph = True          # replay the dense part of forward_all_templates from a captured hipGraph
+    # replay the dense part of forward_all_templates from a captured hipGraph (OSSID_NO_GRAPH=1: eager, for profilers)
+    use_graph = os.environ.get("OSSID_NO_GRAPH", "0") != "1"
 
     def __init__(self, img_size=(480, 480), heatmap_size=(29, 29), template_size=124):
         super().__init__()

@@ -109,11 +109,13 @@ class PackedConv3x3:
             self.scale = (bn.weight.detach().float() * inv).contiguous()
             self.shift = (bn.bias.detach().float() - bn.running_mean.detach().float() * self.scale).contiguous()
 
-    def __call__(self, x):
-        """x: logical [B,Cin,H,W] tensor (any memory format; channels_last is consumed in place) -> logical
-        [B,Cout,H,W] tensor in channels_last memory format."""
+    def __call__(self, x, size=None):
+        """x: logical [B,Cin,Hs,Ws] tensor (any memory format; channels_last is consumed in place) -> logical
+        [B,Cout,H,W] tensor in channels_last memory format. size=(H, W) >= (Hs, Ws): the input is nearest-neighbour
+        up-sampled to that size on the fly (F.interpolate(mode="nearest") fused into the patch staging)."""
         _lib.require_cuda(x)
-        B, C, H, W = x.shape
+        B, C, Hs, Ws = x.shape
+        H, W = (Hs, Ws) if size is None else (int(size[0]), int(size[1]))
         if C != self.cin:
             raise ValueError("expected %d input channels, got %d" % (self.cin, C))
         x = x.float().contiguous(memory_format=torch.channels_last)
@@ -123,6 +125,6 @@ class PackedConv3x3:
         with torch.cuda.device(x.device):
             rc = _lib.fn("ossid_conv3x3_nhwc_fwd")(x.data_ptr(), self.wpk.data_ptr(), p(self.bias), p(self.scale),
                                                    p(self.shift), out.data_ptr(), B, H, W, self.cin, self.cout, self.act,
-                                                   _lib.stream())
+                                                   Hs, Ws, _lib.stream())
         _lib.check(rc, "ossid_conv3x3_nhwc_fwd")
         return out

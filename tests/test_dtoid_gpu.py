@@ -244,3 +244,19 @@ def test_graphed_forward_equals_eager(hiplib):
         assert len(net._graph_cache) <= 2
         out = net.forward_all_templates(img, loc, [g], topk=20)
         assert out[0].numel() >= 1
+
+
+@pytest.mark.parametrize("Hs,Ws,H,W,Cin,Cout", [(29, 39, 58, 78, 256, 128), (232, 312, 480, 640, 32, 16), (5, 7, 5, 7, 16, 8),
+                                                 (58, 78, 116, 156, 128, 64), (10, 13, 23, 31, 16, 32)])
+def test_conv3x3_fused_nearest_upsample(hiplib, Hs, Ws, H, W, Cin, Cout):
+    """conv(F.interpolate(x, mode='nearest')) without materialising the up-sampled tensor: same index rule as torch."""
+    g = torch.Generator().manual_seed(H)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1).cuda()
+    x = torch.randn(2, Cin, Hs, Ws, generator=g).cuda()
+    with torch.no_grad():
+        up = torch.nn.functional.interpolate(x, size=(H, W), mode="nearest")
+        want = ops.PackedConv3x3(conv)(up)                       # the same kernel on the materialised tensor
+        got = ops.PackedConv3x3(conv)(x, size=(H, W))
+        ref = conv.double()(up.double())
+    assert torch.equal(got, want)                                # bit-identical: only the staging index differs
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
