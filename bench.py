@@ -48,6 +48,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=192, help="hypotheses in the CPU-oracle sample")
     p.add_argument("--no-dtoid", action="store_true", help="skip the secondary DTOID measurements")
+    p.add_argument("--streams", type=int, default=1,
+                   help="frames in flight per GPU (HIP streams). 2 overlaps the VALU/LDS-bound sampling kernels of one "
+                        "frame with the MFMA-bound MLP kernels of another (+3.6 %% measured) but then the per-kernel "
+                        "HIP-event durations include the other frame's kernels, so the roofline leg needs 1 (default)")
     p.add_argument("--dtoid-templates", type=int, default=21)
     p.add_argument("--dtoid-batch", type=int, default=8, help="finetune batch per GPU (cfg-4: 64 over 8 GPUs)")
     return p.parse_args()
@@ -195,17 +199,20 @@ def main():
         scores = model.score(px, stage_events=None if i is None else ev_sets[i])
         return scores, scores.argmax()
 
-    for _ in range(a.warmup):
-        scores, top = step()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
+    for k in range(max(a.warmup, len(streams))):
+        with torch.cuda.stream(streams[k % len(streams)]):
+            scores, top = step()
     torch.cuda.synchronize()
 
-    # timed region: EXACTLY K steps between barrier+synchronize pairs
+    # timed region: EXACTLY K steps (frames) between barrier+synchronize pairs; consecutive frames alternate streams
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        scores, top = step(i)
+        with torch.cuda.stream(streams[i % len(streams)]):
+            scores, top = step(i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -255,7 +262,8 @@ def main():
                                    "HSVD_diff_uv_norm features (D=8) + PointNet2SSG (SA 512/0.2/64 [8,64,64,128], "
                                    "SA 128/0.4/64 [131,128,128,256], SA all [259,256,512,1024], FC 512-256-1); "
                                    "BASELINE.json configs[1]" % (N_HYP, N_PTS, IMG_W, IMG_H),
-                       "frames_per_step_per_gpu": 1, "parallelism": "frames sharded, %d rank(s)" % a.gpus,
+                       "frames_per_step_per_gpu": 1, "frames_in_flight_per_gpu": len(streams),
+                       "parallelism": "frames sharded, %d rank(s)" % a.gpus,
                        "top1": top1},
             "roofline": {"bound": "mfma", "kernel": dom + "_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,

@@ -164,9 +164,16 @@ class PointNet2SSG(nn.Module):
         return self._packed[2]
 
     def _workspace(self, nbytes, device):
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        return self._ws
+        """Grow-only scratch buffer, one per (device, stream): frames in flight on different HIP streams must not
+        share stage buffers."""
+        if self._ws is None:
+            self._ws = {}
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
 
     def score(self, point_x, debug=False, stage_events=None):
         """point_x [B, M, 8] float32 on the GPU -> scores [B] (and the stage tensors when debug)."""
