@@ -299,8 +299,10 @@ int ossid_conv3x3_nhwc_fwd(const float* x, const float* wpk, const float* bias, 
         const long blocks128 = (px + 127) / 128 * ((tiles + 3) / 4);
         return blocks128 >= 768 ? OSSID_CONV(4, 4, 8, 8) : OSSID_CONV(4, 2, 8, 8);
     }
-    if (tiles >= 2) return px >= 256L * 768 ? OSSID_CONV(2, 4, 13, 13) : OSSID_CONV(2, 2, 8, 8);
-    return px >= 256L * 768 ? OSSID_CONV(1, 2, 13, 13) : OSSID_CONV(1, 1, 8, 8);
+    // (256-pixel tiles with 13 staged float4 per thread were measured slower on the decoder's few-channel layers:
+    // their K is only 288-576, so the per-workgroup set-up, not the weight stream, is what counts)
+    if (tiles >= 2) return OSSID_CONV(2, 2, 8, 8);
+    return OSSID_CONV(1, 1, 8, 8);
 #undef OSSID_CONV
 }
 

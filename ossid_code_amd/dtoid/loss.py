@@ -65,7 +65,7 @@ class DetectionLoss(nn.Module):
         gcx, gcy = assigned[:, :, 0] + 0.5 * gw, assigned[:, :, 1] + 0.5 * gh
         gw, gh = gw.clamp(min=1), gh.clamp(min=1)
         t = torch.stack([(gcx - acx) / aw, (gcy - acy) / ah, torch.log(gw / aw), torch.log(gh / ah)], 2)
-        t = t / t.new_tensor([0.1, 0.1, 0.2, 0.2])
+        t = torch.stack([t[..., 0] / 0.1, t[..., 1] / 0.1, t[..., 2] / 0.2, t[..., 3] / 0.2], 2)   # no host tensor: graph-safe
         diff = (t - regressions).abs()
         sl1 = torch.where(diff <= 1.0 / 9.0, 0.5 * 9.0 * diff * diff, diff - 0.5 / 9.0)
         reg = torch.where(positive[:, :, None], sl1, torch.zeros_like(sl1)).sum((1, 2))

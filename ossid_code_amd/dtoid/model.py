@@ -22,10 +22,17 @@ _MEAN = (0.485, 0.456, 0.406)
 _STD = (0.229, 0.224, 0.225)
 
 
+_NORM_CONST = {}
+
+
 def normalizeImageRange(img):
-    """ImageNet mean/std normalisation of [B,3,H,W] in [0,1] (reference: utils/__init__.py:33-39)."""
-    mean = img.new_tensor(_MEAN).view(1, 3, 1, 1)
-    std = img.new_tensor(_STD).view(1, 3, 1, 1)
+    """ImageNet mean/std normalisation of [B,3,H,W] in [0,1] (reference: utils/__init__.py:33-39). The two constant
+    vectors are created once per (device, dtype): no host->device copy per call, so the op is graph-capturable."""
+    key = (img.device, img.dtype)
+    if key not in _NORM_CONST:
+        _NORM_CONST[key] = (torch.tensor(_MEAN, dtype=img.dtype, device=img.device).view(1, 3, 1, 1),
+                            torch.tensor(_STD, dtype=img.dtype, device=img.device).view(1, 3, 1, 1))
+    mean, std = _NORM_CONST[key]
     return (img - mean) / std
 
 

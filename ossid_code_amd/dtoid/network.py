@@ -34,7 +34,10 @@ class BBoxTransform(nn.Module):
         self.std = torch.tensor([0.1, 0.1, 0.2, 0.2]) if std is None else std
 
     def forward(self, boxes, deltas):
-        mean, std = self.mean.to(deltas), self.std.to(deltas)
+        key = (deltas.device, deltas.dtype)
+        if getattr(self, "_dev_key", None) != key:      # move the constants once, not per call (graph-capturable)
+            self._dev_key, self._dev_ms = key, (self.mean.to(deltas), self.std.to(deltas))
+        mean, std = self._dev_ms
         w, h = boxes[..., 2] - boxes[..., 0], boxes[..., 3] - boxes[..., 1]
         cx, cy = boxes[..., 0] + 0.5 * w, boxes[..., 1] + 0.5 * h
         d = deltas * std + mean

