@@ -144,18 +144,34 @@ int ossid_dw_xcorr_fwd(const float* x, int x_planes, const float* k, int planes,
 int ossid_dw_xcorr_bwd_x(const float* dout, const float* k, int planes, int H, int W, float* dx, void* stream);
 int ossid_dw_xcorr_bwd_k(const float* x, const float* dout, int planes, int H, int W, float* dk, void* stream);
 
-/* D6-D8  the dense 3x3 convolutions of the head at test time      network.py:102-110, :135-143, :288-326
- * (nn.Conv2d(k=3, stride 1, padding 1) -> optional F.elu -> optional BatchNorm2d(eval)), channels-last:
- * x [B][H][W][Cin] (Cin % 16 == 0), out [B][H][W][Cout] (Cout % 4 == 0), exact f32 on the matrix cores.
- * wpk = ossid_conv3x3_pack_weights(w [Cout][Cin][3][3]); bias / bn_scale / bn_shift [Cout] may be NULL;
- * act 0 = none, 1 = ELU(alpha 1); out = (act(conv + bias)) * bn_scale + bn_shift.
- * src_h/src_w > 0: x is [B][src_h][src_w][Cin] and is nearest-neighbour up-sampled to [H][W] on the fly
- * (F.interpolate(mode="nearest") in front of the conv, network.py:354-357); 0 = no resampling. */
-size_t ossid_conv3x3_packed_floats(int Cout, int Cin);
-int ossid_conv3x3_pack_weights(const float* w, int Cout, int Cin, float* wpk, void* stream);
-int ossid_conv3x3_nhwc_fwd(const float* x, const float* wpk, const float* bias, const float* bn_scale,
-                           const float* bn_shift, float* out, int B, int H, int W, int Cin, int Cout, int act,
-                           int src_h, int src_w, void* stream);
+/* D4, D6-D8  the dense convolutions at test time: the head's 3x3 layers (network.py:102-110, :135-143, :288-326)
+ * and the DenseNet-121 blocks of the image backbone (network.py:164-184), channels-last, exact f32 on the matrix cores.
+ *   out[b][y][x][out_channel_offset + co] = post( act( bias[co] + sum_{ci,tap} w[co][ci][tap] * pre(x)[b][y+dy][x+dx][ci] ) )
+ * taps 9: 3x3 / stride 1 / padding 1 (zero halo);  taps 1: 1x1.
+ * pre  = x * pre_scale[ci] + pre_shift[ci] (then ReLU if pre_relu) on real pixels only -- eval-mode BatchNorm(+ReLU)
+ *        in FRONT of the conv (DenseNet's BN-ReLU-Conv); NULL = identity.
+ * act  = 0 none, 1 ELU(alpha 1);  post = * post_scale[co] + post_shift[co] -- eval-mode BatchNorm BEHIND the ELU
+ *        (`norm(F.elu(conv(x)))`); NULL = identity.
+ * src_height/width > 0 (3x3 only): x is [B][src_h][src_w][..] and is nearest-neighbour up-sampled to [H][W] on the fly
+ *        (F.interpolate(mode="nearest") in front of the conv, network.py:354-357).
+ * in_channel_stride / out_channel_stride (0 = cin / cout) and out_channel_offset let a layer read the first cin channels of
+ *        a wider resident buffer and append its output to it in place (DenseNet concatenation without torch.cat).
+ * cin % 16 == 0; cout, strides and offset % 4 == 0. wpk = ossid_conv_pack_weights(w [cout][cin][kh][kw]). */
+typedef struct ossid_conv_desc {
+    const float* x;
+    const float* wpk;
+    const float* bias;
+    const float* pre_scale;
+    const float* pre_shift;
+    const float* post_scale;
+    const float* post_shift;
+    float* out;
+    int32_t batch, height, width, cin, cout, taps, act, pre_relu;
+    int32_t src_height, src_width, in_channel_stride, out_channel_stride, out_channel_offset;
+} ossid_conv_desc;
+size_t ossid_conv_packed_floats(int Cout, int Cin, int taps);
+int ossid_conv_pack_weights(const float* w, int Cout, int Cin, int taps, float* wpk, void* stream);
+int ossid_conv_nhwc_fwd(const ossid_conv_desc* desc_host, void* stream);
 
 /* D12  torchvision.ops.nms(boxes, scores, iou_threshold)      network.py:563, models/dtoid/utils.py:33
  * boxes [n][4] (x1,y1,x2,y2) ALREADY sorted by descending score (network.py:555 feeds it the top-k order);

@@ -20,6 +20,14 @@ class PN2Weights(C.Structure):
                 ("npoint1", C.c_int32), ("npoint2", C.c_int32), ("radius1", _f), ("radius2", _f)]
 
 
+class ConvDesc(C.Structure):
+    """struct ossid_conv_desc (include/ossid_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("x", "wpk", "bias", "pre_scale", "pre_shift", "post_scale", "post_shift", "out")] + \
+               [(n, C.c_int32) for n in ("batch", "height", "width", "cin", "cout", "taps", "act", "pre_relu",
+                                         "src_height", "src_width", "in_channel_stride", "out_channel_stride",
+                                         "out_channel_offset")]
+
+
 _PROTOS = {
     "ossid_abi_version": (_i, [C.c_char_p, _i]),
     "ossid_zephyr_prep_frame_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -42,9 +50,9 @@ _PROTOS = {
     "ossid_dw_xcorr_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "ossid_dw_xcorr_bwd_x": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ossid_dw_xcorr_bwd_k": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
-    "ossid_conv3x3_packed_floats": (_sz, [_i, _i]),
-    "ossid_conv3x3_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
-    "ossid_conv3x3_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ossid_conv_packed_floats": (_sz, [_i, _i, _i]),
+    "ossid_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "ossid_conv_nhwc_fwd": (_i, [_vp, _vp]),
     "ossid_nms_workspace_bytes": (_sz, [_i]),
     "ossid_nms": (_i, [_vp, _i, _f, _vp, _sz, _vp, _vp, _vp]),
     "ossid_decode_clip_boxes": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),

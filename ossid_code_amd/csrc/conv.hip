@@ -1,24 +1,27 @@
-// 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on the f32 matrix cores (gfx950), channels-last.
+// 3x3 (stride 1, pad 1) and 1x1 convolutions as implicit GEMMs on the f32 matrix cores (gfx950), channels-last.
 //
-// Stands behind the dense 3x3 nn.Conv2d layers of the DTOID head at test time
+// Stand behind the dense nn.Conv2d layers of DTOID at test time
 // (/root/reference/python/ossid/models/dtoid/network.py:102-110 classification trunk, :135-143 regression trunk,
-// :288-326 correlation / fusion / segmentation-decoder convolutions), which the reference runs through cuDNN.
-// Optional fused epilogue: bias -> ELU -> BatchNorm(eval) affine, i.e. the reference's `norm(F.elu(conv(x)))` pattern
-// (network.py:330-357) in one pass over the output.
+// :288-326 correlation / fusion / segmentation-decoder convolutions, :164-184 the DenseNet-121 blocks of the image
+// backbone), which the reference runs through cuDNN, with the elementwise layers around them folded in:
+//   prologue  per-input-channel affine (+ReLU) applied while the input is staged: DenseNet's BN->ReLU->Conv order
+//             (eval-mode BatchNorm = affine); nearest-neighbour up-sampling of the input (decoder, network.py:354-357)
+//   epilogue  bias -> ELU -> per-output-channel affine: the head's `norm(F.elu(conv(x)))` (network.py:330-357)
+//   in/out    channel strides and an output channel offset, so a dense block reads the first c channels of ONE resident
+//             [B][H][W][C_total] buffer and appends its 32 new channels in place (no torch.cat, no re-reads)
 //
 // GEMM view: D[co][px] = sum_{ci,tap} W[co][ci][tap] * X[px + tap][ci].  v_mfma_f32_32x32x2_f32 with output channels
 // on M (accumulator registers), pixels on N (lane&31), exact f32 arithmetic (fmaf chains; no Winograd, no reduced
 // precision).
-//   - input  x   [B][H][W][Cin]   (NHWC; Cin % 16 == 0)
-//   - weight wpk [ceil(Cout/32)][Cin/8][9][64 lanes][4]: lane (c,h) holds W[32mt+c][8kb+4h+0..3][tap] -- the A operands
-//     of four chained MFMAs, streamed from L2 with a two-deep register pipeline (as csrc/pn2.hip); every quad feeds
-//     NT pixel tiles, so weight traffic is 1/(4 NT) dword per MFMA
+//   - weights wpk [ceil(Cout/32)][Cin/8][TAPS][64 lanes][4]: lane (c,h) holds W[32mt+c][8kb+4h+0..3][tap] -- the A
+//     operands of four chained MFMAs, streamed from L2 with a two-deep register pipeline (as csrc/pn2.hip); every quad
+//     feeds NT pixel tiles
 //   - the input patch of a workgroup's pixels (+ halo, zero padded) is staged channels-innermost through double-buffered
 //     LDS in 16-channel chunks: a B operand quad is ONE ds_read_b128, the next chunk's global loads fly under the
 //     current chunk's MFMAs (issue-early / write-late), one barrier per chunk
-//   - output out [B][H][W][Cout]: each lane owns 4 consecutive channels per register quad -> 16-byte stores
-// Workgroup = 4 waves as WM (channel tiles) x WN (pixel groups); pixels are a flat run of the image (FLAT, narrow
-// images such as the 29x39 feature map) or a segment of one row (ROWSEG, wide images of the decoder).
+//   - output: each lane owns 4 consecutive channels per register quad -> 16-byte stores
+// Workgroup = 4 waves as WM (channel tiles) x WN (pixel groups); pixels are a flat run of the image (FLAT) or a
+// segment of one row (ROWSEG, wide images of the decoder).
 #include "common.h"
 
 namespace {
@@ -29,28 +32,41 @@ __device__ __forceinline__ v16f mfma(float a, float b, v16f c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-constexpr int KC = 16;          // channels per LDS chunk
-constexpr int GQ = 3;           // weight quads per prefetch group (one kernel row)
+struct ConvArgs {
+    const float* x;
+    const float4* wpk;
+    const float *bias, *bn_scale, *bn_shift, *pre_scale, *pre_shift;
+    float* out;
+    int H, W, Cin, Cout, n_cotiles, act, buf_pos, Hs, Ws, in_cs, out_cs, out_coff, pre_relu;
+    float scale_h, scale_w;
+};
 
-// NLD = float4 staged per thread per chunk (the patch has at most NLD*64 positions)
-template <int WM, int NT, bool ROWSEG, int NLD>
-__global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restrict__ x, const float4* __restrict__ wpk,
-                                                           const float* __restrict__ bias,
-                                                           const float* __restrict__ bn_scale,
-                                                           const float* __restrict__ bn_shift, float* __restrict__ out,
-                                                           int H, int W, int Cin, int Cout, int n_cotiles, int act,
-                                                           int buf_pos, int Hs, int Ws, float scale_h, float scale_w) {
-    constexpr int WN = 4 / WM;
+// Workgroup = 4 waves = WM (channel tiles) x WK (split of the reduction) x WN (pixel groups), each wave NT pixel tiles.
+// WK > 1 is for small problems (batch-1 backbone layers: a few dozen workgroups in all): the waves of a workgroup
+// share ONE output tile and each walks 1/WK of every channel chunk, the partial accumulators meet in LDS.
+// KCH = channels per LDS chunk (16, or 64 with split-K); NLD = float4 staged per thread per chunk; TAPS = 9 or 1.
+template <int WM, int WK, int NT, bool ROWSEG, int NLD, int TAPS, int KCH>
+__global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
+    constexpr int WN = 4 / (WM * WK);
     constexpr int BPX = WN * NT * 32;
-    extern __shared__ __attribute__((aligned(16))) float4 patch[];   // [2][buf_pos][KC/4]
+    constexpr int F4 = KCH / 4;                 // float4 per patch position
+    constexpr int NKB = KCH / 8 / WK;           // 8-channel blocks of a chunk handled by one wave
+    constexpr int KY = TAPS == 9 ? 3 : 1;       // prefetch groups per channel block (3x3: one kernel row each)
+    constexpr int GQ = TAPS == 9 ? 3 : (NKB >= 2 ? 2 : 1);   // weight quads per prefetch group
+    constexpr int GPC = TAPS == 9 ? NKB * 3 : NKB / GQ;      // groups per chunk per wave
+    static_assert(WM * WK * WN == 4 && KCH % (8 * WK) == 0 && 256 % F4 == 0, "bad tiling");
+    extern __shared__ __attribute__((aligned(16))) float4 patch[];   // [2][buf_pos][F4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
-    const int wm = wave % WM, wn = wave / WM;
+    const int wm = wave % WM, wk = (wave / WM) % WK, wn = wave / (WM * WK);
     const int b = blockIdx.z;
-    const int HW = H * W;
+    const int H = A.H, W = A.W, HW = H * W;
 
     // ---- geometry of this workgroup's pixels and of its patch ----------------------------------------------------
-    int y_first, x_first, PW, PR;
-    if (ROWSEG) {
+    int y_first = 0, x_first = 0, PW, PR;
+    if (TAPS == 1) {
+        PW = BPX;
+        PR = 1;
+    } else if (ROWSEG) {
         const int segs = (W + BPX - 1) / BPX;
         y_first = blockIdx.x / segs;
         x_first = (blockIdx.x % segs) * BPX;
@@ -59,7 +75,6 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restri
     } else {
         const int px0 = blockIdx.x * BPX;
         y_first = px0 / W;
-        x_first = 0;
         const int y_last = min(px0 + BPX - 1, HW - 1) / W;
         PW = W + 2;
         PR = y_last - y_first + 3;
@@ -71,26 +86,36 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < NLD; ++e) {
         const int idx = tid + e * 256;
-        const int pos = idx >> 2, j = idx & 3;
-        const int pr = pos / PW, pc = pos - pr * PW;
-        const int yy = y_first - 1 + pr, xx = x_first - 1 + pc;
-        const bool ok = pos < npos && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        // fused nearest-neighbour upsample (F.interpolate(mode="nearest") in front of the conv, network.py:354-357):
-        // the conv reads its [H][W] input straight from the [Hs][Ws] source, index = min(floor(dst * in/out), in-1)
-        const int sy = (Hs == H) ? yy : min((int)floorf((float)yy * scale_h), Hs - 1);
-        const int sx = (Ws == W) ? xx : min((int)floorf((float)xx * scale_w), Ws - 1);
-        goff[e] = ok ? (((b * Hs + sy) * Ws + sx) * Cin + 4 * j) : -1;
+        const int pos = idx / F4, j = idx % F4;
+        if (TAPS == 1) {
+            const int px = blockIdx.x * BPX + pos;
+            const bool ok = pos < npos && px < HW;
+            goff[e] = ok ? ((b * HW + px) * A.in_cs + 4 * j) : -1;
+        } else {
+            const int pr = pos / PW, pc = pos - pr * PW;
+            const int yy = y_first - 1 + pr, xx = x_first - 1 + pc;
+            const bool ok = pos < npos && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            // fused nearest-neighbour upsample (F.interpolate(mode="nearest") in front of the conv): the conv reads
+            // its [H][W] input straight from the [Hs][Ws] source, index = min(floor(dst * in/out), in-1)
+            const int sy = (A.Hs == H) ? yy : min((int)floorf((float)yy * A.scale_h), A.Hs - 1);
+            const int sx = (A.Ws == W) ? xx : min((int)floorf((float)xx * A.scale_w), A.Ws - 1);
+            goff[e] = ok ? (((b * A.Hs + sy) * A.Ws + sx) * A.in_cs + 4 * j) : -1;
+        }
         lidx[e] = pos < npos ? idx : -1;
     }
 
-    // this lane's pixel in each of its NT tiles: patch position of tap (0,0), validity, output offset
+    // this lane's pixel in each of its NT tiles: patch position of tap (0,0), output pixel index (or -1)
     int pos0[NT], opx[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int j = (wn * NT + t) * 32 + c;
-        if (ROWSEG) {
+        if (TAPS == 1) {
+            const int px = blockIdx.x * BPX + j;
+            pos0[t] = j;
+            opx[t] = (px < HW) ? (b * HW + px) : -1;
+        } else if (ROWSEG) {
             const int xx = x_first + j;
-            pos0[t] = min(j, BPX - 1);
+            pos0[t] = j;
             opx[t] = (xx < W) ? (b * HW + y_first * W + xx) : -1;
         } else {
             const int px = blockIdx.x * BPX + j;
@@ -102,9 +127,9 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restri
     }
 
     const int co_tile = blockIdx.y * WM + wm;
-    const bool active = co_tile < n_cotiles;
-    const int nq = (Cin / 8) * 9;                               // weight quads per channel tile
-    const float4* W4 = wpk + (size_t)(active ? co_tile : 0) * nq * 64 + lane;
+    const bool active = co_tile < A.n_cotiles;
+    const int nq = (A.Cin / 8) * TAPS;                          // weight quads per channel tile
+    const float4* W4 = A.wpk + (size_t)(active ? co_tile : 0) * nq * 64 + lane;
 
     v16f acc[NT];
     {
@@ -114,7 +139,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restri
             const int co = cb + 8 * q;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float bv = (bias && co + i < Cout) ? bias[co + i] : 0.0f;
+                const float bv = (A.bias && wk == 0 && co + i < A.Cout) ? A.bias[co + i] : 0.0f;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t][4 * q + i] = bv;
             }
@@ -122,74 +147,117 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restri
     }
 
     float4 st[NLD];
+    const int jch = 4 * (tid % F4);   // this thread always stages channels ci0 + jch .. +3 (256 % F4 == 0)
     auto stage_load = [&](int ci0) {
 #pragma unroll
         for (int e = 0; e < NLD; ++e)
-            st[e] = goff[e] >= 0 ? *(const float4*)(x + (size_t)goff[e] + ci0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            st[e] = goff[e] >= 0 ? *(const float4*)(A.x + (size_t)goff[e] + ci0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (A.pre_scale) {   // BN(eval) (+ReLU) of the INPUT, applied to real pixels only: the zero halo stays zero
+            const float4 ps = *(const float4*)(A.pre_scale + ci0 + jch), pt = *(const float4*)(A.pre_shift + ci0 + jch);
+#pragma unroll
+            for (int e = 0; e < NLD; ++e) {
+                if (goff[e] < 0) continue;
+                float4 v = st[e];
+                v.x = v.x * ps.x + pt.x, v.y = v.y * ps.y + pt.y, v.z = v.z * ps.z + pt.z, v.w = v.w * ps.w + pt.w;
+                if (A.pre_relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                st[e] = v;
+            }
+        }
     };
     auto stage_write = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < NLD; ++e)
-            if (lidx[e] >= 0) patch[(size_t)buf * buf_pos * 4 + lidx[e]] = st[e];
+            if (lidx[e] >= 0) patch[(size_t)buf * A.buf_pos * F4 + lidx[e]] = st[e];
     };
 
-    const int nchunks = Cin / KC;
+    // weight quads of prefetch group gi (a per-wave linear counter over (chunk, channel block, kernel row))
+    auto quad_of = [&](int gi, int i) {
+        int q;
+        if (TAPS == 9) {
+            const int ky = gi % 3, kbl = (gi / 3) % NKB, ch = gi / (3 * NKB);
+            q = ((ch * (KCH / 8) + wk * NKB + kbl) * 9) + ky * 3 + i;
+        } else {
+            const int g = gi % GPC, ch = gi / GPC;
+            q = ch * (KCH / 8) + wk * NKB + g * GQ + i;
+        }
+        return q < nq ? q : nq - 1;
+    };
+
+    const int nchunks = A.Cin / KCH;
     stage_load(0);
     stage_write(0);
     float4 cur[GQ], nxt[GQ];
 #pragma unroll
-    for (int i = 0; i < GQ; ++i) cur[i] = W4[(size_t)i * 64];
+    for (int i = 0; i < GQ; ++i) cur[i] = W4[(size_t)quad_of(0, i) * 64];
     __syncthreads();
 
-    int qbase = 0;
+    int gi = 0;
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch + 1 < nchunks) stage_load((ch + 1) * KC);      // in flight under this chunk's MFMAs
-        const float4* pb = patch + (size_t)(ch & 1) * buf_pos * 4 + h;
+        if (ch + 1 < nchunks) stage_load((ch + 1) * KCH);     // in flight under this chunk's MFMAs
+        const float4* pb = patch + (size_t)(ch & 1) * A.buf_pos * F4 + h;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int g = 0; g < GPC; ++g) {
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
+            for (int i = 0; i < GQ; ++i) nxt[i] = W4[(size_t)quad_of(gi + 1, i) * 64];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < GQ; ++i) {
-                    int n = qbase + GQ + i;
-                    n = n < nq ? n : nq - 1;
-                    nxt[i] = W4[(size_t)n * 64];
+            for (int i = 0; i < GQ; ++i) {
+                if (!active) break;    // a workgroup's spare waves only help with staging
+                const int kb = wk * NKB + (TAPS == 9 ? g / 3 : g * GQ + i);       // 8-channel block inside the chunk
+                const int toff = TAPS == 9 ? (g % 3) * PW + i : 0;
+                const float4 a = cur[i];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 bq = pb[(size_t)(pos0[t] + toff) * F4 + 2 * kb];
+                    acc[t] = mfma(a.x, bq.x, acc[t]);
+                    acc[t] = mfma(a.y, bq.y, acc[t]);
+                    acc[t] = mfma(a.z, bq.z, acc[t]);
+                    acc[t] = mfma(a.w, bq.w, acc[t]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    if (!active) break;    // a workgroup's spare waves only help with staging
-                    const float4 a = cur[kx];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const float4 bq = pb[(size_t)(pos0[t] + ky * PW + kx) * 4 + 2 * kb];
-                        acc[t] = mfma(a.x, bq.x, acc[t]);
-                        acc[t] = mfma(a.y, bq.y, acc[t]);
-                        acc[t] = mfma(a.z, bq.z, acc[t]);
-                        acc[t] = mfma(a.w, bq.w, acc[t]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < GQ; ++i) cur[i] = nxt[i];
-                qbase += GQ;
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < GQ; ++i) cur[i] = nxt[i];
+            ++gi;
         }
         if (ch + 1 < nchunks) stage_write((ch + 1) & 1);
         __syncthreads();
     }
+    (void)KY;
+
+    // ---- split-K: the WK partial tiles meet in LDS (fixed summation order), each wave then finishes 4/WK register quads
+    if (WK > 1) {
+        float* red = (float*)patch;                               // [WK][WM*WN][NT][16][64]; the patch is dead now
+        const int slot = wm + WM * wn;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                red[(((size_t)(wk * (WM * WN) + slot) * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sum = red[(((size_t)(0 * (WM * WN) + slot) * NT + t) * 16 + r) * 64 + lane];
+#pragma unroll
+                for (int k = 1; k < WK; ++k) sum += red[(((size_t)(k * (WM * WN) + slot) * NT + t) * 16 + r) * 64 + lane];
+                acc[t][r] = sum;
+            }
+    }
 
     if (!active) return;
-    // ---- epilogue: (ELU) -> (BN affine) -> 16-byte stores ---------------------------------------------------------
+    // ---- epilogue: (ELU) -> (per-channel affine) -> 16-byte stores -------------------------------------------------
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+        if (WK > 1 && (q * WK) / 4 != wk) continue;               // with split-K the quads are shared out over the waves
         const int co = co_tile * 32 + 8 * q + 4 * h;
         float sc[4], sh[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            sc[i] = (bn_scale && co + i < Cout) ? bn_scale[co + i] : 1.0f;
-            sh[i] = (bn_shift && co + i < Cout) ? bn_shift[co + i] : 0.0f;
+            sc[i] = (A.bn_scale && co + i < A.Cout) ? A.bn_scale[co + i] : 1.0f;
+            sh[i] = (A.bn_shift && co + i < A.Cout) ? A.bn_shift[co + i] : 0.0f;
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -198,65 +266,69 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restri
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float u = acc[t][4 * q + i];
-                if (act == 1) u = u > 0.0f ? u : expm1f(u);
+                if (A.act == 1) u = u > 0.0f ? u : expm1f(u);
                 v[i] = u * sc[i] + sh[i];
             }
-            float* o = out + (size_t)opx[t] * Cout + co;
-            if (co + 3 < Cout) {
+            float* o = A.out + (size_t)opx[t] * A.out_cs + A.out_coff + co;
+            if (co + 3 < A.Cout) {
                 *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (co + i < Cout) o[i] = v[i];
+                    if (co + i < A.Cout) o[i] = v[i];
             }
         }
     }
 }
 
-// weight repack on the device: w [Cout][Cin][3][3] (torch layout) -> wpk (see the file header)
-__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restrict__ w, int Cout, int Cin,
-                                                           float4* __restrict__ wpk, size_t total) {
+// weight repack on the device: w [Cout][Cin][taps] (torch layout, taps = kh*kw) -> wpk (see the file header)
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, int Cout, int Cin, int taps,
+                                                        float4* __restrict__ wpk, size_t total) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int lane = i & 63;
     size_t r = i >> 6;
-    const int tap = r % 9;
-    r /= 9;
+    const int tap = r % taps;
+    r /= taps;
     const int kb = r % (Cin / 8);
     const int mt = r / (Cin / 8);
     const int co = mt * 32 + (lane & 31), ci = kb * 8 + 4 * (lane >> 5);
     float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (co < Cout) ? w[((size_t)co * Cin + ci + e) * 9 + tap] : 0.0f;
+    for (int e = 0; e < 4; ++e) v[e] = (co < Cout) ? w[((size_t)co * Cin + ci + e) * taps + tap] : 0.0f;
     wpk[i] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <int WM, int NT, bool ROWSEG, int NLD>
-int launch_conv(const float* x, const float4* wpk, const float* bias, const float* sc, const float* sh, float* out, int B,
-                int H, int W, int Cin, int Cout, int act, int Hs, int Ws, hipStream_t s) {
-    constexpr int WN = 4 / WM, BPX = WN * NT * 32;
-    const int n_cotiles = (Cout + 31) / 32;
+template <int WM, int WK, int NT, bool ROWSEG, int NLD, int TAPS, int KCH>
+int launch_conv(ConvArgs a, int B, hipStream_t s) {
+    constexpr int WN = 4 / (WM * WK), BPX = WN * NT * 32, F4 = KCH / 4;
+    if (a.Cin % KCH) return OSSID_EINVAL;
     int rows, PW, nblk;
-    if (ROWSEG) {
+    if (TAPS == 1) {
+        rows = 1;
+        PW = BPX;
+        nblk = (a.H * a.W + BPX - 1) / BPX;
+    } else if (ROWSEG) {
         rows = 3;
         PW = BPX + 2;
-        nblk = H * ((W + BPX - 1) / BPX);
+        nblk = a.H * ((a.W + BPX - 1) / BPX);
     } else {
-        rows = (BPX + W - 2) / W + 1 + 2;
-        if (rows > H + 2) rows = H + 2;
-        PW = W + 2;
-        nblk = (H * W + BPX - 1) / BPX;
+        rows = (BPX + a.W - 2) / a.W + 1 + 2;
+        if (rows > a.H + 2) rows = a.H + 2;
+        PW = a.W + 2;
+        nblk = (a.H * a.W + BPX - 1) / BPX;
     }
-    const int buf_pos = rows * PW;
-    if (buf_pos * 4 > NLD * 256) return OSSID_EINVAL;
-    const size_t lds = (size_t)2 * buf_pos * KC * 4;
-    auto kern = conv3x3_nhwc_kernel<WM, NT, ROWSEG, NLD>;
+    a.buf_pos = rows * PW;
+    if (a.buf_pos * F4 > NLD * 256) return OSSID_EINVAL;
+    size_t lds = (size_t)2 * a.buf_pos * KCH * 4;
+    const size_t red = WK > 1 ? (size_t)WK * (WM * WN) * NT * 16 * 64 * 4 : 0;
+    if (red > lds) lds = red;
+    auto kern = conv_nhwc_kernel<WM, WK, NT, ROWSEG, NLD, TAPS, KCH>;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return OSSID_ELAUNCH;
-    dim3 grid(nblk, (n_cotiles + WM - 1) / WM, B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, wpk, bias, sc, sh, out, H, W, Cin, Cout, n_cotiles, act,
-                       buf_pos, Hs, Ws, (float)Hs / (float)H, (float)Ws / (float)W);
+    dim3 grid(nblk, (a.n_cotiles + WM - 1) / WM, B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     return ossid_launch_status();
 }
 
@@ -264,45 +336,68 @@ int launch_conv(const float* x, const float4* wpk, const float* bias, const floa
 
 extern "C" {
 
-size_t ossid_conv3x3_packed_floats(int Cout, int Cin) { return (size_t)((Cout + 31) / 32) * (Cin / 8) * 9 * 64 * 4; }
+size_t ossid_conv_packed_floats(int Cout, int Cin, int taps) {
+    return (size_t)((Cout + 31) / 32) * (Cin / 8) * taps * 64 * 4;
+}
 
-int ossid_conv3x3_pack_weights(const float* w, int Cout, int Cin, float* wpk, void* stream) {
-    if (!w || !wpk || Cout <= 0 || Cin <= 0 || Cin % 16) return OSSID_EINVAL;
-    const size_t total = ossid_conv3x3_packed_floats(Cout, Cin) / 4;
-    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       Cout, Cin, (float4*)wpk, total);
+int ossid_conv_pack_weights(const float* w, int Cout, int Cin, int taps, float* wpk, void* stream) {
+    if (!w || !wpk || Cout <= 0 || Cin <= 0 || Cin % 16 || (taps != 1 && taps != 9)) return OSSID_EINVAL;
+    const size_t total = ossid_conv_packed_floats(Cout, Cin, taps) / 4;
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       Cout, Cin, taps, (float4*)wpk, total);
     return ossid_launch_status();
 }
 
-int ossid_conv3x3_nhwc_fwd(const float* x, const float* wpk, const float* bias, const float* bn_scale,
-                           const float* bn_shift, float* out, int B, int H, int W, int Cin, int Cout, int act,
-                           int src_h, int src_w, void* stream) {
+int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
+    if (!d) return OSSID_EINVAL;
+    const int B = d->batch, H = d->height, W = d->width, Cin = d->cin, Cout = d->cout;
     if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 16 || (Cout % 4) || B > 65535) return OSSID_EINVAL;
+    if (d->taps != 1 && d->taps != 9) return OSSID_EINVAL;
     if (B == 0) return OSSID_OK;
-    if (!x || !wpk || !out || (act != 0 && act != 1)) return OSSID_EINVAL;
-    const int Hs = src_h > 0 ? src_h : H, Ws = src_w > 0 ? src_w : W;
-    if (Hs > H || Ws > W) return OSSID_EINVAL;   // only up-sampling is fused
+    if (!d->x || !d->wpk || !d->out || (d->act != 0 && d->act != 1)) return OSSID_EINVAL;
+    ConvArgs a;
+    a.x = d->x, a.wpk = (const float4*)d->wpk, a.bias = d->bias, a.bn_scale = d->post_scale, a.bn_shift = d->post_shift;
+    a.pre_scale = d->pre_scale, a.pre_shift = d->pre_shift, a.pre_relu = d->pre_relu, a.out = d->out;
+    a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout, a.n_cotiles = (Cout + 31) / 32, a.act = d->act, a.buf_pos = 0;
+    a.Hs = d->src_height > 0 ? d->src_height : H, a.Ws = d->src_width > 0 ? d->src_width : W;
+    a.in_cs = d->in_channel_stride > 0 ? d->in_channel_stride : Cin;
+    a.out_cs = d->out_channel_stride > 0 ? d->out_channel_stride : Cout;
+    a.out_coff = d->out_channel_offset;
+    if (a.Hs > H || a.Ws > W || a.in_cs < Cin || a.out_cs < a.out_coff + Cout || (a.in_cs % 4) || (a.out_cs % 4) ||
+        (a.out_coff % 4) || (a.pre_scale && !a.pre_shift) || (d->taps == 1 && (a.Hs != H || a.Ws != W)))
+        return OSSID_EINVAL;
+    a.scale_h = (float)a.Hs / (float)H, a.scale_w = (float)a.Ws / (float)W;
     hipStream_t s = (hipStream_t)stream;
-    const float4* w4 = (const float4*)wpk;
-    const bool rowseg = W > 100;
-    const int tiles = (Cout + 31) / 32;
-#define OSSID_CONV(WM_, NT_, NLDF_, NLDR_)                                                                           \
-    (rowseg ? launch_conv<WM_, NT_, true, NLDR_>(x, w4, bias, bn_scale, bn_shift, out, B, H, W, Cin, Cout, act, Hs,  \
-                                                 Ws, s)                                                              \
-            : launch_conv<WM_, NT_, false, NLDF_>(x, w4, bias, bn_scale, bn_shift, out, B, H, W, Cin, Cout, act, Hs, \
-                                                  Ws, s))
-    // waves go to channel tiles while there are at least that many; the rest of the workgroup takes more pixels.
-    // 128 pixels per workgroup unless that leaves the 256 CUs with under ~3 workgroups each; layers with one or two
-    // channel tiles take 256 pixels so that each streamed weight quad still feeds two pixel tiles.
+    const int tiles = a.n_cotiles;
     const long px = (long)B * H * W;
+    // How many workgroups would the plain tiling (128 output channels x 64 pixels) give? Under ~0.6 per CU the problem is
+    // "small" (batch-1 backbone layers, batch-8 head layers): one channel tile per workgroup, the four waves split
+    // the reduction instead (64-channel chunks), which multiplies the workgroup count by up to 4 and cuts every wave's
+    // MFMA chain -- the critical path of such a launch -- by 4.
+    const long plain_wgs = (px + 63) / 64 * ((tiles + 3) / 4);
+    const bool small = plain_wgs < 160 && (Cin % 64) == 0;
+    if (d->taps == 1) {   // no halo: the patch is just the pixel run
+        if (small) return launch_conv<1, 4, 1, false, 2, 1, 64>(a, B, s);
+        if (tiles >= 4)
+            return px >= 128L * 512 ? launch_conv<4, 1, 4, false, 2, 1, 16>(a, B, s)
+                                    : launch_conv<4, 1, 1, false, 1, 1, 16>(a, B, s);
+        if (tiles >= 2) return launch_conv<2, 1, 2, false, 2, 1, 16>(a, B, s);
+        return launch_conv<1, 1, 1, false, 2, 1, 16>(a, B, s);
+    }
+    if (small) return launch_conv<1, 4, 1, true, 7, 9, 64>(a, B, s);     // row segments of 32 pixels
+    const bool rowseg = W > 100;
+#define OSSID_CONV(WM_, NT_)                                                                                         \
+    (rowseg ? launch_conv<WM_, 1, NT_, true, 8, 9, 16>(a, B, s) : launch_conv<WM_, 1, NT_, false, 8, 9, 16>(a, B, s))
+    // waves go to channel tiles while there are at least that many; the rest of the workgroup takes more pixels.
+    // 128 pixels per workgroup unless that leaves the 256 CUs with under ~3 workgroups each. (256-pixel tiles with 13
+    // staged float4 per thread were measured slower on the decoder's few-channel layers: their K is only 288-576, so
+    // the per-workgroup set-up, not the weight stream, is what counts.)
     if (tiles >= 4) {
         const long blocks128 = (px + 127) / 128 * ((tiles + 3) / 4);
-        return blocks128 >= 768 ? OSSID_CONV(4, 4, 8, 8) : OSSID_CONV(4, 2, 8, 8);
+        return blocks128 >= 768 ? OSSID_CONV(4, 4) : OSSID_CONV(4, 2);
     }
-    // (256-pixel tiles with 13 staged float4 per thread were measured slower on the decoder's few-channel layers:
-    // their K is only 288-576, so the per-workgroup set-up, not the weight stream, is what counts)
-    if (tiles >= 2) return OSSID_CONV(2, 2, 8, 8);
-    return OSSID_CONV(1, 1, 8, 8);
+    if (tiles >= 2) return OSSID_CONV(2, 2);
+    return OSSID_CONV(1, 1);
 #undef OSSID_CONV
 }
 

@@ -270,7 +270,58 @@ class FusedHead:
         return out.permute(0, 2, 3, 1).reshape(x2.shape[0], -1, 4)
 
 
+class FusedBackbone:
+    """Test-time execution plan of the DenseNet-121 part of ImageFeatExtract on csrc/conv.hip. Each dense layer is two
+    launches -- 1x1 conv with norm1+ReLU folded into its input staging, 3x3 conv with norm2+ReLU folded likewise -- and
+    writes its 32 channels straight into the block's resident channels-last buffer; transitions are one fused 1x1 conv
+    plus the average pool; norm5 -> c1 (1x1) -> ELU -> n1 is ONE launch. The stem (7x7 stride-2 conv, template
+    modulation, norm0/ReLU/max-pool) stays on torch ops. Rebuilt whenever the parameters change."""
+
+    def __init__(self, ife):
+        P = ops.PackedConv
+        self.ife = ife
+        seq = list(ife.backdense_1) + list(ife.backdense_2)      # norm0 relu0 pool0 block1 | trans1 block2 ... norm5
+        self.stem = seq[:3]
+        self.stages = []
+        for m in seq[3:]:
+            if hasattr(m, "nlayers"):                            # DenseBlock
+                layers = [(P(l.conv1, pre_bn=l.norm1, pre_relu=True), P(l.conv2, pre_bn=l.norm2, pre_relu=True))
+                          for l in m.values()]
+                self.stages.append(("block", m, layers))
+            elif isinstance(m, nn.BatchNorm2d):                  # norm5, folded into c1's input staging
+                self.final = P(ife.c1, bn=ife.n1, act=True, pre_bn=m, pre_relu=False)
+            else:                                                # Transition: norm relu conv pool
+                self.stages.append(("trans", m, P(m.conv, pre_bn=m.norm, pre_relu=True)))
+
+    def __call__(self, image, template_feat):
+        ife = self.ife
+        x0 = ife.backdense_0(image)
+        x = x0 + ops.dw_xcorr(x0, template_feat)
+        for m in self.stem:
+            x = m(x)
+        x = x.contiguous(memory_format=torch.channels_last)
+        for kind, mod, packed in self.stages:
+            B, C, H, W = x.shape
+            if kind == "block":
+                ctot = C + mod.nlayers * mod.growth
+                buf = torch.empty((B, ctot, H, W), dtype=torch.float32, device=x.device,
+                                  memory_format=torch.channels_last)
+                buf[:, :C] = x
+                tmp = torch.empty((B, 128, H, W), dtype=torch.float32, device=x.device,
+                                  memory_format=torch.channels_last)
+                c = C
+                for conv1, conv2 in packed:
+                    conv1.run(buf, B, H, W, tmp, in_cs=ctot)
+                    conv2.run(tmp, B, H, W, buf, out_cs=ctot, out_coff=c)
+                    c += mod.growth
+                x = buf
+            else:
+                x = mod.pool(packed(x))
+        return self.final(x)
+
+
 class Network(nn.Module):
+    use_fused_backbone = True  # test-time DenseNet blocks on csrc/conv.hip; False = the nn.Module path (MIOpen)
     use_fused_head = True     # test-time head on csrc/conv.hip; False = the nn.Module path (MIOpen convolutions)
     # replay the dense part of forward_all_templates from a captured hipGraph (OSSID_NO_GRAPH=1: eager, for profilers)
     use_graph = os.environ.get("OSSID_NO_GRAPH", "0") != "1"
@@ -292,6 +343,14 @@ class Network(nn.Module):
             conv.bias.data.fill_(b)
         self.regressBoxes = BBoxTransform()
         self.clipBoxes = ClipBoxes()
+
+    def _fused_backbone(self):
+        key = FusedHead.version_key(self.image_feature_extractor)
+        cached = self.__dict__.get("_fused_bb_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, FusedBackbone(self.image_feature_extractor))
+            self.__dict__["_fused_bb_cache"] = cached
+        return cached[1]
 
     def _fused_head(self):
         mods = (self.correlation_model, self.classification, self.regression)
@@ -331,7 +390,10 @@ class Network(nn.Module):
     def _dense_all_templates(self, image, template_features, template_global):
         """Backbone once + head per template chunk -> dense (cls [n_t,A,2], reg [n_t,A,4], seg [n_t,1,H,W],
         heat [n_t,1,hh,hw], feature-map shape). No host syncs, no data-dependent shapes: capturable in a hipGraph."""
-        features = self.image_feature_extractor(image, template_global)
+        if self.use_fused_backbone and image.is_cuda and not self.training:
+            features = self._fused_backbone()(image, template_global)
+        else:
+            features = self.image_feature_extractor(image, template_global)
         fused = self._fused_head() if (self.use_fused_head and features.is_cuda and not self.training) else None
         cls_out, reg_out, seg_out, heat_out = [], [], [], []
         for chunk in template_features:
@@ -353,7 +415,9 @@ class Network(nn.Module):
         host-bound). One graph per (image shape, chunk sizes, packed-head identity); inputs are copied into the
         graph's static buffers, outputs are read from them."""
         fused = self._fused_head() if self.use_fused_head else None
-        key = (tuple(image.shape), tuple(int(c.shape[0]) for c in template_features), id(fused), str(image.device))
+        fused_bb = self._fused_backbone() if self.use_fused_backbone else None
+        key = (tuple(image.shape), tuple(int(c.shape[0]) for c in template_features), id(fused), id(fused_bb),
+               str(image.device))
         cache = self.__dict__.setdefault("_graph_cache", {})
         entry = cache.get(key)
         if entry is None:
@@ -370,7 +434,7 @@ class Network(nn.Module):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 outs = self._dense_all_templates(s_img, s_tf, s_g)
-            entry = (graph, s_img, s_tf, s_g, outs, fused)
+            entry = (graph, s_img, s_tf, s_g, outs, (fused, fused_bb))
             cache[key] = entry
         graph, s_img, s_tf, s_g, outs, _ = entry
         s_img.copy_(image)

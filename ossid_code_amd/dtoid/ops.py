@@ -1,8 +1,12 @@
 """Torch-facing wrappers of the DTOID device ops in libossid_hip.so (include/ossid_hip.h, "DTOID ops").
 Tensors only cross as raw pointers; autograd sees DwXcorr as one differentiable node."""
+import ctypes
+
 import torch
 
 from .. import _lib
+
+C_byref = ctypes.byref
 
 
 class _DwXcorr(torch.autograd.Function):
@@ -86,33 +90,56 @@ def decode_clip_boxes(anchors, deltas, img_w, img_h):
     return out
 
 
-class PackedConv3x3:
-    """Weights of one nn.Conv2d(k=3, stride 1, padding 1) in the MFMA operand layout of csrc/conv.hip, plus the fused
-    epilogue vectors (bias, and the eval-mode BatchNorm affine that follows the ELU in the reference head)."""
+def _bn_affine(bn):
+    """eval-mode BatchNorm2d as a per-channel (scale, shift)"""
+    inv = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+    scale = (bn.weight.detach().float() * inv).contiguous()
+    return scale, (bn.bias.detach().float() - bn.running_mean.detach().float() * scale).contiguous()
 
-    def __init__(self, conv, bn=None, act=False):
+
+class PackedConv:
+    """One nn.Conv2d (3x3 / stride 1 / padding 1, or 1x1) in the MFMA operand layout of csrc/conv.hip with its fused
+    neighbours: `pre_bn` (+ReLU) = eval-mode BatchNorm in FRONT of the conv (DenseNet's BN-ReLU-Conv), `act` = ELU and
+    `bn` = eval-mode BatchNorm BEHIND it (the head's norm(F.elu(conv(x))))."""
+
+    def __init__(self, conv, bn=None, act=False, pre_bn=None, pre_relu=False):
         w = conv.weight.detach().float().contiguous()
         _lib.require_cuda(w)
         self.cout, self.cin = int(w.shape[0]), int(w.shape[1])
-        if tuple(w.shape[2:]) != (3, 3) or conv.stride != (1, 1) or conv.padding != (1, 1) or self.cin % 16 or self.cout % 4:
-            raise ValueError("PackedConv3x3 handles 3x3 / stride 1 / padding 1 with Cin % 16 == 0 and Cout % 4 == 0")
-        n = _lib.fn("ossid_conv3x3_packed_floats")(self.cout, self.cin)
+        k = tuple(w.shape[2:])
+        ok = (k == (3, 3) and conv.padding == (1, 1)) or (k == (1, 1) and conv.padding == (0, 0))
+        if not ok or conv.stride != (1, 1) or conv.groups != 1 or self.cin % 16 or self.cout % 4:
+            raise ValueError("PackedConv handles 3x3/pad 1 and 1x1, stride 1, Cin % 16 == 0, Cout % 4 == 0")
+        self.taps = k[0] * k[1]
+        n = _lib.fn("ossid_conv_packed_floats")(self.cout, self.cin, self.taps)
         self.wpk = torch.empty(n, dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
-            _lib.check(_lib.fn("ossid_conv3x3_pack_weights")(w.data_ptr(), self.cout, self.cin, self.wpk.data_ptr(),
-                                                             _lib.stream()), "ossid_conv3x3_pack_weights")
+            _lib.check(_lib.fn("ossid_conv_pack_weights")(w.data_ptr(), self.cout, self.cin, self.taps,
+                                                          self.wpk.data_ptr(), _lib.stream()), "ossid_conv_pack_weights")
         self.bias = None if conv.bias is None else conv.bias.detach().float().contiguous()
         self.act = 1 if act else 0
-        self.scale = self.shift = None
-        if bn is not None:
-            inv = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
-            self.scale = (bn.weight.detach().float() * inv).contiguous()
-            self.shift = (bn.bias.detach().float() - bn.running_mean.detach().float() * self.scale).contiguous()
+        self.scale, self.shift = _bn_affine(bn) if bn is not None else (None, None)
+        self.pre_scale, self.pre_shift = _bn_affine(pre_bn) if pre_bn is not None else (None, None)
+        self.pre_relu = 1 if pre_relu else 0
+
+    def run(self, x_nhwc, B, H, W, out_nhwc, in_cs=0, out_cs=0, out_coff=0, src_hw=(0, 0)):
+        """Raw call on physical [B][H][W][C] buffers (tensors only provide pointers)."""
+        d = _lib.ConvDesc()
+        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        d.x, d.wpk, d.bias, d.out = x_nhwc.data_ptr(), self.wpk.data_ptr(), p(self.bias), out_nhwc.data_ptr()
+        d.pre_scale, d.pre_shift, d.post_scale, d.post_shift = p(self.pre_scale), p(self.pre_shift), p(self.scale), p(self.shift)
+        d.batch, d.height, d.width, d.cin, d.cout, d.taps = B, H, W, self.cin, self.cout, self.taps
+        d.act, d.pre_relu = self.act, self.pre_relu
+        d.src_height, d.src_width = int(src_hw[0]), int(src_hw[1])
+        d.in_channel_stride, d.out_channel_stride, d.out_channel_offset = in_cs, out_cs, out_coff
+        with torch.cuda.device(out_nhwc.device):
+            _lib.check(_lib.fn("ossid_conv_nhwc_fwd")(C_byref(d), _lib.stream()), "ossid_conv_nhwc_fwd")
+        return out_nhwc
 
     def __call__(self, x, size=None):
         """x: logical [B,Cin,Hs,Ws] tensor (any memory format; channels_last is consumed in place) -> logical
-        [B,Cout,H,W] tensor in channels_last memory format. size=(H, W) >= (Hs, Ws): the input is nearest-neighbour
-        up-sampled to that size on the fly (F.interpolate(mode="nearest") fused into the patch staging)."""
+        [B,Cout,H,W] tensor in channels_last memory format. size=(H, W) >= (Hs, Ws) (3x3 only): the input is
+        nearest-neighbour up-sampled to that size on the fly."""
         _lib.require_cuda(x)
         B, C, Hs, Ws = x.shape
         H, W = (Hs, Ws) if size is None else (int(size[0]), int(size[1]))
@@ -121,10 +148,7 @@ class PackedConv3x3:
         x = x.float().contiguous(memory_format=torch.channels_last)
         out = torch.empty((B, self.cout, H, W), dtype=torch.float32, device=x.device,
                           memory_format=torch.channels_last)
-        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-        with torch.cuda.device(x.device):
-            rc = _lib.fn("ossid_conv3x3_nhwc_fwd")(x.data_ptr(), self.wpk.data_ptr(), p(self.bias), p(self.scale),
-                                                   p(self.shift), out.data_ptr(), B, H, W, self.cin, self.cout, self.act,
-                                                   Hs, Ws, _lib.stream())
-        _lib.check(rc, "ossid_conv3x3_nhwc_fwd")
-        return out
+        return self.run(x, B, H, W, out, src_hw=(Hs, Ws) if size is not None else (0, 0))
+
+
+PackedConv3x3 = PackedConv   # the head's name for it

@@ -291,3 +291,56 @@ def test_graphed_finetune_step_matches_eager(hiplib):
     # the Adam trajectory itself is only reproducible to ~1e-3, its updates are sign-like for tiny gradients)
     assert torch.allclose(r0, r1, rtol=2e-2, atol=1e-5)
     assert float((p0 - p1).abs().max()) < 5e-4                     # 3 Adam steps of lr 1e-4 (sign-like updates)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 1024, 640, 29, 39), (1, 256, 128, 120, 160), (2, 64, 128, 30, 40),
+                                             (1, 512, 256, 60, 80), (3, 32, 32, 7, 5), (1, 96, 24, 9, 11)])
+def test_conv1x1_with_pre_and_post_fusion(hiplib, B, Cin, Cout, H, W):
+    """1x1 conv with BN+ReLU folded into the input staging and ELU+BN into the epilogue vs float64 torch."""
+    g = torch.Generator().manual_seed(Cin + Cout)
+
+    def rbn(n):
+        bn = torch.nn.BatchNorm2d(n).eval()
+        with torch.no_grad():
+            bn.running_mean.copy_(0.1 * torch.randn(n, generator=g)), bn.running_var.copy_(0.5 + torch.rand(n, generator=g))
+            bn.weight.copy_(1 + 0.2 * torch.randn(n, generator=g)), bn.bias.copy_(0.1 * torch.randn(n, generator=g))
+        return bn
+
+    conv, pre, post = torch.nn.Conv2d(Cin, Cout, 1), rbn(Cin), rbn(Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    with torch.no_grad():
+        ref = post.double()(torch.nn.functional.elu(conv.double()(torch.relu(pre.double()(x.double())))))
+    conv, pre, post = conv.float().cuda(), pre.float().cuda(), post.float().cuda()
+    got = ops.PackedConv(conv, bn=post, act=True, pre_bn=pre, pre_relu=True)(x.cuda())
+    assert float((got.cpu().double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+
+
+def test_conv_writes_into_a_channel_slice(hiplib):
+    """DenseNet-style in-place concatenation: read the first c channels of a wide buffer, append 32 at an offset."""
+    g = torch.Generator().manual_seed(9)
+    B, H, W, C, ctot = 2, 9, 13, 64, 128
+    buf = torch.randn(B, ctot, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    before = buf.clone()
+    conv = torch.nn.Conv2d(C, 32, 3, padding=1, bias=False).cuda()
+    pk = ops.PackedConv(conv)
+    pk.run(buf, B, H, W, buf, in_cs=ctot, out_cs=ctot, out_coff=96)
+    with torch.no_grad():
+        want = conv(before[:, :C].contiguous())
+    assert torch.equal(buf[:, :96], before[:, :96])                       # nothing else touched
+    assert torch.allclose(buf[:, 96:], want, rtol=1e-4, atol=1e-4)
+
+
+def test_fused_backbone_matches_module_path(hiplib):
+    """DenseNet-121 trunk of ImageFeatExtract on the hand-written kernels vs the nn.Module path (MIOpen), 480x640."""
+    torch.manual_seed(11)
+    ife = dtoid.ImageFeatExtract().cuda().eval()
+    with torch.no_grad():
+        for m in ife.modules():                                           # non-trivial BatchNorm statistics
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1), m.running_var.uniform_(0.5, 1.5), m.weight.normal_(1, 0.1), m.bias.normal_(0, 0.1)
+        img = torch.rand(1, 3, 480, 640, device="cuda")
+        tg = torch.randn(1, 64, 3, 3, device="cuda") * 0.1
+        ref = ife(img, tg)
+        got = dtoid.network.FusedBackbone(ife)(img, tg)
+    assert got.shape == ref.shape == (1, 640, 29, 39)
+    assert float((got - ref).abs().max()) <= 1e-3 * float(ref.abs().max())   # 120 chained layers, two f32 sum orders

@@ -60,6 +60,29 @@ def main():
                     xl = x.contiguous(memory_format=torch.channels_last)
                     t = timeit(lambda: pk(xl))
                     out["conv %s B=%d" % (name, B)].update({"hip_ms": t * 1e3, "hip_TFLOPs": fl / t / 1e12})
+    if "backbone" in a.what:
+        net = dtoid.Network(img_size=(480, 640), heatmap_size=(29, 39)).cuda().eval()
+        img = torch.rand(1, 3, 480, 640, device="cuda")
+        tg = torch.randn(1, 64, 3, 3, device="cuda") * 0.1
+
+        def graphed(fn):
+            s_ = torch.cuda.Stream()
+            s_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s_), torch.no_grad():
+                for _ in range(2):
+                    fn()
+            torch.cuda.current_stream().wait_stream(s_)
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_), torch.no_grad():
+                fn()
+            return g_
+        with torch.no_grad():
+            fb = net._fused_backbone()
+            for name, fn in (("module(MIOpen)", lambda: net.image_feature_extractor(img, tg)), ("fused(HIP)", lambda: fb(img, tg))):
+                te = timeit(fn, 2, 5)
+                g_ = graphed(fn)
+                tg_ = timeit(g_.replay, 2, 10)
+                out["backbone %s" % name] = {"eager_ms": te * 1e3, "graph_ms": tg_ * 1e3, "TFLOPs_graph": 39.7e9 / tg_ / 1e12}
     if "forward" in a.what:
         m = dtoid.DtoidNet(cfg).cuda().eval()
         b = _batch(cfg, 1, "cuda")
