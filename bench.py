@@ -53,6 +53,7 @@ def parse():
                         "frame with the MFMA-bound MLP kernels of another (+3.6 %% measured) but then the per-kernel "
                         "HIP-event durations include the other frame's kernels, so the roofline leg needs 1 (default)")
     p.add_argument("--dtoid-templates", type=int, default=21)
+    p.add_argument("--dtoid-timeout", type=int, default=420, help="watchdog (s) for the secondary DTOID leg")
     p.add_argument("--dtoid-batch", type=int, default=8, help="finetune batch per GPU (cfg-4: 64 over 8 GPUs)")
     return p.parse_args()
 
@@ -230,21 +231,18 @@ def main():
     for e in ev_sets:
         e.close()
 
-    dtoid_out = None
-    if not a.no_dtoid:
-        try:
-            del scores, top
-            torch.cuda.empty_cache()
-            scores, top = step()
-            dtoid_out = dtoid_leg(a, dev, dist, world)
-        except Exception as exc:   # the secondary measurement must never take the headline number down with it
-            dtoid_out = {"error": repr(exc)[:300]}
+    top1 = int(top.item())
+    got_sample = scores[: len(base_scores)].cpu().numpy() if base_scores is not None else None
 
-    if rank == 0:
-        top1 = int(top.item())
+    def emit(dtoid_out):
+        """rank 0 prints THE json line (everything above is already measured; dtoid_out may be an error note)"""
+        if rank != 0:
+            return
         if base_scores is not None:   # the GPU scores of the sampled hypotheses are the oracle's, bit for bit
-            got = scores[: len(base_scores)].cpu().numpy()
-            assert np.array_equal(got, base_scores), "GPU scores differ from the CPU oracle"
+            assert np.array_equal(got_sample, base_scores), "GPU scores differ from the CPU oracle"
+        print(json.dumps(make_line(dtoid_out)), flush=True)
+
+    def make_line(dtoid_out):
         traffic = None
         try:   # HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
@@ -256,7 +254,7 @@ def main():
         dom_ms = float(stage_ms[names.index(dom)])
         achieved = STAGE_FLOPS[dom] * N_HYP / (dom_ms * 1e-3) / 1e12
         feat_bytes = N_HYP * N_PTS * (32 + 8) + IMG_H * IMG_W * 16 + N_PTS * 48 + N_HYP * 64
-        out = {
+        return {
             "metric": "hypotheses scored/sec", "value": a.gpus * a.steps * N_HYP / elapsed, "unit": "hyp/s",
             "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -265,8 +263,7 @@ def main():
                                    "SA 128/0.4/64 [131,128,128,256], SA all [259,256,512,1024], FC 512-256-1); "
                                    "BASELINE.json configs[1]" % (N_HYP, N_PTS, IMG_W, IMG_H),
                        "frames_per_step_per_gpu": 1, "frames_in_flight_per_gpu": len(streams),
-                       "parallelism": "frames sharded, %d rank(s)" % a.gpus,
-                       "top1": top1},
+                       "parallelism": "frames sharded, %d rank(s)" % a.gpus, "top1": top1},
             "roofline": {"bound": "mfma", "kernel": dom + "_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
                          "traffic": traffic, "avg_launch_ms": dom_ms,
@@ -278,7 +275,27 @@ def main():
             "cpu_baseline": base,
             "dtoid": dtoid_out,
         }
-        print(json.dumps(out))
+
+    dtoid_out = None
+    if not a.no_dtoid:
+        # The secondary measurement must never take the headline number down with it: any exception becomes a note,
+        # and a watchdog prints the line and leaves if a collective of the multi-rank finetune leg should ever hang.
+        import threading
+
+        def on_timeout():   # a thread, not a signal: the main thread may be blocked inside a collective
+            emit({"error": "DTOID leg timed out after %d s" % a.dtoid_timeout})
+            os._exit(0)
+        watchdog = threading.Timer(a.dtoid_timeout, on_timeout)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            del scores, top
+            torch.cuda.empty_cache()
+            dtoid_out = dtoid_leg(a, dev, dist, world)
+        except Exception as exc:
+            dtoid_out = {"error": repr(exc)[:300]}
+        watchdog.cancel()
+    emit(dtoid_out)
     if dist is not None:
         dist.destroy_process_group()
 

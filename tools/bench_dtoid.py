@@ -91,7 +91,15 @@ def main():
         t = timeit(lambda: m.forwardTestTime(test))
         out["forward n_t=%d" % a.nt] = {"ms": t * 1e3, "imgs_per_s": 1.0 / t,
                                         "TFLOPs": (39.7e9 + 46.0e9 * a.nt) / t / 1e12}
-    if "finetune" in a.what:
+    if "finetune_cl" in a.what:   # experiment: whole model + inputs in channels_last memory format
+        m = dtoid.DtoidNet(cfg).cuda().train().to(memory_format=torch.channels_last)
+        flat = finetune.FlatParams(m)
+        opt = finetune.FusedAMSGrad(flat)
+        b = _batch(cfg, a.batch, "cuda")
+        b = {k: (v.contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v) for k, v in b.items()}
+        t = timeit(lambda: finetune.finetune_step(m, b, opt), warm=3, reps=4)
+        out["finetune channels_last B=%d" % a.batch] = {"ms": t * 1e3, "samples_per_s": a.batch / t}
+    if "finetune" in a.what.split(","):
         m = dtoid.DtoidNet(cfg).cuda().train()
         flat = finetune.FlatParams(m)
         opt = finetune.FusedAMSGrad(flat)
