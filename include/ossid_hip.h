@@ -173,6 +173,18 @@ size_t ossid_conv_packed_floats(int Cout, int Cin, int taps);
 int ossid_conv_pack_weights(const float* w, int Cout, int Cin, int taps, float* wpk, void* stream);
 int ossid_conv_nhwc_fwd(const ossid_conv_desc* desc_host, void* stream);
 
+/* D16  weight gradient of the 3x3 / stride 1 / pad 1 convolution (loss.backward() of the finetune step,
+ * scripts/online_learning.py:670-672): dw[co][ci][ky][kx] (+)= sum_{b,y,x} dy[b][y][x][co] * x[b][y+ky-1][x+kx-1][ci].
+ * x [B][H][W][in_channel_stride], dy [B][H][W][dy_channel_stride] channels-last (0 = Cin / Cout); dw in torch layout
+ * [Cout][Cin][3][3]; accumulate != 0 adds to dw. Split-K partial slabs in `workspace`, summed in a fixed order
+ * (bit-reproducible). The data gradient needs no entry point of its own: it is ossid_conv_nhwc_fwd on dy with the
+ * 180-degree-rotated, transposed weights. */
+int ossid_conv3x3_wgrad_splits(int B, int H, int W, int Cin, int Cout);
+size_t ossid_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int ossid_conv3x3_wgrad(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int in_channel_stride,
+                        int dy_channel_stride, void* workspace, size_t workspace_bytes, float* dw, int accumulate,
+                        void* stream);
+
 /* D12  torchvision.ops.nms(boxes, scores, iou_threshold)      network.py:563, models/dtoid/utils.py:33
  * boxes [n][4] (x1,y1,x2,y2) ALREADY sorted by descending score (network.py:555 feeds it the top-k order);
  * keep [n] receives the indices of the survivors in that order, *num_keep their count. n <= 16384. */

@@ -60,6 +60,31 @@ def main():
                     xl = x.contiguous(memory_format=torch.channels_last)
                     t = timeit(lambda: pk(xl))
                     out["conv %s B=%d" % (name, B)].update({"hip_ms": t * 1e3, "hip_TFLOPs": fl / t / 1e12})
+    if "bwd" in a.what:   # backward passes of the head shapes: MIOpen vs the hand-written kernels
+        from ossid_code_amd.dtoid import ops
+        for name, ci, co in (("corr 640->256", 640, 256), ("cf 768->512", 768, 512), ("cls/reg 512->256", 512, 256),
+                             ("trunk 256->256", 256, 256)):
+            B = a.batch
+            x = torch.randn(B, ci, 29, 39, device="cuda").contiguous(memory_format=torch.channels_last)
+            w = torch.randn(co, ci, 3, 3, device="cuda") * 0.01
+            gy = torch.randn(B, co, 29, 39, device="cuda").contiguous(memory_format=torch.channels_last)
+            fl = 2.0 * B * 29 * 39 * co * ci * 9
+            t_wm = timeit(lambda: torch.nn.grad.conv2d_weight(x, w.shape, gy, padding=1))
+            t_dm = timeit(lambda: torch.nn.grad.conv2d_input(x.shape, w, gy, padding=1))
+            xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+
+            def hip_bwd():
+                xr.grad = wr.grad = None
+                ops.conv3x3(xr, wr).backward(gy)
+            def hip_fwd():
+                with torch.no_grad():
+                    ops.conv3x3(xr, wr)
+            t_f = timeit(hip_fwd)
+            t_all = timeit(hip_bwd)
+            out["bwd %s B=%d" % (name, B)] = {"miopen_wgrad_ms": t_wm * 1e3, "miopen_dgrad_ms": t_dm * 1e3,
+                                            "hip_fwd_ms": t_f * 1e3, "hip_fwd+dgrad+wgrad_ms": t_all * 1e3,
+                                            "miopen_wgrad_TF": fl / t_wm / 1e12, "miopen_dgrad_TF": fl / t_dm / 1e12,
+                                            "hip_bwd_TF(2 passes)": 2 * fl / (t_all - t_f) / 1e12}
     if "backbone" in a.what:
         net = dtoid.Network(img_size=(480, 640), heatmap_size=(29, 39)).cuda().eval()
         img = torch.rand(1, 3, 480, 640, device="cuda")
