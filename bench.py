@@ -137,12 +137,20 @@ def dtoid_leg(a, dev, dist, world):
     t_ft_eager = timed(lambda: finetune.finetune_step(m, batch, opt, sync), 2, 4)
     graphed = finetune.GraphedForwardBackward(m, flat, batch)
     t_ft = timed(lambda: finetune.finetune_step(m, batch, opt, sync, graphed=graphed), 2, 6)
+    del graphed
+    from ossid_code_amd.dtoid import ops as dops
+    dops.set_train_conv_impl("hip")      # the head's 3x3 convs (fwd, dgrad, wgrad) on csrc/conv.hip instead of MIOpen
+    try:
+        t_ft_hip = timed(lambda: finetune.finetune_step(m, batch, opt, sync), 2, 4)
+    finally:
+        dops.set_train_conv_impl("miopen")
     return {"forward": {"metric": "DTOID imgs/sec", "value": world / t_fwd, "unit": "img/s", "ms_per_image": 1e3 * t_fwd,
                         "config": "forward_all_templates, 1 image x %d local templates per rank, 480x640, topk 500, f32; "
                                   "hand-written MFMA conv head + hipGraph" % nt,
                         "tflops": world * (39.7e9 + 46.0e9 * nt) / t_fwd / 1e12},
             "finetune": {"metric": "DTOID finetune samples/sec", "value": world * B / t_ft, "unit": "sample/s",
-                         "ms_per_step": 1e3 * t_ft, "ms_per_step_eager": 1e3 * t_ft_eager, "global_batch": world * B,
+                         "ms_per_step": 1e3 * t_ft, "ms_per_step_eager": 1e3 * t_ft_eager,
+                         "ms_per_step_head_convs_hand_written": 1e3 * t_ft_hip, "global_batch": world * B,
                          "config": "DtoidNet.forward + 4-term loss + backward (hipGraph replay) + fused AMSGrad, batch %d per GPU, BatchNorm "
                                    "in train mode per rank, gradient mean over %d rank(s)%s" %
                                    (B, world, " (RCCL all-reduce of the flat 136 MB buffer)" if world > 1 else ""),

@@ -521,13 +521,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 extern "C" {
 
 int ossid_conv3x3_wgrad_splits(int B, int H, int W, int Cin, int Cout) {
+    (void)W;
     const long tiles = (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * 3;
-    long want = (4096 + tiles - 1) / tiles;                 // aim at ~4096 waves: 2 per SIMD on 256 CUs, twice over
+    // as many row-splits as keep ALL waves resident at once (two per SIMD on 256 CUs = 2048): a second, partly filled
+    // round of waves would double the run time
+    long want = 2048 / tiles;
     const long rows = (long)B * H;
     if (want > rows) want = rows;
     if (want < 1) want = 1;
-    return (int)((want + 3) / 4 * 4);                       // whole workgroups of four waves
-    (void)W;
+    return (int)want;
 }
 
 size_t ossid_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
@@ -546,8 +548,7 @@ int ossid_conv3x3_wgrad(const float* x, const float* dy, int B, int H, int W, in
     const int tiles = co_pairs * ci_pairs * 3;
     const long waves = (long)tiles * nsplit;
     hipStream_t s = (hipStream_t)stream;
-    // a split that meets no valid row (tiny images) must still leave zeros in its slab
-    if (hipMemsetAsync(workspace, 0, (size_t)nsplit * Cout * Cin * 9 * sizeof(float), s) != hipSuccess) return OSSID_ELAUNCH;
+    // (no memset: every wave writes its whole 64x64x3 region of its slab, zeros included, so the slabs are fully defined)
     hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, dy, (float*)workspace, B,
                        H, W, Cin, Cout, in_cs, dy_cs, nsplit, ci_pairs, tiles);
     const size_t n = (size_t)Cout * Cin * 9;

@@ -71,8 +71,8 @@ def _head_trunk(mod, cin, feature_size):
 
 def _run_trunk(mod, x):
     for i in (1, 2, 3, 4):
-        x = getattr(mod, "act%d" % i)(getattr(mod, "conv%d" % i)(x))
-    return mod.output(x)
+        x = getattr(mod, "act%d" % i)(ops.conv_module(getattr(mod, "conv%d" % i), x))
+    return ops.conv_module(mod.output, x)
 
 
 class ClassificationModel(nn.Module):
@@ -196,7 +196,7 @@ class CorrelationModel(nn.Module):
         self.corr_conv_heatmap = nn.Conv2d(512, 1, 1)
 
     def _cab(self, conv, norm, x):
-        return norm(F.elu(conv(x)))
+        return norm(F.elu(ops.conv_module(conv, x)))
 
     def forward(self, image_feat, template_feat, test=False):
         t2 = self._cab(self.c2, self.n2, self._cab(self.c1, self.n1, template_feat))       # 7x7 -> 5x5 -> 3x3

@@ -228,3 +228,21 @@ def conv3x3(x, weight, bias=None):
     """Differentiable 3x3 / stride 1 / padding 1 convolution on the hand-written kernels (needs Cin, Cout % 16 == 0)."""
     _lib.require_cuda(x, weight)
     return _Conv3x3.apply(x, weight, bias)
+
+
+TRAIN_CONV_IMPL = "miopen"   # "hip": the head's 3x3 convolutions run forward/dgrad/wgrad on csrc/conv.hip in training too
+
+
+def set_train_conv_impl(name):
+    global TRAIN_CONV_IMPL
+    if name not in ("miopen", "hip"):
+        raise ValueError(name)
+    TRAIN_CONV_IMPL = name
+
+
+def conv_module(mod, x):
+    """Apply an nn.Conv2d: through the hand-written differentiable kernel when selected and eligible, else torch."""
+    if (TRAIN_CONV_IMPL == "hip" and x.is_cuda and mod.kernel_size == (3, 3) and mod.padding == (1, 1) and
+            mod.stride == (1, 1) and mod.groups == 1 and mod.in_channels % 16 == 0 and mod.out_channels % 16 == 0):
+        return conv3x3(x, mod.weight, mod.bias)
+    return mod(x)

@@ -370,3 +370,15 @@ def test_conv3x3_autograd_all_three_passes(hiplib, B, Cin, Cout, H, W):
     wd.grad = None
     y2.backward(go.cuda())
     assert torch.equal(wd.grad, g1)
+
+
+def test_head_training_on_hand_written_convs_matches_reference_golden(hiplib):
+    """The reference-golden forward/backward check of the head with every eligible 3x3 convolution (forward, data
+    gradient, weight gradient) on csrc/conv.hip instead of MIOpen."""
+    ops.set_train_conv_impl("hip")
+    try:
+        out, _ = run_head("cuda")
+    finally:
+        ops.set_train_conv_impl("miopen")
+    for k, v in out.items():
+        assert close(v, G[k], rtol=2e-3, atol=2e-4), k
