@@ -203,6 +203,31 @@ int ossid_amsgrad_step(float* param, const float* grad, float* exp_avg, float* e
                        size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                        void* stream);
 
+/* =============================================================================================
+ * The steps either side of the hot path, one frame at a time, all on the device
+ * ============================================================================================= */
+
+/* 8f-1  DTOID batch producer: processData (utils/data.py:7-83: depth2xyz at the original resolution, bilinear resize of
+ * image / mask / xyz to [H][W], image /255, CHW), datasets/dtoid_bop_dataset.py:256-290.
+ * img u8 [Ho][Wo][3], depth f32 [Ho][Wo] (m), mask f32 [Ho][Wo] in [0,1] -> img_out [3][H][W], xyz_out [3][H][W], mask_out [H][W].
+ * Equal sizes (480x640 LM-O / YCB-V frames) are an exact copy. */
+int ossid_dtoid_prep_sample(const uint8_t* img, const float* depth, const float* mask, int Ho, int Wo, float fx, float fy,
+                            float cx, float cy, int H, int W, float* img_out, float* xyz_out, float* mask_out, void* stream);
+/* mask -> bbox_gt (x1,y1,x2,y2,label) = min/max of the non-zero pixels (dtoid_bop_dataset.py:274-279; label -1 for an
+ * empty mask) and the Gaussian heat map around its centre, float64 (utils/__init__.py:354-367; :283-287). */
+int ossid_mask_bbox_heatmap(const float* mask, int H, int W, int heat_h, int heat_w, double heat_scale, double sigma,
+                            int32_t* bbox5, double* heatmap, void* stream);
+
+/* 8f-3  post-score step (scripts/online_learning.py:485-500, :557-558): a depth-only point-splat renderer in place of
+ * pyrender (z-buffer of the posed model cloud, (2*radius+1)^2 pixel splats; zbuf_workspace = H*W*4 bytes), the bop19
+ * visibility mask visib = (d_pred - d_obs <= delta or d_obs == 0) and d_pred > 0, and the set sizes of both IoUs:
+ * counts4 = |pred&gt|, |pred|gt|, |visib&gt_visib|, |visib|gt_visib| (gt masks u8, may be NULL). */
+int ossid_render_depth_points(const float* transform, const float* points, int M, float fx, float fy, float cx, float cy,
+                              int H, int W, int radius, void* zbuf_workspace, float* depth_out, void* stream);
+int ossid_visib_mask_iou(const float* depth_obs, const float* depth_pred, const uint8_t* gt_mask, const uint8_t* gt_mask_visib,
+                         int H, int W, float delta, uint8_t* pred_mask, uint8_t* pred_mask_visib, int32_t* counts4,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

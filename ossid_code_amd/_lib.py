@@ -37,6 +37,10 @@ _PROTOS = {
     "ossid_zephyr_inconst_count": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp]),
     "ossid_zephyr_featurize": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
     "ossid_pose_errors": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ossid_dtoid_prep_sample": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
+    "ossid_mask_bbox_heatmap": (_i, [_vp, _i, _i, _i, _i, C.c_double, C.c_double, _vp, _vp, _vp]),
+    "ossid_render_depth_points": (_i, [_vp, _vp, _i, _f, _f, _f, _f, _i, _i, _i, _vp, _vp, _vp]),
+    "ossid_visib_mask_iou": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "ossid_pn2_fps": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ossid_pn2_ball_query": (_i, [_vp, _i, _i, _i, _vp, _i, _f, _i, _vp, _vp]),
     "ossid_pn2_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -1,0 +1,94 @@
+"""batch producer, bbox/heat map, visibility mask + IoU, splat renderer, BOP csv.
+CPU tests pin the numpy oracle (against the reference's own heatmapGaussain via the golden file) and the host-side csv
+writer; GPU tests compare the kernels with the oracle."""
+import csv
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline_oracle as po
+from ossid_code_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = np.load(os.path.join(ROOT, "tests", "golden", "dtoid_head.npz"))
+
+
+def test_oracle_heatmap_matches_reference_golden():
+    got = po.heatmap_gaussian(29, 39, 12.3, 7.9, np.sqrt(1.5))
+    assert got.shape == (29, 39) and np.array_equal(got, G["gauss"])
+
+
+def test_bop_csv_format(tmp_path):
+    from ossid_code_amd.pipeline import save_results_bop
+    pose = np.eye(4)
+    pose[:3, 3] = [0.1, -0.2, 0.8]
+    path = save_results_bop([{"scene_id": 2, "im_id": 5, "obj_id": 9, "pose": pose, "score": 21.5, "time": 0.3}],
+                            str(tmp_path), "my_exp", "lmo")
+    assert os.path.basename(path) == "my-exp_lmo-test.csv"
+    rows = list(csv.DictReader(open(path)))
+    assert list(rows[0].keys()) == ["scene_id", "im_id", "obj_id", "score", "R", "t", "time"]
+    assert rows[0]["t"] == "100.0 -200.0 800.0" and rows[0]["R"].split(" ")[0] == "1.0" and rows[0]["score"] == "21.5"
+    assert pose[2, 3] == 0.8                                  # caller's pose untouched
+
+
+def _frame(seed=0):
+    d = synth.make_scoring_inputs(N=2, M=900, seed=seed)
+    rng = np.random.default_rng(seed)
+    mask = np.zeros((480, 640), np.uint8)
+    mask[150:331, 200:401] = 255
+    mask[rng.random(mask.shape) < 0.3] = 0
+    return d, mask
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("out_hw", [None, (240, 320), (224, 224), (496, 656)])
+def test_batch_producer_matches_oracle(hiplib, out_hw):
+    from ossid_code_amd.pipeline import make_dtoid_sample
+    d, mask = _frame()
+    H, W = (480, 640) if out_hw is None else out_hw
+    s = make_dtoid_sample(d["img"], d["depth"], mask, d["cam_K"], out_hw=out_hw, heatmap_hw=(29, 39))
+    im, m, xyz = po.process_data(d["img"], mask / 255.0, d["depth"], d["cam_K"], H, W)
+    assert s["img"].shape == (3, H, W) and s["xyz"].shape == (3, H, W) and s["mask"].shape == (1, H, W)
+    if out_hw is None:                                        # same size: exact
+        assert np.array_equal(s["img"].cpu().numpy(), im) and np.array_equal(s["mask"].cpu().numpy(), m)
+        assert np.array_equal(s["xyz"].cpu().numpy(), xyz)
+    else:                                                     # float bilinear: same formula, fused multiply-adds aside
+        assert np.abs(s["img"].cpu().numpy() - im).max() <= 1.0 / 255 + 1e-6      # rounding to uint8 may flip one step
+        assert np.allclose(s["mask"].cpu().numpy(), m, atol=1e-6) and np.allclose(s["xyz"].cpu().numpy(), xyz, atol=1e-5)
+    box = po.mask_bbox(m[0])
+    assert s["bbox_gt"].cpu().numpy().astype(int).tolist() == [box.tolist()]
+    scale = 29.0 / H
+    want = po.heatmap_gaussian(29, 39, (box[0] + box[2]) / 2.0 * scale, (box[1] + box[3]) / 2.0 * scale, np.sqrt(1.5))
+    assert s["heatmap"].dtype == torch.float64 and np.allclose(s["heatmap"].cpu().numpy()[0], want, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.gpu
+def test_empty_mask_gives_padding_label(hiplib):
+    from ossid_code_amd.pipeline import make_dtoid_sample
+    d, mask = _frame()
+    s = make_dtoid_sample(d["img"], d["depth"], np.zeros_like(mask), d["cam_K"])
+    assert float(s["bbox_gt"][0, 4]) == -1 and float(s["heatmap"].abs().max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("radius", [0, 1, 2])
+def test_splat_renderer_and_visibility(hiplib, radius):
+    from ossid_code_amd.pipeline import render_depth_points, visibility_and_iou
+    d, _ = _frame(3)
+    pose = d["pose_hypos"][0]
+    H, W = 120, 160
+    K = d["cam_K"].copy()
+    K[:2] *= 0.25
+    got = render_depth_points(pose, d["model_points"], K, (H, W), radius=radius).cpu().numpy()
+    want = po.render_depth_points(pose, d["model_points"], K, H, W, radius)
+    assert np.array_equal(got, want) and (got > 0).sum() > 20
+    rng = np.random.default_rng(0)
+    d_obs = np.where(rng.random((H, W)) < 0.1, 0, want + rng.normal(0, 0.01, (H, W))).astype(np.float32)
+    gt = want > 0
+    gtv = gt & (rng.random((H, W)) < 0.8)
+    pm, vm, iou, iou_v = visibility_and_iou(d_obs, got, gt, gtv)
+    wpm, wvm, wiou, wiou_v = po.visib_and_iou(d_obs, want, gt, gtv, 15 / 1000.0)
+    assert np.array_equal(pm.cpu().numpy(), wpm) and np.array_equal(vm.cpu().numpy(), wvm)
+    assert iou == wiou == 1.0 and abs(iou_v - wiou_v) < 1e-12
