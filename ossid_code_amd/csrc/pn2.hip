@@ -455,42 +455,58 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float* __restrict__ 
 }
 
 // ---- ball query: one wave per centre, 64 candidate points per ballot -------------------------------
-constexpr int BQ_CPB = 64;  // centres per workgroup
-__global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ xyz, int stride, int n,
-                                                         const float* __restrict__ new_xyz, int npoint, float r2,
-                                                         int* __restrict__ idx) {
+// A workgroup of 16 waves stages the point set ONCE in LDS and covers up to 512 centres (all of SA1's): with 64 centres
+// per 4-wave workgroup the same 2048 points were staged eight times per hypothesis (and the strided 12-of-32-byte row
+// reads cost twice their bytes), which was most of the kernel.
+constexpr int BQ_CPB = 512;       // centres per workgroup
+constexpr int BQ_THREADS = 1024;
+__global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float* __restrict__ xyz, int stride, int n,
+                                                                const float* __restrict__ new_xyz, int npoint, float r2,
+                                                                int* __restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* pts = (float4*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const float* base = xyz + (size_t)b * n * stride;
-    for (int k = tid; k < n; k += 256)
+    for (int k = tid; k < n; k += BQ_THREADS)
         pts[k] = make_float4(base[(size_t)k * stride], base[(size_t)k * stride + 1], base[(size_t)k * stride + 2], 0.f);
     __syncthreads();
     const int jend = min((int)(blockIdx.y + 1) * BQ_CPB, npoint);
-    for (int j = blockIdx.y * BQ_CPB + wave; j < jend; j += 4) {
+    for (int j = blockIdx.y * BQ_CPB + wave; j < jend; j += BQ_THREADS / 64) {
         const float* c = new_xyz + ((size_t)b * npoint + j) * 3;
         const float cx = c[0], cy = c[1], cz = c[2];
         int* o = idx + ((size_t)b * npoint + j) * 64;
         int cnt = 0, first = -1;
-        for (int k0 = 0; k0 < n && cnt < 64; k0 += 64) {
-            const int k = k0 + lane;
-            bool hit = false;
-            if (k < n) {
-                float4 p = pts[k];
-                float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
-                float d2 = (dx * dx + dy * dy) + dz * dz;
-                hit = d2 < r2;
+        // four 64-point chunks per trip (most centres need ~25 chunks to collect 64 neighbours: the trip's latency
+        // chain -- LDS read, compare, ballot, scalar bookkeeping -- is what bounds the kernel, so give it 4x the work);
+        // slots are still handed out in index order, hits past the 64th are simply not stored
+        for (int k0 = 0; k0 < n && cnt < 64; k0 += 256) {
+            bool hit[4];
+            unsigned long long bal[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 64 * u + lane;
+                hit[u] = false;
+                if (k < n) {
+                    float4 p = pts[k];
+                    float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
+                    float d2 = (dx * dx + dy * dy) + dz * dz;
+                    hit[u] = d2 < r2;
+                }
+                bal[u] = __ballot(hit[u]);
             }
-            const unsigned long long bal = __ballot(hit);
-            if (bal) {
-                if (first < 0) first = k0 + __ffsll((long long)bal) - 1;
-                int slot = cnt + __popcll(bal & ((1ull << lane) - 1ull));
-                if (hit && slot < 64) o[slot] = k;
-                cnt += __popcll(bal);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (bal[u]) {
+                    if (first < 0) first = k0 + 64 * u + __ffsll((long long)bal[u]) - 1;
+                    int slot = cnt + __popcll(bal[u] & ((1ull << lane) - 1ull));
+                    if (hit[u] && slot < 64) o[slot] = k0 + 64 * u + lane;
+                    cnt += __popcll(bal[u]);
+                }
             }
         }
         if (first < 0) first = 0;
+        if (cnt > 64) cnt = 64;
         if (lane >= cnt) o[lane] = first;
     }
 }
@@ -905,8 +921,8 @@ int launch_ball(const float* xyz, int stride, int B, int n, const float* new_xyz
                                 (int)lds) != hipSuccess)
             return OSSID_ELAUNCH;
     const float r2 = radius * radius;
-    hipLaunchKernelGGL(ball_query_kernel, dim3(B, (npoint + BQ_CPB - 1) / BQ_CPB), dim3(256), lds, s, xyz, stride, n,
-                       new_xyz, npoint, r2, idx);
+    hipLaunchKernelGGL(ball_query_kernel, dim3(B, (npoint + BQ_CPB - 1) / BQ_CPB), dim3(BQ_THREADS), lds, s, xyz, stride,
+                       n, new_xyz, npoint, r2, idx);
     return ossid_launch_status();
 }
 
