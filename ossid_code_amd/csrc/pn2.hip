@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* base = xyz + (size_t)blockIdx.x * n * stride;
     float px[P], py[P], pz[P], tmp[P];
-    bool live[P];
+    int anyz = 0;
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const int k = tid * P + j;
@@ -393,10 +393,14 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float* __restrict__ 
             pts[k] = make_float4(x, y, z, 0.f);
         }
         px[j] = x, py[j] = y, pz[j] = z;
-        tmp[j] = 1e10f;
-        live[j] = (k < n) && (((x * x + y * y) + z * z) > 1e-3f);
+        anyz |= (z != 0.0f);
+        // a point that may never be picked (|p|^2 <= 1e-3, or padding) gets running distance -1: min(d, -1) stays -1
+        // and -1 never beats the initial best of -1, which is exactly pointnet2's `continue`
+        tmp[j] = ((k < n) && (((x * x + y * y) + z * z) > 1e-3f)) ? 1e10f : -1.0f;
     }
-    __syncthreads();
+    // the scorer's point sets are planar (SPEC 3.4: channel 2 is 0): with every z == 0 the dz terms are exact zeros and
+    // can be skipped without changing a single bit; any non-zero z in the set selects the general loop
+    const bool planar = !__syncthreads_or(anyz);
     int old = 0;
     int* io = idx_out + (size_t)blockIdx.x * npoint;
     float* xo = new_xyz + (size_t)blockIdx.x * npoint * 3;
@@ -410,12 +414,22 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float* __restrict__ 
         const float4 po = pts[old];
         float best = -1.0f;
         int besti = 0;
+        if (planar) {
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const float dx = px[j] - po.x, dy = py[j] - po.y, dz = pz[j] - po.z;
-            const float d = (dx * dx + dy * dy) + dz * dz;
-            const float d2 = fminf(d, tmp[j]);
-            if (live[j]) {
+            for (int j = 0; j < P; ++j) {
+                const float dx = px[j] - po.x, dy = py[j] - po.y;
+                const float d2 = fminf(dx * dx + dy * dy, tmp[j]);
+                tmp[j] = d2;
+                if (d2 > best) {
+                    best = d2;
+                    besti = tid * P + j;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const float dx = px[j] - po.x, dy = py[j] - po.y, dz = pz[j] - po.z;
+                const float d2 = fminf((dx * dx + dy * dy) + dz * dz, tmp[j]);
                 tmp[j] = d2;
                 if (d2 > best) {
                     best = d2;
