@@ -67,3 +67,45 @@ def test_frame_sharding_is_a_partition():
             flat = sorted(i for p in parts for i in p)
             assert flat == list(range(n_frames))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def _sequential_reference(n_frames, interval, confident_of):
+    """The reference's single-process loop: the detector version a frame sees = number of finetunes before it."""
+    version, train, nxt, seen = 0, 0, interval, []
+    for f in range(n_frames):
+        c = confident_of(f, version)
+        seen.append((f, version, c))
+        if c:
+            train += 1
+            if train == nxt:
+                version += 1
+                nxt += interval
+    return seen
+
+
+def test_speculative_window_reproduces_sequential_semantics():
+    """8 'GPUs' scoring windows of frames with frozen weights, in-order commit, re-issue after a finetune: every frame
+    ends up scored with exactly the detector version the sequential loop would have used."""
+    import random
+    from ossid_code_amd.stream import SpeculativeWindow
+    for seed in range(20):
+        rng = random.Random(seed)
+        table = {}
+
+        def confident_of(f, version):
+            return table.setdefault((f, version), rng.random() < 0.45)
+        n_frames, interval = 97, 5
+        for world in (1, 2, 8):
+            win = SpeculativeWindow(n_frames, world, interval)
+            version, seen = 0, []
+            while not win.done:
+                frames = win.window()
+                flags = [confident_of(f, version) for f in frames]          # all ranks use the CURRENT weights
+                before = len(win.committed)
+                fired = win.commit(flags)
+                for f, c in win.committed[before:]:
+                    seen.append((f, version, c))
+                if fired is not None:
+                    version += 1                                            # DDP finetune on all ranks
+            assert seen == _sequential_reference(n_frames, interval, confident_of), (seed, world)
+            assert [f for f, _, _ in seen] == list(range(n_frames))          # every frame committed once, in order

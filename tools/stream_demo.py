@@ -1,0 +1,106 @@
+"""Synthetic online stream on one MI355X: detect -> score N hypotheses -> pseudo-label -> finetune every
+`--interval` confident frames. Prints one JSON line with frames/s and the per-stage wall time. Random-init networks and
+synthetic frames: this measures the loop, not accuracy.
+  python tools/stream_demo.py --frames 24 --hypos 1000 --interval 8
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from ossid_code_amd import dtoid, pipeline, synth, zephyr            # noqa: E402
+from ossid_code_amd.dtoid import finetune                             # noqa: E402
+from ossid_code_amd.stream import OnlineStream                        # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--hypos", type=int, default=1000)
+    ap.add_argument("--points", type=int, default=2048)
+    ap.add_argument("--templates", type=int, default=21)
+    ap.add_argument("--interval", type=int, default=8)
+    ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    det = dtoid.DtoidNet(dtoid.DtoidConfig()).to(dev).eval()
+    flat = finetune.FlatParams(det)
+    opt = finetune.FusedAMSGrad(flat, lr=1e-4, weight_decay=1e-6)
+    class Args:
+        dataset, no_valid_proj, no_valid_depth, inconst_ratio_th, interp = "HSVD_diff_uv_norm", True, True, 100, 0
+
+    dataset = zephyr.ScoreDataset([], "", "lmo", Args(), mode="test")
+    scorer = synth.random_pn2_state(zephyr.PointNet2SSG(dataset.dim_point, Args(), num_class=1), 0).to(0).eval()
+    g = torch.Generator().manual_seed(1)
+    limg = torch.rand(a.templates, 3, 124, 124, generator=g)
+    lmask = (torch.rand(a.templates, 1, 124, 124, generator=g) > 0.5).float()
+    frames = []
+    for f in range(a.frames):
+        d = synth.make_scoring_inputs(a.hypos, a.points, seed=100 + f)
+        d.update(limg=limg, lmask=lmask, obj_id=1, pose_gt=d["pose_hypos"][0].copy())
+        frames.append(d)
+    ft_time, ft_steps = [0.0], [0]
+
+    def finetune_fn(samples):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tl, tm = limg.to(dev), lmask.to(dev)
+        items = []
+        for _, s in samples:
+            s = dict(s)
+            s.update(limg=tl[0], lmask=tm[0], gimg=tl[1 % a.templates], gmask=tm[1 % a.templates])
+            items.append(s)
+        det.train()
+        rng = np.random.default_rng(len(items))
+        for _ in range(a.epochs):
+            order = rng.permutation(len(items))
+            for b0 in range(0, len(order), a.batch):
+                batch = pipeline.collate([items[i] for i in order[b0:b0 + a.batch]])
+                finetune.finetune_step(det, batch, opt)
+                ft_steps[0] += 1
+        det.eval()
+        det.clearCache()                       # template features depend on the weights that just changed
+        torch.cuda.synchronize()
+        ft_time[0] += time.perf_counter() - t0
+
+    stream = OnlineStream(det, scorer, dataset, confident_threshold=-1e30, finetune_fn=finetune_fn)
+    r0 = stream.process(frames[0])             # warm-up: graph capture, workspace allocation ...
+    snap_p, snap_b = flat.param.clone(), [b.clone() for b in det.buffers()]
+    epochs, a.epochs = a.epochs, 1                # ... and MIOpen's per-shape algorithm search for the training convs
+    for nb in sorted({a.batch, a.interval % a.batch or a.batch}):
+        finetune_fn([(frames[0], r0["sample"])] * nb)
+    a.epochs = epochs
+    with torch.no_grad():
+        flat.param.copy_(snap_p)
+        for b, s0 in zip(det.buffers(), snap_b):
+            b.copy_(s0)
+    for t in (opt.exp_avg, opt.exp_avg_sq, opt.max_exp_avg_sq):
+        t.zero_()
+    opt.step_count, ft_time[0], ft_steps[0] = 0, 0.0, 0
+    det.clearCache()
+    for k in stream.times:
+        stream.times[k] = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    results, win = stream.run(frames, a.interval)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    per = {k: 1e3 * v / a.frames for k, v in stream.times.items()}
+    print(json.dumps({"metric": "online stream frames/sec", "value": a.frames / total, "unit": "frames/s", "n_gpus": 1,
+                      "frames": a.frames, "hypotheses_per_frame": a.hypos, "points": a.points,
+                      "templates": a.templates, "finetunes": len(win.train_set) // a.interval,
+                      "finetune_steps": ft_steps[0], "finetune_ms_per_step": 1e3 * ft_time[0] / max(1, ft_steps[0]),
+                      "ms_per_frame_excl_finetune": 1e3 * (total - ft_time[0]) / a.frames,
+                      "stage_ms_per_frame": per, "hyp_per_sec_in_stream": a.hypos / (per["score"] * 1e-3),
+                      "data": "synthetic", "weights": "random-init"}))
+
+
+if __name__ == "__main__":
+    main()
