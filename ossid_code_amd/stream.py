@@ -129,3 +129,64 @@ class OnlineStream:
             if fired is not None and self.finetune_fn is not None:
                 self.finetune_fn(samples)
         return results, win
+
+
+def run_speculative(frames, process_fn, finetune_fn, finetune_interval, dist=None, group=None):
+    """The multi-GPU stream, SPMD: every rank calls this with the same `frames`. process_fn(frame) -> (confident, sample)
+    scores one frame with this rank's (replicated) weights; finetune_fn(train_set) is entered by ALL ranks together with the
+    identical, frame-ordered list of (frame_id, sample) and is expected to run the data-parallel finetune (GradSync).
+    Per window: one frame per rank, an all_gather of the confident flags, in-order commit, an all_gather_object-free
+    sample exchange (each confident sample is broadcast from the rank that produced it: a 480x640 sample is ~5 MB, one
+    xGMI hop). Returns the committed [(frame_id, confident)] and the SpeculativeWindow (for .discarded)."""
+    world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    win = SpeculativeWindow(len(frames), world, finetune_interval)
+    train = []
+    while not win.done:
+        ids = win.window()
+        mine = ids[rank] if rank < len(ids) else None
+        confident, sample = process_fn(frames[mine]) if mine is not None else (False, None)
+        if world > 1:
+            flag = torch.tensor([1 if confident else 0], dtype=torch.int32)
+            dev = next((v.device for v in (sample or {}).values() if torch.is_tensor(v)), None)
+            backend_cuda = dist.get_backend(group) == "nccl"
+            if backend_cuda:
+                flag = flag.cuda()
+            flags = [torch.zeros_like(flag) for _ in range(world)]
+            dist.all_gather(flags, flag, group=group)
+            flags = [bool(int(f)) for f in flags][: len(ids)]
+        else:
+            flags = [bool(confident)]
+        n_before = len(win.committed)
+        fired = win.commit(flags)
+        for f, c in win.committed[n_before:]:
+            if not c:
+                continue
+            src = f - ids[0]
+            if world > 1:
+                sample_f = _broadcast_sample(sample if src == rank else None, src, dist, group)
+            else:
+                sample_f = sample
+            train.append((f, sample_f))
+        if fired is not None:
+            finetune_fn(train)
+    return win.committed, win
+
+
+def _broadcast_sample(sample, src, dist, group):
+    """Sends a dict of tensors from rank `src` to everyone: the (small) key/shape/dtype header as an object, the payload as
+    tensor broadcasts on the group's device."""
+    header = [None]
+    if sample is not None:
+        header = [[(k, tuple(v.shape), v.dtype) for k, v in sample.items() if torch.is_tensor(v)]]
+    dist.broadcast_object_list(header, src=src, group=group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    out = {}
+    for k, shape, dtype in header[0]:
+        if sample is not None:
+            t = sample[k].contiguous()
+        else:
+            t = torch.empty(shape, dtype=dtype, device="cuda" if on_gpu else "cpu")
+        dist.broadcast(t, src=src, group=group)
+        out[k] = t
+    return out

@@ -109,3 +109,59 @@ def test_speculative_window_reproduces_sequential_semantics():
                     version += 1                                            # DDP finetune on all ranks
             assert seen == _sequential_reference(n_frames, interval, confident_of), (seed, world)
             assert [f for f, _, _ in seen] == list(range(n_frames))          # every frame committed once, in order
+
+
+def _stream_worker(rank, world, port, n_frames, interval, q):
+    import torch
+    import torch.distributed as dist
+    from ossid_code_amd.stream import run_speculative
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    version = torch.zeros(1)                                   # stands for the replicated detector weights
+    seen_by_me = []
+
+    def process(frame):
+        conf = ((frame * 7 + int(version.item()) * 3) % 5) < 2
+        seen_by_me.append((frame, int(version.item())))
+        return conf, {"x": torch.full((2, 3), float(frame)), "v": version.clone()}
+
+    sets = []
+
+    def finetune(train):
+        # every rank must hold the same frame-ordered set, with the payload produced by whichever rank scored the frame
+        sets.append([(f, float(s["x"][0, 0]), float(s["v"][0])) for f, s in train])
+        g = torch.ones(1)
+        dist.all_reduce(g)                                     # the data-parallel step: everyone takes part
+        version.add_(g / world)
+
+    committed, win = run_speculative(list(range(n_frames)), process, finetune, interval, dist)
+    q.put((rank, committed, sets, seen_by_me, win.discarded))
+    dist.destroy_process_group()
+
+
+def test_speculative_stream_gloo_world2_matches_sequential():
+    import torch.multiprocessing as mp
+    n_frames, interval = 41, 4
+    # sequential truth
+    version, train, nxt, truth, sets = 0, [], interval, [], []
+    for f in range(n_frames):
+        c = ((f * 7 + version * 3) % 5) < 2
+        truth.append((f, c))
+        if c:
+            train.append((f, float(f), float(version)))
+            if len(train) == nxt:
+                sets.append(list(train))
+                version += 1
+                nxt += interval
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_stream_worker, args=(r, 2, port, n_frames, interval, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    for rank, committed, rsets, seen, discarded in got:
+        assert committed == truth, rank
+        assert rsets == sets, rank
+    assert got[0][4] == got[1][4] and got[0][4] > 0           # some speculated frames were thrown away and re-issued
