@@ -41,6 +41,8 @@ def main():
     g = torch.Generator().manual_seed(1)
     limg = torch.rand(a.templates, 3, 124, 124, generator=g)
     lmask = (torch.rand(a.templates, 1, 124, 124, generator=g) > 0.5).float()
+    bank = pipeline.TemplateBank(n_local_test=a.templates)
+    bank.add(1, limg, lmask)
     frames = []
     for f in range(a.frames):
         d = synth.make_scoring_inputs(a.hypos, a.points, seed=100 + f)
@@ -51,12 +53,10 @@ def main():
     def finetune_fn(samples):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        tl, tm = limg.to(dev), lmask.to(dev)
-        items = []
-        for _, s in samples:
-            s = dict(s)
-            s.update(limg=tl[0], lmask=tm[0], gimg=tl[1 % a.templates], gmask=tm[1 % a.templates])
-            items.append(s)
+        ps = pipeline.PseudoLabelSet(bank, mode="train", seed=len(samples))
+        for i, (fr, smp) in enumerate(samples):
+            ps.add(1, 0, i, fr["img"], fr["depth"], fr["cam_K"], smp["mask"][0], 0.0)
+        items = [ps[i] for i in range(len(ps))]
         det.train()
         rng = np.random.default_rng(len(items))
         for _ in range(a.epochs):
