@@ -654,10 +654,24 @@ __global__ __launch_bounds__(256, 2) void p2_kernel(const float* __restrict__ fe
 // One wave per centre, its two 32-sample column tiles one after the other (a tile holds 64 + 64
 // activation registers); the first tile's pooled maxima wait in the output row and are merged by the
 // same lane when the second tile is done.
+// Weights: the last layer's 128 KB stay resident in LDS; the middle layer's 64 KB do not fit beside them, so they go
+// round a two-slot LDS RING of 8 KB chunks (8 quads = half an output tile) filled by LDS-DMA (global_load_lds_dwordx4:
+// the packed quad image is lane-linear, one 1 KB wave-instruction per quad, no VGPRs): the 8 waves walk the layer in
+// step, each issues one quad of chunk k+1 right after the barrier that publishes chunk k, and the 2 x 32 MFMAs per
+// SIMD of a chunk cover the L2 latency of the next. (Streaming this layer through registers from L2 instead ran the
+// matrix core at ~62 % for a third of the kernel's work.)
 constexpr int SA2_CPW = 8;
 constexpr int SA2_THREADS = 512;                       // 8 waves = the whole CU at two waves per SIMD
-constexpr int SA2_W3 = 0, SA2_B3 = 32768, SA2_B2 = SA2_B3 + 256, SA2_WX = SA2_B2 + 128,
-              SA2_LDS_FLOATS = SA2_WX + 384;          // W3p 128 KB | b3 | b2 | wxyz  = 134 144 B
+constexpr int SA2_CHUNK = 8 * 256;                     // floats per ring slot: 8 quads x 64 lanes x 4
+constexpr int SA2_W3 = 0, SA2_B3 = 32768, SA2_B2 = SA2_B3 + 256, SA2_WX = SA2_B2 + 128, SA2_RING = SA2_WX + 384,
+              SA2_KEEP = SA2_RING + 2 * SA2_CHUNK,
+              SA2_LDS_FLOATS = SA2_KEEP + 8 * 256;   // W3p 128 KB | b3 | b2 | wxyz | ring 16 KB | keep 8 KB = 158 720 B
+
+__device__ __forceinline__ void lds_dma_quad(const float4* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 __global__ __launch_bounds__(SA2_THREADS, 2) void sa2_kernel(const float* __restrict__ P, const float* __restrict__ xyz1,
                                                              int np1, const int* __restrict__ ball,
                                                              const float* __restrict__ cxyz, int np2, int total,
@@ -666,54 +680,96 @@ __global__ __launch_bounds__(SA2_THREADS, 2) void sa2_kernel(const float* __rest
                                                              const float* __restrict__ W3p, const float* __restrict__ b3,
                                                              float* __restrict__ feat) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
+    // chunk g of the middle layer = quads 8g..8g+7; this wave moves quad 8g+wave into slot g&1
+    const float4* W2q = (const float4*)W2p + (size_t)wave * 64 + lane;
+    float* ring_mine = wl + SA2_RING + wave * 256;
+    lds_dma_quad(W2q, ring_mine);
     stage_lds(wl + SA2_W3, W3p, 32768);
     stage_lds(wl + SA2_B3, b3, 256);
     stage_lds(wl + SA2_B2, b2, 128);
     stage_lds(wl + SA2_WX, wxyz, 384);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
-    const int row = scatter_row(lane);
-#pragma unroll 1
-    for (int cw = 0; cw < SA2_CPW; ++cw) {
-        const int centre = (blockIdx.x * (SA2_THREADS / 64) + wave) * SA2_CPW + cw;
-        if (centre >= total) break;
-        const int n = centre / np2;
-        const float cx = cxyz[(size_t)centre * 3], cy = cxyz[(size_t)centre * 3 + 1], cz = cxyz[(size_t)centre * 3 + 2];
-        float* out = feat + (size_t)centre * 256 + c;
-#pragma unroll 1
-        for (int t = 0; t < 2; ++t) {
-            const float* w = wl + opaque_zero();
-            W2p = opaque(W2p);
-            const int i = ball[(size_t)centre * 64 + t * 32 + c];
-            const size_t pt = (size_t)n * np1 + i;
-            const float dx = xyz1[pt * 3] - cx, dy = xyz1[pt * 3 + 1] - cy, dz = xyz1[pt * 3 + 2] - cz;
-            v16f X1[1][4], Y2[1][4];
+    float* keep = wl + SA2_KEEP + wave * 256 + c;          // the first tile's pooled maxima of this wave's centre
+
+    // The 8 waves keep step through the ring's barriers, so a tile's gather must not sit between them: the sample
+    // indices of tile it+1 are fetched under tile it's first chunk and its 16 P quads + xyz under tile it's last layer.
+    constexpr int NTILE = SA2_CPW * 2;
+    const int centre0 = (blockIdx.x * (SA2_THREADS / 64) + wave) * SA2_CPW;
+    auto centre_of = [&](int it) { return min(centre0 + (it >> 1), total - 1); };
+    float4 pvn[16];
+    float nx, ny, nz, ncx, ncy, ncz;
+    int inext;
+    auto fetch_index = [&](int it) {
+        const int ce = centre_of(it);
+        inext = ball[(size_t)ce * 64 + (it & 1) * 32 + c];
+        ncx = cxyz[(size_t)ce * 3], ncy = cxyz[(size_t)ce * 3 + 1], ncz = cxyz[(size_t)ce * 3 + 2];
+    };
+    auto fetch_rows = [&](int it) {
+        const size_t pt = (size_t)(centre_of(it) / np2) * np1 + inext;
+        nx = xyz1[pt * 3], ny = xyz1[pt * 3 + 1], nz = xyz1[pt * 3 + 2];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+        for (int j = 0; j < 16; ++j) pvn[j] = *(const float4*)(P + pt * 128 + (j >> 2) * 32 + 8 * (j & 3) + 4 * h);
+    };
+    fetch_index(0);
+    fetch_rows(0);
+#pragma unroll 1
+    for (int it = 0; it < NTILE; ++it) {
+        const float* w = wl + opaque_zero();
+        const int t = it & 1;
+        const bool live = centre0 + (it >> 1) < total;       // a spare wave keeps step with the ring, stores nothing
+        float* out = feat + (size_t)centre_of(it) * 256 + c;
+        const float dx = nx - ncx, dy = ny - ncy, dz = nz - ncz;
+        v16f X1[1][4], Y2[1][4];
+        v16f acc;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int off = kt * 32 + 8 * q + 4 * h;
-                    float4 p = *(const float4*)(P + pt * 128 + off);
-                    float4 wx = *(const float4*)(w + SA2_WX + off), wy = *(const float4*)(w + SA2_WX + 128 + off),
-                           wz = *(const float4*)(w + SA2_WX + 256 + off);
-                    X1[0][kt][4 * q + 0] = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, p.x))), 0.0f);
-                    X1[0][kt][4 * q + 1] = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, p.y))), 0.0f);
-                    X1[0][kt][4 * q + 2] = fmaxf(fmaf(wz.z, dz, fmaf(wy.z, dy, fmaf(wx.z, dx, p.z))), 0.0f);
-                    X1[0][kt][4 * q + 3] = fmaxf(fmaf(wz.w, dz, fmaf(wy.w, dy, fmaf(wx.w, dx, p.w))), 0.0f);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            // middle layer: weights streamed from L2 (64 KB more would not fit beside W3 in the 160 KB of LDS)
-            stream_layer<4, 4, 1, 8>((const float4*)W2p + lane, w + SA2_B2, X1, h,
-                                     [&](int mt, v16f(&acc)[1]) { Y2[0][mt] = relu16(acc[0]); });
-            stream_last_layer<4, 1, 4>((const float4*)(w + SA2_W3) + lane, w + SA2_B3, Y2, c, 8,
-                                       [&](int mt, v16f(&acc)[1]) {
-                                           float r = pool_swapped(acc[0]);
-                                           if (h == 0) {
-                                               if (t == 1) r = fmaxf(r, out[mt * 32]);
-                                               out[mt * 32] = r;
-                                           }
-                                       });
+        for (int g = 0; g < 8; ++g) {
+            __syncthreads();          // chunk g has landed in slot g&1 (every wave waited for its own piece) and
+                                      // nobody reads slot (g+1)&1 any more
+            if (!(it == NTILE - 1 && g == 7))
+                lds_dma_quad(W2q + (size_t)(((g + 1) & 7) * 8) * 64, ring_mine + ((g + 1) & 1) * SA2_CHUNK);
+            if (g == 0) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int off = kt * 32 + 8 * q + 4 * h;
+                        const float4 p = pvn[kt * 4 + q];
+                        float4 wx = *(const float4*)(w + SA2_WX + off), wy = *(const float4*)(w + SA2_WX + 128 + off),
+                               wz = *(const float4*)(w + SA2_WX + 256 + off);
+                        X1[0][kt][4 * q + 0] = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, p.x))), 0.0f);
+                        X1[0][kt][4 * q + 1] = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, p.y))), 0.0f);
+                        X1[0][kt][4 * q + 2] = fmaxf(fmaf(wz.z, dz, fmaf(wy.z, dy, fmaf(wx.z, dx, p.z))), 0.0f);
+                        X1[0][kt][4 * q + 3] = fmaxf(fmaf(wz.w, dz, fmaf(wy.w, dy, fmaf(wx.w, dx, p.w))), 0.0f);
+                        if (q == 3) __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of later rows from piling up
+                    }
+                fetch_index(min(it + 1, NTILE - 1));          // retired by the next barrier's wait, under this chunk
+            }
+            const float4* rb = (const float4*)(w + SA2_RING + (g & 1) * SA2_CHUNK) + lane;
+            float4 a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = rb[j * 64];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int quad = g * 8 + j, mt = quad / 16, kq = quad % 16, kt = kq / 4, q = kq % 4;
+                if (kq == 0) acc = bias_tile(w + SA2_B2, mt, h);
+                acc = mfma4(a[j], X1[0][kt], 4 * q, acc);
+                if (kq == 15) Y2[0][mt] = relu16(acc);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_rows(min(it + 1, NTILE - 1));                    // in flight under the last layer
+        __builtin_amdgcn_sched_barrier(0);
+        stream_last_layer<4, 1, 4>((const float4*)(w + SA2_W3) + lane, w + SA2_B3, Y2, c, 8,
+                                   [&](int mt, v16f(&acc3)[1]) {
+                                       float r = pool_swapped(acc3[0]);
+                                       if (h == 0) {
+                                           if (t == 0) {
+                                               keep[mt * 32] = r;
+                                           } else if (live) {
+                                               out[mt * 32] = fmaxf(r, keep[mt * 32]);
+                                           }
+                                       }
+                                   });
     }
 }
 
