@@ -42,6 +42,7 @@ struct ConvArgs {
     const float *bias, *bn_scale, *bn_shift, *pre_scale, *pre_shift;
     float* out;
     int H, W, Cin, Cout, n_cotiles, act, buf_pos, Hs, Ws, in_cs, out_cs, out_coff, pre_relu;
+    int gx, gy, gz;   // logical grid: pixel blocks x channel-tile groups x images (the launch itself is 1-D)
     float scale_h, scale_w;
 };
 
@@ -62,7 +63,31 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float4 patch[];   // [2][buf_pos][F4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
     const int wm = wave % WM, wk = (wave / WM) % WK, wn = wave / (WM * WK);
-    const int b = blockIdx.z;
+    // ---- logical block (bx, by, b) from the 1-D launch id, XCD-aware ------------------------------------------------
+    // Workgroup ids go round-robin over the 8 XCDs, each with a private 4 MB L2. The packed weights of ONE channel-tile
+    // group (WM x 32 output channels x Cin x taps: 2.9 MB for 640->256, 3.5 MB for 768->512) fit there, those of the
+    // whole layer do not, so every XCD is given pixel blocks of a single group: id%8 picks (group, slot), id/8 walks
+    // the pixel blocks. (A performance choice only -- any placement computes the same values.)
+    int bx, by, b;
+    {
+        const int L = blockIdx.x, P = A.gx * A.gz;
+        int pt;
+        if (A.gy <= 8 && (8 % A.gy) == 0) {
+            const int k = L & 7, R = 8 / A.gy;
+            by = k % A.gy;
+            pt = (L >> 3) * R + k / A.gy;
+        } else if ((A.gy & 7) == 0) {
+            const int j = L >> 3;
+            by = (L & 7) + 8 * (j / P);
+            pt = j % P;
+        } else {
+            by = (L / A.gx) % A.gy;
+            pt = (L % A.gx) + A.gx * (L / (A.gx * A.gy));
+        }
+        if (pt >= P) return;
+        bx = pt % A.gx;
+        b = pt / A.gx;
+    }
     const int H = A.H, W = A.W, HW = H * W;
 
     // ---- geometry of this workgroup's pixels and of its patch ----------------------------------------------------
@@ -72,12 +97,12 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         PR = 1;
     } else if (ROWSEG) {
         const int segs = (W + BPX - 1) / BPX;
-        y_first = blockIdx.x / segs;
-        x_first = (blockIdx.x % segs) * BPX;
+        y_first = bx / segs;
+        x_first = (bx % segs) * BPX;
         PW = BPX + 2;
         PR = 3;
     } else {
-        const int px0 = blockIdx.x * BPX;
+        const int px0 = bx * BPX;
         y_first = px0 / W;
         const int y_last = min(px0 + BPX - 1, HW - 1) / W;
         PW = W + 2;
@@ -92,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         const int idx = tid + e * 256;
         const int pos = idx / F4, j = idx % F4;
         if (TAPS == 1) {
-            const int px = blockIdx.x * BPX + pos;
+            const int px = bx * BPX + pos;
             const bool ok = pos < npos && px < HW;
             goff[e] = ok ? ((b * HW + px) * A.in_cs + 4 * j) : -1;
         } else {
@@ -114,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     for (int t = 0; t < NT; ++t) {
         const int j = (wn * NT + t) * 32 + c;
         if (TAPS == 1) {
-            const int px = blockIdx.x * BPX + j;
+            const int px = bx * BPX + j;
             pos0[t] = j;
             opx[t] = (px < HW) ? (b * HW + px) : -1;
         } else if (ROWSEG) {
@@ -122,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
             pos0[t] = j;
             opx[t] = (xx < W) ? (b * HW + y_first * W + xx) : -1;
         } else {
-            const int px = blockIdx.x * BPX + j;
+            const int px = bx * BPX + j;
             const int pxc = min(px, HW - 1);
             const int y = pxc / W, xx = pxc - y * W;
             pos0[t] = (y - y_first) * PW + xx;
@@ -130,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         }
     }
 
-    const int co_tile = blockIdx.y * WM + wm;
+    const int co_tile = by * WM + wm;
     const bool active = co_tile < A.n_cotiles;
     const int nq = (A.Cin / 8) * TAPS;                          // weight quads per channel tile
     const float4* W4 = A.wpk + (size_t)(active ? co_tile : 0) * nq * 64 + lane;
@@ -198,22 +223,34 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     int gi = 0;
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
+#ifndef OSSID_ABL_NOSTAGE
         if (ch + 1 < nchunks) stage_load((ch + 1) * KCH);     // in flight under this chunk's MFMAs
+#endif
         const float4* pb = patch + (size_t)(ch & 1) * A.buf_pos * F4 + h;
 #pragma unroll
         for (int g = 0; g < GPC; ++g) {
 #pragma unroll
+#ifndef OSSID_ABL_NOW
             for (int i = 0; i < GQ; ++i) nxt[i] = W4[(size_t)quad_of(gi + 1, i) * 64];
+#else
+            for (int i = 0; i < GQ; ++i) nxt[i] = cur[i];
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < GQ; ++i) {
-                if (!active) break;    // a workgroup's spare waves only help with staging
+                // (a workgroup's spare waves -- channel tiles past the last -- run the same MFMAs on tile 0's weights and
+                // store nothing: a per-wave branch here would put the accumulators through VGPR<->AGPR copies and a
+                // matrix-pipe drain around every group)
                 const int kb = wk * NKB + (TAPS == 9 ? g / 3 : g * GQ + i);       // 8-channel block inside the chunk
                 const int toff = TAPS == 9 ? (g % 3) * PW + i : 0;
                 const float4 a = cur[i];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
+#ifndef OSSID_ABL_NOB
                     const float4 bq = pb[(size_t)(pos0[t] + toff) * F4 + 2 * kb];
+#else
+                    const float4 bq = make_float4(a.y, a.x, a.w, a.z);
+#endif
                     acc[t] = mfma(a.x, bq.x, acc[t]);
                     acc[t] = mfma(a.y, bq.y, acc[t]);
                     acc[t] = mfma(a.z, bq.z, acc[t]);
@@ -331,8 +368,15 @@ int launch_conv(ConvArgs a, int B, hipStream_t s) {
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return OSSID_ELAUNCH;
-    dim3 grid(nblk, (a.n_cotiles + WM - 1) / WM, B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    a.gx = nblk, a.gy = (a.n_cotiles + WM - 1) / WM, a.gz = B;
+    const long P = (long)a.gx * a.gz;
+    long nwg;
+    if (a.gy <= 8 && 8 % a.gy == 0)
+        nwg = 8 * ((P + 8 / a.gy - 1) / (8 / a.gy));
+    else
+        nwg = P * a.gy;          // gy a multiple of 8 (exact) or the plain mapping
+    if (nwg > 0x7fffffffL) return OSSID_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, s, a);
     return ossid_launch_status();
 }
 
@@ -403,8 +447,24 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
     // staged float4 per thread were measured slower on the decoder's few-channel layers: their K is only 288-576, so
     // the per-workgroup set-up, not the weight stream, is what counts.)
     if (tiles >= 4) {
-        const long blocks128 = (px + 127) / 128 * ((tiles + 3) / 4);
-        return blocks128 >= 768 ? OSSID_CONV(4, 4) : OSSID_CONV(4, 2);
+        // Pixel tiles per wave (NT x 32 pixels per workgroup): two workgroups fit a CU, and the tail of a launch packs
+        // them two to a CU again, so time goes in whole "rounds" of 512 workgroups. Pick the NT with the least
+        // rounds x tile work (a quarter tile of fixed cost per workgroup favours the larger tile on a draw).
+        const long groups = (tiles + 3) / 4;
+        int best = 2;
+        double best_cost = 1e30;
+        for (int nt = 1; nt <= 4; ++nt) {
+            const long per = rowseg ? (long)H * ((W + nt * 32 - 1) / (nt * 32)) : ((long)H * W + nt * 32 - 1) / (nt * 32);
+            const long nwg = per * B * groups;
+            const double cost = (double)((nwg + 511) / 512) * (nt + 0.25);
+            if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && nt > best)) best = nt, best_cost = cost;
+        }
+        switch (best) {
+            case 1: return OSSID_CONV(4, 1);
+            case 2: return OSSID_CONV(4, 2);
+            case 3: return OSSID_CONV(4, 3);
+            default: return OSSID_CONV(4, 4);
+        }
     }
     if (tiles >= 2) return OSSID_CONV(2, 2);
     return OSSID_CONV(1, 1);
