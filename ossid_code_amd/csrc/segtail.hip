@@ -1,0 +1,202 @@
+// The tail of DTOID's segmentation decoder in one launch (gfx950):
+//   nearest up-sample [Hs][Ws] -> [H][W]  ->  conv3x3 32->16 + bias -> ELU -> BatchNorm(eval)  ->  conv3x3 16->1 + bias
+// (/root/reference/python/ossid/models/dtoid/network.py:357-362: `x = F.interpolate(x, size=img_size)`,
+//  `x = self.ns5(F.elu(self.s5(x)))`, `seg = self.seg_final(x)`.)
+//
+// At 480x640 with 21 templates these two layers were 1.9 ms of a 14.7 ms frame as separate launches: the 32->16 layer
+// wasted half of every 32x32 matrix-core tile on channel padding and re-read each source row three times (2.5 GB past
+// L2 for a 0.2 GB source), and the 16->1 layer is a 413 MB read for 1.9 GFLOP. Fused, the 16-channel full-resolution
+// tensor (21 x 480 x 640 x 16 floats) never exists: a workgroup owns a 14 x 30 pixel output tile, stages the SOURCE
+// pixels under its (18 x 34)-pixel up-sampled footprint once, runs the first conv for the 16 x 32 pixels the second conv
+// needs on v_mfma_f32_16x16x4_f32 (16 output channels = one tile, no padding waste) into LDS, and finishes with the
+// 144-tap second conv on the vector ALUs.
+//
+// MFMA operand layout (16x16x4, one block): A = weights, lane l holds W[co = l%16][k = l/16]; B = activations, lane l
+// holds X[k = l/16][px = l%16]; D: lane l holds rows co = 4*(l/16)+r (r = 0..3) of column px = l%16. A lane's B quad is
+// ONE ds_read_b128 of four consecutive channels of its pixel (k-group g = l/16 <-> channels 16*cb + 4g + i for the i-th
+// MFMA of the quad); the 18 weight quads (9 taps x 2 channel blocks) live in registers for the whole workgroup.
+#include "common.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int ST_TH = 14, ST_TW = 30;            // output tile
+constexpr int ST_MH = ST_TH + 2, ST_MW = ST_TW + 2;   // first-conv ("mid") region: 16 x 32 = 32 MFMA column tiles
+constexpr int ST_CIN = 32, ST_CMID = 16;
+constexpr int ST_PSTRIDE = 36;                   // floats per staged source pixel (32 + 4: conflict-free ds_read_b128)
+constexpr int ST_MSTRIDE = 20;                   // floats per mid pixel (16 + 4)
+constexpr int ST_PR = 12, ST_PC = 20;            // source patch capacity (rows, cols) -- checked on the host
+constexpr int ST_PATCH_FLOATS = (ST_PR * ST_PC + 1) * ST_PSTRIDE;    // + one all-zero pixel for the padding taps
+constexpr int ST_MID_FLOATS = ST_MH * ST_MW * ST_MSTRIDE;
+constexpr int ST_W2_FLOATS = 9 * 16;
+constexpr int ST_LDS_FLOATS = ST_PATCH_FLOATS + ST_MID_FLOATS + ST_W2_FLOATS;
+
+struct SegTailArgs {
+    const float* x;          // [B][Hs][Ws][in_cs]
+    const float4* w1p;       // packed [9 taps][2 blocks][64 lanes] float4
+    const float *b1, *bn_scale, *bn_shift;   // [16]
+    const float* w2;         // [16][3][3] (torch layout of a [1][16][3][3] weight)
+    float b2;
+    float* out;              // [B][H][W]
+    int H, W, Hs, Ws, in_cs, tiles_x, tiles_y;
+    float scale_h, scale_w;
+};
+
+__device__ __forceinline__ int src_index(int dst, float scale, int n_src) {
+    return min((int)floorf((float)dst * scale), n_src - 1);   // F.interpolate(mode="nearest")
+}
+
+__global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* patch = lds;
+    float* mid = lds + ST_PATCH_FLOATS;
+    float* w2s = mid + ST_MID_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
+    const int y0 = ty * ST_TH, x0 = tx * ST_TW;              // first output pixel of the tile
+    const int H = A.H, W = A.W;
+
+    // ---- source patch: the source pixels under up-sampled rows y0-2 .. y0+TH+1, cols x0-2 .. x0+TW+1 (clamped) --------
+    const int sr0 = src_index(max(y0 - 2, 0), A.scale_h, A.Hs), sr1 = src_index(min(y0 + ST_TH + 1, H - 1), A.scale_h, A.Hs);
+    const int sc0 = src_index(max(x0 - 2, 0), A.scale_w, A.Ws), sc1 = src_index(min(x0 + ST_TW + 1, W - 1), A.scale_w, A.Ws);
+    const int nr = sr1 - sr0 + 1, nc = sc1 - sc0 + 1;        // <= ST_PR, ST_PC (host-checked)
+    {
+        const int nf4 = nr * nc * (ST_CIN / 4);
+        for (int i = tid; i < nf4; i += 256) {
+            const int p = i >> 3, j = i & 7;
+            const int r = p / nc, cc = p - r * nc;
+            const float4 v = *(const float4*)(A.x + ((size_t)(b * A.Hs + sr0 + r) * A.Ws + sc0 + cc) * A.in_cs + 4 * j);
+            *(float4*)(patch + (size_t)(r * ST_PC + cc) * ST_PSTRIDE + 4 * j) = v;
+        }
+        if (tid < ST_PSTRIDE / 4) *(float4*)(patch + (size_t)ST_PR * ST_PC * ST_PSTRIDE + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < ST_W2_FLOATS) {                           // second-conv weights as [tap][16]
+            const int tap = tid >> 4, ci = tid & 15;
+            w2s[tid] = A.w2[ci * 9 + tap];
+        }
+    }
+    // weight quads of the first conv, resident in registers
+    float4 wq[18];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) wq[q] = A.w1p[q * 64 + lane];
+    float bias4[4], sc4[4], sh4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias4[r] = A.b1[4 * g + r], sc4[r] = A.bn_scale[4 * g + r], sh4[r] = A.bn_shift[4 * g + r];
+    __syncthreads();
+
+    // ---- first conv on the matrix cores: 32 column tiles of 16 pixels (one mid row half each), 8 per wave --------------
+    const int zero_off = ST_PR * ST_PC * ST_PSTRIDE;
+#pragma unroll 1
+    for (int t = wave; t < ST_MH * 2; t += 4) {
+        const int my = t >> 1, mx = (t & 1) * 16 + c;
+        const int Y = y0 - 1 + my, X = x0 - 1 + mx;          // up-sampled coordinates of this lane's mid pixel
+        int ro[3], co[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int yy = Y - 1 + d, xx = X - 1 + d;
+            ro[d] = (yy >= 0 && yy < H) ? (src_index(yy, A.scale_h, A.Hs) - sr0) * ST_PC : -1;
+            co[d] = (xx >= 0 && xx < W) ? (src_index(xx, A.scale_w, A.Ws) - sc0) : -1;
+        }
+        v4f acc = {bias4[0], bias4[1], bias4[2], bias4[3]};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int off = (ro[dy] >= 0 && co[dx] >= 0) ? (ro[dy] + co[dx]) * ST_PSTRIDE : zero_off;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const float4 bq = *(const float4*)(patch + off + 16 * cb + 4 * g);
+                    const float4 a = wq[(dy * 3 + dx) * 2 + cb];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc, 0, 0, 0);
+                }
+            }
+        // ELU -> BatchNorm; a mid pixel outside the image is the second conv's zero padding
+        const bool inside = Y >= 0 && Y < H && X >= 0 && X < W;
+        float4 o;
+        float* op = &o.x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float u = acc[r];
+            u = u > 0.0f ? u : expm1f(u);
+            op[r] = inside ? u * sc4[r] + sh4[r] : 0.0f;
+        }
+        *(float4*)(mid + (size_t)(my * ST_MW + mx) * ST_MSTRIDE + 4 * g) = o;
+    }
+    __syncthreads();
+
+    // ---- second conv (16 -> 1) on the vector ALUs: one output pixel per thread, two passes ------------------------------
+    for (int p = tid; p < ST_TH * ST_TW; p += 256) {
+        const int oy = p / ST_TW, ox = p - oy * ST_TW;
+        const int y = y0 + oy, x = x0 + ox;
+        if (y >= H || x >= W) continue;
+        float s = A.b2;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const float* m = mid + (size_t)((oy + dy) * ST_MW + ox + dx) * ST_MSTRIDE;
+                const float* w = w2s + (dy * 3 + dx) * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *(const float4*)(m + 4 * q), k = *(const float4*)(w + 4 * q);
+                    s = fmaf(v.x, k.x, s);
+                    s = fmaf(v.y, k.y, s);
+                    s = fmaf(v.z, k.z, s);
+                    s = fmaf(v.w, k.w, s);
+                }
+            }
+        A.out[((size_t)b * H + y) * W + x] = s;
+    }
+}
+
+// w1 [16][32][3][3] (torch) -> [tap][cb][lane = g*16 + co] float4 of channels 16cb + 4g + 0..3
+__global__ __launch_bounds__(256) void seg_tail_pack_kernel(const float* __restrict__ w1, float4* __restrict__ w1p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 18 * 64) return;
+    const int lane = i & 63, q = i >> 6, cb = q & 1, tap = q >> 1, g = lane >> 4, co = lane & 15;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = w1[((size_t)co * ST_CIN + 16 * cb + 4 * g + e) * 9 + tap];
+    w1p[i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ossid_seg_tail_packed_floats(void) { return 18 * 64 * 4; }
+
+int ossid_seg_tail_pack_weights(const float* w1, float* w1p, void* stream) {
+    if (!w1 || !w1p) return OSSID_EINVAL;
+    hipLaunchKernelGGL(seg_tail_pack_kernel, dim3(5), dim3(256), 0, (hipStream_t)stream, w1, (float4*)w1p);
+    return ossid_launch_status();
+}
+
+int ossid_seg_tail_fwd(const float* x, int batch, int src_height, int src_width, int in_channel_stride, int height,
+                       int width, const float* w1p, const float* b1, const float* post_scale, const float* post_shift,
+                       const float* w2, float b2, float* out, void* stream) {
+    if (batch < 0 || height <= 0 || width <= 0 || src_height <= 0 || src_width <= 0 || src_height > height ||
+        src_width > width || in_channel_stride < ST_CIN || (in_channel_stride % 4) || batch > 65535)
+        return OSSID_EINVAL;
+    if (batch == 0) return OSSID_OK;
+    if (!x || !w1p || !b1 || !post_scale || !post_shift || !w2 || !out) return OSSID_EINVAL;
+    SegTailArgs a;
+    a.x = x, a.w1p = (const float4*)w1p, a.b1 = b1, a.bn_scale = post_scale, a.bn_shift = post_shift, a.w2 = w2, a.b2 = b2;
+    a.out = out, a.H = height, a.W = width, a.Hs = src_height, a.Ws = src_width, a.in_cs = in_channel_stride;
+    a.scale_h = (float)src_height / (float)height, a.scale_w = (float)src_width / (float)width;
+    // the source footprint of an (TH+4) x (TW+4) up-sampled window must fit the staged patch
+    const int need_r = (int)((ST_TH + 3) * a.scale_h) + 2, need_c = (int)((ST_TW + 3) * a.scale_w) + 2;
+    if (need_r > ST_PR || need_c > ST_PC) return OSSID_EINVAL;
+    a.tiles_x = (width + ST_TW - 1) / ST_TW, a.tiles_y = (height + ST_TH - 1) / ST_TH;
+    const int lds = ST_LDS_FLOATS * 4;
+    if (hipFuncSetAttribute((const void*)seg_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return OSSID_ELAUNCH;
+    hipLaunchKernelGGL(seg_tail_kernel, dim3(a.tiles_x * a.tiles_y, batch), dim3(256), lds, (hipStream_t)stream, a);
+    return ossid_launch_status();
+}
+
+}  // extern "C"

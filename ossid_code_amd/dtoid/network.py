@@ -230,6 +230,7 @@ class FusedHead:
         self.dot3 = P(corr.corr_conv_dot3x3, corr.norm_corr_dot3x3, act=True)
         self.cf = P(corr.cf, corr.nf, act=True)
         self.seg = [P(getattr(corr, "s%d" % i), getattr(corr, "ns%d" % i), act=True) for i in (1, 2, 3, 4, 5)]
+        self.tail = ops.SegTail(corr.s5, corr.ns5, corr.seg_final)
         self.cls = [P(getattr(cls, "conv%d" % i), act=True) for i in (1, 2, 3, 4)] + [P(cls.output)]
         self.reg = [P(getattr(reg, "conv%d" % i), act=True) for i in (1, 2, 3, 4)] + [P(reg.output)]
         self.num_classes = cls.num_classes
@@ -252,8 +253,10 @@ class FusedHead:
         s = self.seg[0](x2)
         for i in (1, 2, 3):
             s = self.seg[i](s, size=(2 * s.shape[2], 2 * s.shape[3]))
-        s = self.seg[4](s, size=corr.img_size)
-        return x2, heat_map, corr.seg_final(s)
+        seg = self.tail(s, size=corr.img_size)        # up-sample + s5/ELU/ns5 + seg_final in one launch
+        if seg is None:
+            seg = corr.seg_final(self.seg[4](s, size=corr.img_size))
+        return x2, heat_map, seg
 
     @staticmethod
     def _trunk(convs, x):

@@ -151,6 +151,47 @@ class PackedConv:
         return self.run(x, B, H, W, out, src_hw=(Hs, Ws) if size is not None else (0, 0))
 
 
+class SegTail:
+    """The decoder's last two layers as ONE launch (csrc/segtail.hip): nearest up-sample to `size` -> conv3x3 32->16 ->
+    ELU -> eval BatchNorm -> conv3x3 16->1 (network.py:357-362: s5/ns5 after F.interpolate, then seg_final).
+    `__call__` returns None when the kernel does not take the shape (up-sampling ratio under ~1.5): the caller then
+    runs the two layers separately."""
+
+    def __init__(self, conv1, bn1, conv2):
+        w1 = conv1.weight.detach().float().contiguous()
+        w2 = conv2.weight.detach().float().contiguous()
+        _lib.require_cuda(w1)
+        if tuple(w1.shape) != (16, 32, 3, 3) or tuple(w2.shape) != (1, 16, 3, 3) or conv1.padding != (1, 1) or \
+                conv2.padding != (1, 1) or conv1.stride != (1, 1) or conv2.stride != (1, 1):
+            raise ValueError("SegTail is the 32->16->1 tail of the DTOID decoder")
+        self.w1p = torch.empty(_lib.fn("ossid_seg_tail_packed_floats")(), dtype=torch.float32, device=w1.device)
+        with torch.cuda.device(w1.device):
+            _lib.check(_lib.fn("ossid_seg_tail_pack_weights")(w1.data_ptr(), self.w1p.data_ptr(), _lib.stream()),
+                       "ossid_seg_tail_pack_weights")
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=w1.device)  # noqa: E731
+        self.b1 = z(16) if conv1.bias is None else conv1.bias.detach().float().contiguous()
+        self.scale, self.shift = _bn_affine(bn1)
+        self.w2 = w2.reshape(16, 9).contiguous()
+        self.b2 = 0.0 if conv2.bias is None else float(conv2.bias.detach().float().item())
+
+    def __call__(self, x, size):
+        _lib.require_cuda(x)
+        B, C, Hs, Ws = x.shape
+        H, W = int(size[0]), int(size[1])
+        if C != 32:
+            raise ValueError("expected 32 input channels, got %d" % C)
+        if -(-17 * Hs // H) + 2 > 12 or -(-33 * Ws // W) + 2 > 20 or Hs > H or Ws > W:   # the kernel's patch capacity
+            return None
+        x = x.float().contiguous(memory_format=torch.channels_last)
+        out = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.fn("ossid_seg_tail_fwd")(x.data_ptr(), B, Hs, Ws, 32, H, W, self.w1p.data_ptr(),
+                                               self.b1.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                                               self.w2.data_ptr(), self.b2, out.data_ptr(), _lib.stream())
+        _lib.check(rc, "ossid_seg_tail_fwd")
+        return out
+
+
 PackedConv3x3 = PackedConv   # the head's name for it
 
 

@@ -382,3 +382,30 @@ def test_head_training_on_hand_written_convs_matches_reference_golden(hiplib):
         ops.set_train_conv_impl("miopen")
     for k, v in out.items():
         assert close(v, G[k], rtol=2e-3, atol=2e-4), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Hs,Ws,H,W", [(2, 232, 312, 480, 640), (1, 29, 39, 61, 83), (3, 20, 24, 40, 48),
+                                         (1, 7, 9, 30, 31)])
+def test_seg_tail_fused_matches_torch(hiplib, B, Hs, Ws, H, W):
+    """up-sample + conv 32->16 + ELU + BN + conv 16->1 in one launch vs the same layers in torch (network.py:357-362);
+    covers ragged tiles (sizes that are no multiple of the 14 x 30 tile) and non-integer up-sampling ratios."""
+    import torch.nn.functional as F
+    torch.manual_seed(B * 1000 + H)
+    c1 = torch.nn.Conv2d(32, 16, 3, padding=1).cuda()
+    bn = torch.nn.BatchNorm2d(16).cuda().eval()
+    c2 = torch.nn.Conv2d(16, 1, 3, padding=1).cuda()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.2)
+    x = torch.randn(B, 32, Hs, Ws, device="cuda")
+    tail = ops.SegTail(c1, bn, c2)
+    got = tail(x, size=(H, W))
+    assert got is not None and got.shape == (B, 1, H, W)
+    with torch.no_grad():
+        want = c2(bn(F.elu(c1(F.interpolate(x, size=(H, W))))))
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-4), float((got - want).abs().max())
+    # a shape the fused kernel does not take (no up-sampling): the caller falls back
+    assert tail(x, size=(Hs, Ws)) is None
