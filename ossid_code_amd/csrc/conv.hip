@@ -21,7 +21,8 @@
 //     current chunk's MFMAs (issue-early / write-late), one barrier per chunk
 //   - output: each lane owns 4 consecutive channels per register quad -> 16-byte stores
 // Workgroup = 4 waves as WM (channel tiles) x WN (pixel groups); pixels are a flat run of the image (FLAT) or a
-// segment of one row (ROWSEG, wide images of the decoder).
+// segment of one row (ROWSEG = 1), or a 2-D tile of WN*NT rows x 32 columns (ROWSEG = 2: wide images of the decoder --
+// a third of the halo of a row segment, no ragged last segment worth speaking of).
 #include "common.h"
 
 namespace {
@@ -50,7 +51,7 @@ struct ConvArgs {
 // WK > 1 is for small problems (batch-1 backbone layers: a few dozen workgroups in all): the waves of a workgroup
 // share ONE output tile and each walks 1/WK of every channel chunk, the partial accumulators meet in LDS.
 // KCH = channels per LDS chunk (16, or 64 with split-K); NLD = float4 staged per thread per chunk; TAPS = 9 or 1.
-template <int WM, int WK, int NT, bool ROWSEG, int NLD, int TAPS, int KCH>
+template <int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
 __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     constexpr int WN = 4 / (WM * WK);
     constexpr int BPX = WN * NT * 32;
@@ -73,9 +74,11 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         const int L = blockIdx.x, P = A.gx * A.gz;
         int pt;
         if (A.gy <= 8 && (8 % A.gy) == 0) {
-            const int k = L & 7, R = 8 / A.gy;
+            // the R = 8/gy XCDs of a group each take a CONTIGUOUS run of pixel blocks: neighbouring blocks share halo
+            // rows (and, with the fused up-sampling, whole source rows), which then hit in that XCD's L2
+            const int k = L & 7, R = 8 / A.gy, per = (P + R - 1) / R;
             by = k % A.gy;
-            pt = (L >> 3) * R + k / A.gy;
+            pt = (L >> 3) < per ? (k / A.gy) * per + (L >> 3) : P;
         } else if ((A.gy & 7) == 0) {
             const int j = L >> 3;
             by = (L & 7) + 8 * (j / P);
@@ -95,6 +98,12 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     if (TAPS == 1) {
         PW = BPX;
         PR = 1;
+    } else if (ROWSEG == 2) {
+        const int segs = (W + 31) / 32;
+        y_first = (bx / segs) * (BPX / 32);
+        x_first = (bx % segs) * 32;
+        PW = 34;
+        PR = BPX / 32 + 2;
     } else if (ROWSEG) {
         const int segs = (W + BPX - 1) / BPX;
         y_first = bx / segs;
@@ -142,6 +151,10 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
             const int px = bx * BPX + j;
             pos0[t] = j;
             opx[t] = (px < HW) ? (b * HW + px) : -1;
+        } else if (ROWSEG == 2) {
+            const int row = wn * NT + t, yy = y_first + row, xx = x_first + c;
+            pos0[t] = row * PW + c;
+            opx[t] = (yy < H && xx < W) ? (b * HW + yy * W + xx) : -1;
         } else if (ROWSEG) {
             const int xx = x_first + j;
             pos0[t] = j;
@@ -340,7 +353,7 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
     wpk[i] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <int WM, int WK, int NT, bool ROWSEG, int NLD, int TAPS, int KCH>
+template <int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
 int launch_conv(ConvArgs a, int B, hipStream_t s) {
     constexpr int WN = 4 / (WM * WK), BPX = WN * NT * 32, F4 = KCH / 4;
     if (a.Cin % KCH) return OSSID_EINVAL;
@@ -349,6 +362,10 @@ int launch_conv(ConvArgs a, int B, hipStream_t s) {
         rows = 1;
         PW = BPX;
         nblk = (a.H * a.W + BPX - 1) / BPX;
+    } else if (ROWSEG == 2) {
+        rows = BPX / 32 + 2;
+        PW = 34;
+        nblk = ((a.H + BPX / 32 - 1) / (BPX / 32)) * ((a.W + 31) / 32);
     } else if (ROWSEG) {
         rows = 3;
         PW = BPX + 2;
@@ -441,7 +458,7 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
         return launch_conv<1, 4, 1, false, 6, 9, 32>(a, B, s);
     const bool rowseg = W > 100;
 #define OSSID_CONV(WM_, NT_)                                                                                         \
-    (rowseg ? launch_conv<WM_, 1, NT_, true, 8, 9, 16>(a, B, s) : launch_conv<WM_, 1, NT_, false, 8, 9, 16>(a, B, s))
+    (rowseg ? launch_conv<WM_, 1, NT_, 2, 8, 9, 16>(a, B, s) : launch_conv<WM_, 1, NT_, 0, 8, 9, 16>(a, B, s))
     // waves go to channel tiles while there are at least that many; the rest of the workgroup takes more pixels.
     // 128 pixels per workgroup unless that leaves the 256 CUs with under ~3 workgroups each. (256-pixel tiles with 13
     // staged float4 per thread were measured slower on the decoder's few-channel layers: their K is only 288-576, so
@@ -454,7 +471,7 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
         int best = 2;
         double best_cost = 1e30;
         for (int nt = 1; nt <= 4; ++nt) {
-            const long per = rowseg ? (long)H * ((W + nt * 32 - 1) / (nt * 32)) : ((long)H * W + nt * 32 - 1) / (nt * 32);
+            const long per = rowseg ? (long)((H + nt - 1) / nt) * ((W + 31) / 32) : ((long)H * W + nt * 32 - 1) / (nt * 32);
             const long nwg = per * B * groups;
             const double cost = (double)((nwg + 511) / 512) * (nt + 0.25);
             if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && nt > best)) best = nt, best_cost = cost;
@@ -467,7 +484,7 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
         }
     }
     if (tiles >= 2) return OSSID_CONV(2, 2);
-    return OSSID_CONV(1, 1);
+    return rowseg ? OSSID_CONV(1, 2) : OSSID_CONV(1, 1);   // wide image: 8 rows x 32 columns, each weight quad feeds two rows
 #undef OSSID_CONV
 }
 

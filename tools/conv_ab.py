@@ -42,6 +42,15 @@ def main():
         fl = 2.0 * B * h * w * co * ci * 9
         out[name] = {"ms": round(t * 1e3, 4), "TF": round(fl / t / 1e12, 1)}
         tot += t
+    from ossid_code_amd import _lib
+    if hasattr(ops, "SegTail") and hasattr(_lib.lib(), "ossid_seg_tail_fwd"):
+        c1, bn, c2 = torch.nn.Conv2d(32, 16, 3, padding=1).cuda(), torch.nn.BatchNorm2d(16).cuda().eval(), \
+            torch.nn.Conv2d(16, 1, 3, padding=1).cuda()
+        tail = ops.SegTail(c1, bn, c2)
+        x = torch.randn(a.nt, 32, 232, 312, device="cuda").contiguous(memory_format=torch.channels_last)
+        t = timeit(lambda: tail(x, size=(480, 640)))
+        fl = 2.0 * a.nt * 480 * 640 * 9 * (16 * 32 + 16)
+        out["tail 32->16->1 fused @480x640"] = {"ms": round(t * 1e3, 4), "TF": round(fl / t / 1e12, 1)}
     out["sum_ms"] = round(tot * 1e3, 3)
     print(json.dumps(out, indent=1))
 
