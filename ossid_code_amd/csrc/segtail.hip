@@ -9,7 +9,7 @@
 // tensor (21 x 480 x 640 x 16 floats) never exists: a workgroup owns a 14 x 30 pixel output tile, stages the SOURCE
 // pixels under its (18 x 34)-pixel up-sampled footprint once, runs the first conv for the 16 x 32 pixels the second conv
 // needs on v_mfma_f32_16x16x4_f32 (16 output channels = one tile, no padding waste) into LDS, and finishes with the
-// 144-tap second conv on the vector ALUs.
+// 144-tap second conv on the vector ALUs (weights as scalar operands).
 //
 // MFMA operand layout (16x16x4, one block): A = weights, lane l holds W[co = l%16][k = l/16]; B = activations, lane l
 // holds X[k = l/16][px = l%16]; D: lane l holds rows co = 4*(l/16)+r (r = 0..3) of column px = l%16. A lane's B quad is
@@ -29,8 +29,7 @@ constexpr int ST_MSTRIDE = 20;                   // floats per mid pixel (16 + 4
 constexpr int ST_PR = 12, ST_PC = 20;            // source patch capacity (rows, cols) -- checked on the host
 constexpr int ST_PATCH_FLOATS = (ST_PR * ST_PC + 1) * ST_PSTRIDE;    // + one all-zero pixel for the padding taps
 constexpr int ST_MID_FLOATS = ST_MH * ST_MW * ST_MSTRIDE;
-constexpr int ST_W2_FLOATS = 9 * 16;
-constexpr int ST_LDS_FLOATS = ST_PATCH_FLOATS + ST_MID_FLOATS + ST_W2_FLOATS;
+constexpr int ST_LDS_FLOATS = ST_PATCH_FLOATS + ST_MID_FLOATS + 144;
 
 struct SegTailArgs {
     const float* x;          // [B][Hs][Ws][in_cs]
@@ -43,11 +42,27 @@ struct SegTailArgs {
     float scale_h, scale_w;
 };
 
+// ELU(alpha = 1) without libm's expm1f (~40 instructions, four per lane per 72 MFMAs here): a degree-7 Taylor polynomial
+// near zero, where exp(x) - 1 would cancel, and the hardware exponential elsewhere; relative error < 1e-6.
+__device__ __forceinline__ float elu_fast(float x) {
+    const float xm = fminf(x, 0.0f);
+    float p = 1.0f / 5040.0f;
+    p = fmaf(p, xm, 1.0f / 720.0f);
+    p = fmaf(p, xm, 1.0f / 120.0f);
+    p = fmaf(p, xm, 1.0f / 24.0f);
+    p = fmaf(p, xm, 1.0f / 6.0f);
+    p = fmaf(p, xm, 0.5f);
+    p = fmaf(p, xm, 1.0f);
+    const float near0 = p * xm, far = __expf(xm) - 1.0f;
+    const float neg = xm > -0.35f ? near0 : far;
+    return x > 0.0f ? x : neg;
+}
+
 __device__ __forceinline__ int src_index(int dst, float scale, int n_src) {
     return min((int)floorf((float)dst * scale), n_src - 1);   // F.interpolate(mode="nearest")
 }
 
-__global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A) {
+__global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A, const float* __restrict__ w2) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* patch = lds;
     float* mid = lds + ST_PATCH_FLOATS;
@@ -70,11 +85,8 @@ __global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A) {
             const float4 v = *(const float4*)(A.x + ((size_t)(b * A.Hs + sr0 + r) * A.Ws + sc0 + cc) * A.in_cs + 4 * j);
             *(float4*)(patch + (size_t)(r * ST_PC + cc) * ST_PSTRIDE + 4 * j) = v;
         }
+        if (tid < 144) w2s[tid] = w2[(tid & 15) * 9 + (tid >> 4)];       // second-conv weights as [tap][16]
         if (tid < ST_PSTRIDE / 4) *(float4*)(patch + (size_t)ST_PR * ST_PC * ST_PSTRIDE + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < ST_W2_FLOATS) {                           // second-conv weights as [tap][16]
-            const int tap = tid >> 4, ci = tid & 15;
-            w2s[tid] = A.w2[ci * 9 + tap];
-        }
     }
     // weight quads of the first conv, resident in registers
     float4 wq[18];
@@ -85,51 +97,104 @@ __global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A) {
     for (int r = 0; r < 4; ++r) bias4[r] = A.b1[4 * g + r], sc4[r] = A.bn_scale[4 * g + r], sh4[r] = A.bn_shift[4 * g + r];
     __syncthreads();
 
-    // ---- first conv on the matrix cores: 32 column tiles of 16 pixels (one mid row half each), 8 per wave --------------
+    // ---- first conv on the matrix cores: 32 column tiles of 16 pixels (one mid row half each), 8 per wave, two at a time
+    // (two independent accumulator chains keep the matrix pipe fed past the 8-pass latency of a dependent MFMA)
     const int zero_off = ST_PR * ST_PC * ST_PSTRIDE;
-#pragma unroll 1
-    for (int t = wave; t < ST_MH * 2; t += 4) {
-        const int my = t >> 1, mx = (t & 1) * 16 + c;
-        const int Y = y0 - 1 + my, X = x0 - 1 + mx;          // up-sampled coordinates of this lane's mid pixel
-        int ro[3], co[3];
+    // per-lane column offsets of the 3 taps for the two possible mid columns of this lane (left / right half row):
+    // they do not depend on the tile, so they are worked out once (floats per pixel folded in; < 0 = zero padding)
+    int cofs[2][3];
+    bool cin[2];
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        const int X = x0 - 1 + hx * 16 + c;
+        cin[hx] = X >= 0 && X < W;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const int yy = Y - 1 + d, xx = X - 1 + d;
-            ro[d] = (yy >= 0 && yy < H) ? (src_index(yy, A.scale_h, A.Hs) - sr0) * ST_PC : -1;
-            co[d] = (xx >= 0 && xx < W) ? (src_index(xx, A.scale_w, A.Ws) - sc0) : -1;
+            const int xx = X - 1 + d;
+            cofs[hx][d] = (xx >= 0 && xx < W) ? (src_index(xx, A.scale_w, A.Ws) - sc0) * ST_PSTRIDE + 4 * g : -1;
         }
-        v4f acc = {bias4[0], bias4[1], bias4[2], bias4[3]};
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll 1
+#ifdef ST_ABL_NOMFMA
+    for (int t0 = wave_u; t0 < 0; t0 += 8) {
+#else
+    for (int t0 = wave_u; t0 < ST_MH * 2; t0 += 8) {
+#endif
+        int off[2][9];
+        bool inside[2];
+        int mpos[2];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int u = 0; u < 2; ++u) {
+            const int t = t0 + 4 * u;                        // wave-uniform
+            const int my = t >> 1, hx = t & 1;
+            const int Y = y0 - 1 + my;                       // up-sampled row of this tile's mid pixels
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int off = (ro[dy] >= 0 && co[dx] >= 0) ? (ro[dy] + co[dx]) * ST_PSTRIDE : zero_off;
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = Y - 1 + dy;
+                const int rofs = (yy >= 0 && yy < H) ? (src_index(yy, A.scale_h, A.Hs) - sr0) * (ST_PC * ST_PSTRIDE) : -1;
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    const float4 bq = *(const float4*)(patch + off + 16 * cb + 4 * g);
-                    const float4 a = wq[(dy * 3 + dx) * 2 + cb];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc, 0, 0, 0);
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int cf = hx ? cofs[1][dx] : cofs[0][dx];
+                    off[u][dy * 3 + dx] = (rofs >= 0 && cf >= 0) ? rofs + cf : zero_off + 4 * g;
                 }
             }
-        // ELU -> BatchNorm; a mid pixel outside the image is the second conv's zero padding
-        const bool inside = Y >= 0 && Y < H && X >= 0 && X < W;
-        float4 o;
-        float* op = &o.x;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float u = acc[r];
-            u = u > 0.0f ? u : expm1f(u);
-            op[r] = inside ? u * sc4[r] + sh4[r] : 0.0f;
+            inside[u] = Y >= 0 && Y < H && (hx ? cin[1] : cin[0]);
+            mpos[u] = (my * ST_MW + hx * 16 + c) * ST_MSTRIDE + 4 * g;
         }
-        *(float4*)(mid + (size_t)(my * ST_MW + mx) * ST_MSTRIDE + 4 * g) = o;
+        v4f acc0 = {bias4[0], bias4[1], bias4[2], bias4[3]}, acc1 = acc0;
+        // the B quads of step s+1 are read from LDS while step s's eight MFMAs run (pinned: left alone the compiler
+        // issues each read right in front of its first use and every step waits out the LDS latency)
+        float4 p0 = *(const float4*)(patch + off[0][0]), p1 = *(const float4*)(patch + off[1][0]);
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            const int tn = (st + 1) >> 1, cbn = (st + 1) & 1;
+            float4 n0 = p0, n1 = p1;
+            if (st + 1 < 18) {
+                n0 = *(const float4*)(patch + off[0][tn] + 16 * cbn);
+                n1 = *(const float4*)(patch + off[1][tn] + 16 * cbn);
+            }
+#ifndef ST_NOPIN
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            const float4 a = wq[st];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, p0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, p1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, p0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, p1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, p0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, p1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, p0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, p1.w, acc1, 0, 0, 0);
+#ifndef ST_NOPIN
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            p0 = n0, p1 = n1;
+        }
+        // ELU -> BatchNorm; a mid pixel outside the image is the second conv's zero padding
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const v4f acc = u ? acc1 : acc0;
+            float4 o;
+            float* op = &o.x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[r];
+                v = elu_fast(v);
+                op[r] = inside[u] ? v * sc4[r] + sh4[r] : 0.0f;
+            }
+            *(float4*)(mid + mpos[u]) = o;
+        }
     }
     __syncthreads();
 
+#ifndef ST_CONV2_SCALAR
     // ---- second conv (16 -> 1) on the vector ALUs: one output pixel per thread, two passes ------------------------------
+#ifdef ST_ABL_NOCONV2
+    for (int p = tid; p < 1; p += 256) {
+#else
     for (int p = tid; p < ST_TH * ST_TW; p += 256) {
+#endif
         const int oy = p / ST_TW, ox = p - oy * ST_TW;
         const int y = y0 + oy, x = x0 + ox;
         if (y >= H || x >= W) continue;
@@ -152,6 +217,40 @@ __global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A) {
         A.out[((size_t)b * H + y) * W + x] = s;
     }
 }
+#else
+    // ---- second conv (16 -> 1) on the vector ALUs: two vertically adjacent output pixels per thread (their 3x3 windows
+    // share two of three mid rows: 48 LDS reads for both instead of 72), weights through the scalar unit ----------------
+    {
+        const int p = tid;                                   // 7 row pairs x 30 columns = 210 threads
+        if (p < (ST_TH / 2) * ST_TW) {
+            const int oy = 2 * (p / ST_TW), ox = p % ST_TW;
+            float s0 = A.b2, s1 = A.b2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* m = mid + (size_t)((oy + r) * ST_MW + ox + dx) * ST_MSTRIDE;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *(const float4*)(m + 4 * q);
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int ci = 4 * q + e;
+                            if (r < 3) s0 = fmaf(vv[e], w2[ci * 9 + r * 3 + dx], s0);
+                            if (r > 0) s1 = fmaf(vv[e], w2[ci * 9 + (r - 1) * 3 + dx], s1);
+                        }
+                    }
+                }
+            const int y = y0 + oy, x = x0 + ox;
+            if (x < W) {
+                if (y < H) A.out[((size_t)b * H + y) * W + x] = s0;
+                if (y + 1 < H) A.out[((size_t)b * H + y + 1) * W + x] = s1;
+            }
+        }
+    }
+}
+#endif
 
 // w1 [16][32][3][3] (torch) -> [tap][cb][lane = g*16 + co] float4 of channels 16cb + 4g + 0..3
 __global__ __launch_bounds__(256) void seg_tail_pack_kernel(const float* __restrict__ w1, float4* __restrict__ w1p) {
@@ -195,7 +294,7 @@ int ossid_seg_tail_fwd(const float* x, int batch, int src_height, int src_width,
     const int lds = ST_LDS_FLOATS * 4;
     if (hipFuncSetAttribute((const void*)seg_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return OSSID_ELAUNCH;
-    hipLaunchKernelGGL(seg_tail_kernel, dim3(a.tiles_x * a.tiles_y, batch), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(seg_tail_kernel, dim3(a.tiles_x * a.tiles_y, batch), dim3(256), lds, (hipStream_t)stream, a, w2);
     return ossid_launch_status();
 }
 
