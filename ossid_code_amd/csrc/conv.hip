@@ -443,6 +443,8 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
     const bool small = plain_wgs < 160 && (Cin % 64) == 0;
     if (d->taps == 1) {   // no halo: the patch is just the pixel run
         if (small) return launch_conv<1, 4, 1, false, 2, 1, 64>(a, B, s);
+        // DenseNet's concatenated widths are multiples of 32, every other one not of 64: same split, 32-channel chunks
+        if (plain_wgs < 160 && (Cin % 32) == 0) return launch_conv<1, 4, 1, false, 1, 1, 32>(a, B, s);
         if (tiles >= 4)
             return px >= 128L * 512 ? launch_conv<4, 1, 4, false, 2, 1, 16>(a, B, s)
                                     : launch_conv<4, 1, 1, false, 1, 1, 16>(a, B, s);
