@@ -191,10 +191,13 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     float4 st[NLD];
     const int jch = 4 * (tid % F4);   // this thread always stages channels ci0 + jch .. +3 (256 % F4 == 0)
     auto stage_load = [&](int ci0) {
+        // a ragged LAST chunk (Cin no multiple of KCH) stages zeros for the channels past Cin; their weight quads are
+        // clamped to the last real one (quad_of), and 0 x w adds nothing
+        const bool chan_ok = ci0 + jch < A.Cin;
 #pragma unroll
         for (int e = 0; e < NLD; ++e)
-            st[e] = goff[e] >= 0 ? *(const float4*)(A.x + (size_t)goff[e] + ci0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (A.pre_scale) {   // BN(eval) (+ReLU) of the INPUT, applied to real pixels only: the zero halo stays zero
+            st[e] = (goff[e] >= 0 && chan_ok) ? *(const float4*)(A.x + (size_t)goff[e] + ci0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (A.pre_scale && chan_ok) {   // BN(eval) (+ReLU) of the INPUT, on real pixels only: the zero halo stays zero
             const float4 ps = *(const float4*)(A.pre_scale + ci0 + jch), pt = *(const float4*)(A.pre_shift + ci0 + jch);
 #pragma unroll
             for (int e = 0; e < NLD; ++e) {
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         return q < nq ? q : nq - 1;
     };
 
-    const int nchunks = A.Cin / KCH;
+    const int nchunks = (A.Cin + KCH - 1) / KCH;
     stage_load(0);
     stage_write(0);
     float4 cur[GQ], nxt[GQ];
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
 template <int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
 int launch_conv(ConvArgs a, int B, hipStream_t s) {
     constexpr int WN = 4 / (WM * WK), BPX = WN * NT * 32, F4 = KCH / 4;
-    if (a.Cin % KCH) return OSSID_EINVAL;
+    if (a.Cin % KCH && !(WK > 1 && a.Cin % 8 == 0)) return OSSID_EINVAL;   // the split-K variants take a ragged last chunk
     int rows, PW, nblk;
     if (TAPS == 1) {
         rows = 1;
@@ -440,18 +443,17 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
     // the reduction instead (64-channel chunks), which multiplies the workgroup count by up to 4 and cuts every wave's
     // MFMA chain -- the critical path of such a launch -- by 4.
     const long plain_wgs = (px + 63) / 64 * ((tiles + 3) / 4);
-    const bool small = plain_wgs < 160 && (Cin % 64) == 0;
     if (d->taps == 1) {   // no halo: the patch is just the pixel run
-        if (small) return launch_conv<1, 4, 1, false, 2, 1, 64>(a, B, s);
-        // DenseNet's concatenated widths are multiples of 32, every other one not of 64: same split, 32-channel chunks
-        if (plain_wgs < 160 && (Cin % 32) == 0) return launch_conv<1, 4, 1, false, 1, 1, 32>(a, B, s);
+        // small: under one workgroup per CU, so LDS is no constraint and the launch is a chain of memory latencies, one
+        // per chunk: 256-channel chunks (ragged last one: DenseNet's widths are multiples of 32), 64 channels per wave
+        if (plain_wgs < 160) return launch_conv<1, 4, 1, false, 8, 1, 256>(a, B, s);
         if (tiles >= 4)
             return px >= 128L * 512 ? launch_conv<4, 1, 4, false, 2, 1, 16>(a, B, s)
                                     : launch_conv<4, 1, 1, false, 1, 1, 16>(a, B, s);
         if (tiles >= 2) return launch_conv<2, 1, 2, false, 2, 1, 16>(a, B, s);
         return launch_conv<1, 1, 1, false, 2, 1, 16>(a, B, s);
     }
-    if (small) return launch_conv<1, 4, 1, true, 7, 9, 64>(a, B, s);     // row segments of 32 pixels
+    if (plain_wgs < 160) return launch_conv<1, 4, 1, true, 13, 9, 128>(a, B, s);   // row segments of 32 pixels, 128-channel chunks
     // medium problems on narrow images (the 29x39 head at n_t ~ 10 or batch 8: ~1 plain workgroup per CU, i.e. one or
     // two waves per SIMD and a ragged tail): one channel tile x 32 flat pixels per workgroup, reduction split over the
     // four waves in 32-channel chunks -> 8x as many, 4x shorter work items
