@@ -453,14 +453,20 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
         if (tiles >= 2) return launch_conv<2, 1, 2, false, 2, 1, 16>(a, B, s);
         return launch_conv<1, 1, 1, false, 2, 1, 16>(a, B, s);
     }
-    if (plain_wgs < 160) return launch_conv<1, 4, 1, true, 13, 9, 128>(a, B, s);   // row segments of 32 pixels, 128-channel chunks
+    const bool rowseg = W > 100;
+    // workgroups of the variant the rules below would pick on a wide image (2-D tiles of 8 / 4 / NT rows x 32 columns)
+    const long wide_wgs = !rowseg ? (1L << 40)
+                                  : (long)B * ((W + 31) / 32) * (tiles >= 4 ? (H + 1) / 2 * ((tiles + 3) / 4)
+                                                                            : tiles >= 2 ? (H + 3) / 4 : (H + 7) / 8);
+    // under one workgroup per CU either way: row segments of 32 pixels, one channel tile, the reduction split over the
+    // four waves in 128-channel chunks
+    if (plain_wgs < 160 || wide_wgs < 256) return launch_conv<1, 4, 1, true, 13, 9, 128>(a, B, s);
     // medium problems on narrow images (the 29x39 head at n_t ~ 10 or batch 8: ~1 plain workgroup per CU, i.e. one or
     // two waves per SIMD and a ragged tail): one channel tile x 32 flat pixels per workgroup, reduction split over the
     // four waves in 32-channel chunks -> 8x as many, 4x shorter work items
     const int rows32 = (32 + W - 2) / W + 3;                          // patch rows of a 32-pixel flat run
     if (plain_wgs < OSSID_MEDIUM_WGS && (Cin % 32) == 0 && (rows32 < H + 2 ? rows32 : H + 2) * (W + 2) * 8 <= 6 * 256)
         return launch_conv<1, 4, 1, false, 6, 9, 32>(a, B, s);
-    const bool rowseg = W > 100;
 #define OSSID_CONV(WM_, NT_)                                                                                         \
     (rowseg ? launch_conv<WM_, 1, NT_, 2, 8, 9, 16>(a, B, s) : launch_conv<WM_, 1, NT_, 0, 8, 9, 16>(a, B, s))
     // waves go to channel tiles while there are at least that many; the rest of the workgroup takes more pixels.
