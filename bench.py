@@ -166,7 +166,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL ("nccl") is the product path. OSSID_BENCH_BACKEND=gloo exists only to rehearse the multi-rank control
+        # flow on a box with fewer GPUs than ranks (ranks then share devices; the numbers mean nothing).
+        backend = os.environ.get("OSSID_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+            local %= max(1, torch.cuda.device_count())
     assert torch.cuda.is_available(), "bench.py measures the GPU path; no GPU is visible"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
