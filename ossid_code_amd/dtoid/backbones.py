@@ -31,6 +31,54 @@ class DenseLayer(nn.Module):
         return self.conv2(self.relu2(self.norm2(y)))
 
 
+DENSE_BLOCK_INPLACE_GRAD = True   # training: one resident feature buffer and one gradient buffer per dense block
+
+
+def _alias(buf, channels):
+    """The first `channels` channels of `buf` as a tensor with its OWN autograd version counter (a plain view would share
+    buf's, and the later in-place appends to other channels would invalidate what the layer saved for backward)."""
+    t = torch.empty(0, dtype=buf.dtype, device=buf.device)
+    t.set_(buf.untyped_storage(), buf.storage_offset(), (buf.shape[0], channels, buf.shape[2], buf.shape[3]), buf.stride())
+    return t
+
+
+class _DenseBlockFn(torch.autograd.Function):
+    """A dense block in training without torch.cat and without autograd's O(L^2) gradient accumulation.
+    Forward: every layer reads a channel-prefix alias of ONE [B, C_total, H, W] buffer and appends its 32 channels to it;
+    each layer's own little graph (BN-ReLU-conv-BN-ReLU-conv, ordinary autograd, same kernels as before) is kept.
+    Backward: one gradient buffer of the same shape; layers are replayed last to first, each adds its input gradient
+    onto the channel prefix in place - L strided adds instead of ~L^2/2 small ones (DenseNet-121 at batch 8: 1 364
+    elementwise launches, 6 ms of a 57 ms step). Parameter gradients accumulate into .grad as usual."""
+
+    @staticmethod
+    def forward(ctx, x, block):
+        B, C, H, W = x.shape
+        buf = x.new_empty(B, C + block.nlayers * block.growth, H, W)
+        buf[:, :C] = x
+        graphs, c = [], C
+        for layer in block.values():
+            with torch.enable_grad():
+                inp = _alias(buf, c).requires_grad_()
+                out = layer(inp)
+            buf[:, c:c + block.growth] = out.detach()
+            graphs.append((inp, out))
+            c += block.growth
+        ctx.graphs, ctx.cin, ctx.growth = graphs, C, block.growth
+        return buf
+
+    @staticmethod
+    def backward(ctx, gbuf):
+        g = gbuf.clone(memory_format=torch.contiguous_format)
+        c = ctx.cin + len(ctx.graphs) * ctx.growth
+        for inp, out in reversed(ctx.graphs):
+            c -= ctx.growth
+            torch.autograd.backward([out], [g[:, c:c + ctx.growth]])
+            g[:, :c] += inp.grad
+            inp.grad = None
+        ctx.graphs = None
+        return g[:, :ctx.cin], None
+
+
 class DenseBlock(nn.ModuleDict):
     def __init__(self, nlayers, cin, growth=32, bn_size=4):
         super().__init__()
@@ -40,6 +88,8 @@ class DenseBlock(nn.ModuleDict):
 
     def forward(self, x):
         if torch.is_grad_enabled() and x.requires_grad or self.training:
+            if DENSE_BLOCK_INPLACE_GRAD and torch.is_grad_enabled() and x.requires_grad and x.is_cuda:
+                return _DenseBlockFn.apply(x, self)
             feats = [x]
             for layer in self.values():
                 feats.append(layer(torch.cat(feats, 1)))

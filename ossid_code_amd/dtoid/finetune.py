@@ -61,6 +61,32 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
 
+    # ---- "scatter" protocol: backward with p.grad = None, then ONE multi-tensor copy into the flat buffer -------------
+    # With p.grad preset to a view of the flat buffer autograd ACCUMULATES (p.grad += g): one add kernel per parameter
+    # per step (~600 launches, 2.6 ms of the 57 ms step). With p.grad = None it hands over the freshly computed tensor
+    # at no cost, and torch._foreach_copy_ packs all of them into the flat buffer in a handful of launches.
+    def detach_grads(self):
+        for _, p in self.entries:
+            p.grad = None
+
+    def gather_grads(self):
+        if not hasattr(self, "_views"):
+            self._views = [self.grad[off:off + n].view_as(p) for (name, p), (off, n) in
+                           zip(self.entries, (self.offsets[name] for name, _ in self.entries))]
+        dst, src, missing = [], [], False
+        for (_, p), v in zip(self.entries, self._views):
+            if p.grad is None:
+                missing = True
+            else:
+                dst.append(v)
+                src.append(p.grad)
+        if missing:
+            self.grad.zero_()          # a parameter without a gradient this step contributes zero (rare: unused branches)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for (_, p), v in zip(self.entries, self._views):
+            p.grad = v
+
     def used_grad(self):
         return self.grad[: self.n_used]
 
@@ -138,17 +164,19 @@ class GraphedForwardBackward:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                flat.zero_grad()
+                flat.detach_grads()
                 model(self.static)["loss"].backward()
+                flat.gather_grads()
         torch.cuda.current_stream(dev).wait_stream(side)
         with torch.no_grad():
             for b, s0 in zip(model.buffers(), saved):
                 b.copy_(s0)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            flat.zero_grad()
+            flat.detach_grads()
             out = model(self.static)
             out["loss"].backward()
+            flat.gather_grads()
             self.loss = out["loss"].detach()
         flat.zero_grad()
 
@@ -176,8 +204,14 @@ def _finetune_step_eager(model, batch, optimizer, sync=None):
     """One finetune iteration on a batch already on the device; returns the detached loss."""
     out = model(batch)
     loss = out["loss"]
-    optimizer.zero_grad()
-    loss.backward()
+    flat = getattr(optimizer, "flat", None)
+    if flat is not None:               # FusedAMSGrad over FlatParams: gradients gathered by one multi-tensor copy
+        flat.detach_grads()
+        loss.backward()
+        flat.gather_grads()
+    else:
+        optimizer.zero_grad()
+        loss.backward()
     if sync is not None:
         sync.sync()
     optimizer.step()
