@@ -4,6 +4,7 @@ import os
 import socket
 import sys
 
+import numpy as np
 import torch
 import torch.multiprocessing as mp
 
@@ -165,3 +166,38 @@ def test_speculative_stream_gloo_world2_matches_sequential():
         assert committed == truth, rank
         assert rsets == sets, rank
     assert got[0][4] == got[1][4] and got[0][4] > 0           # some speculated frames were thrown away and re-issued
+
+
+def _top1_worker(rank, world, port, scores, q):
+    import torch.distributed as dist
+    from ossid_code_amd import parallel
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    out = []
+    for s in scores:
+        lo, hi = parallel.shard_hypotheses(len(s), rank, world)
+        out.append(parallel.reduce_top1(s[lo:hi], lo, dist))
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_within_frame_hypothesis_sharding_top1_matches_unsharded_argmax():
+    """Split a frame's hypotheses over 3 ranks, exchange 8 bytes per rank: same (max, argmax) as the unsharded array,
+    including ties (lowest index wins), fewer hypotheses than ranks, and an empty frame."""
+    import torch.multiprocessing as mp
+    from ossid_code_amd import parallel
+    rng = np.random.default_rng(0)
+    cases = [rng.normal(size=1000).astype(np.float32), np.array([1.0, 5.0, 5.0, 2.0, 5.0], np.float32),
+             np.array([3.0, 7.0], np.float32), np.zeros(0, np.float32), rng.normal(size=7).astype(np.float32)]
+    assert [parallel.shard_hypotheses(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_top1_worker, args=(r, 3, port, cases, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    want = [(float(s.max()), int(s.argmax())) if len(s) else (float("-inf"), -1) for s in cases]
+    for rank, out in got:
+        assert out == want, (rank, out, want)
