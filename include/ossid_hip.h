@@ -177,14 +177,14 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* desc_host, void* stream);
  *   out[b][y][x] = b2 + conv3x3_{16->1}( post( ELU( b1 + conv3x3_{32->16}( nearest_upsample(x -> [H][W]) ) ) ) )
  * x [B][src_height][src_width][in_channel_stride] channels-last (the first 32 channels are read); w1p =
  * ossid_seg_tail_pack_weights(w1 [16][32][3][3]); post = * post_scale[16] + post_shift[16] (eval-mode BatchNorm);
- * w2 [16][3][3] (the [1][16][3][3] weight); out [B][H][W]. Both convolutions zero-pad at the [H][W] border. The
+ * w2 [16][3][3] (the [1][16][3][3] weight); b2 [1] (device, may be NULL); out [B][H][W]. Both convolutions zero-pad at the [H][W] border. The
  * 16-channel full-resolution tensor is never materialised. Returns OSSID_EINVAL when the up-sampling ratio is
  * below ~1.5 (the source footprint of a tile would not fit the staged patch): run the two layers separately then. */
 size_t ossid_seg_tail_packed_floats(void);
 int ossid_seg_tail_pack_weights(const float* w1, float* w1p, void* stream);
 int ossid_seg_tail_fwd(const float* x, int batch, int src_height, int src_width, int in_channel_stride, int height,
                        int width, const float* w1p, const float* b1, const float* post_scale, const float* post_shift,
-                       const float* w2, float b2, float* out, void* stream);
+                       const float* w2, const float* b2, float* out, void* stream);
 
 /* D16  weight gradient of the 3x3 / stride 1 / pad 1 convolution (loss.backward() of the finetune step,
  * scripts/online_learning.py:670-672): dw[co][ci][ky][kx] (+)= sum_{b,y,x} dy[b][y][x][co] * x[b][y+ky-1][x+kx-1][ci].

@@ -59,7 +59,7 @@ _PROTOS = {
     "ossid_conv_nhwc_fwd": (_i, [_vp, _vp]),
     "ossid_seg_tail_packed_floats": (_sz, []),
     "ossid_seg_tail_pack_weights": (_i, [_vp, _vp, _vp]),
-    "ossid_seg_tail_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
+    "ossid_seg_tail_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_conv3x3_wgrad_splits": (_i, [_i, _i, _i, _i, _i]),
     "ossid_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ossid_conv3x3_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),

@@ -36,7 +36,7 @@ struct SegTailArgs {
     const float4* w1p;       // packed [9 taps][2 blocks][64 lanes] float4
     const float *b1, *bn_scale, *bn_shift;   // [16]
     const float* w2;         // [16][3][3] (torch layout of a [1][16][3][3] weight)
-    float b2;
+    const float* b2;         // [1] or NULL
     float* out;              // [B][H][W]
     int H, W, Hs, Ws, in_cs, tiles_x, tiles_y;
     float scale_h, scale_w;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A, c
         const int oy = p / ST_TW, ox = p - oy * ST_TW;
         const int y = y0 + oy, x = x0 + ox;
         if (y >= H || x >= W) continue;
-        float s = A.b2;
+        float s = A.b2 ? A.b2[0] : 0.0f;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A, c
         const int p = tid;                                   // 7 row pairs x 30 columns = 210 threads
         if (p < (ST_TH / 2) * ST_TW) {
             const int oy = 2 * (p / ST_TW), ox = p % ST_TW;
-            float s0 = A.b2, s1 = A.b2;
+            float s0 = A.b2 ? A.b2[0] : 0.0f, s1 = s0;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -277,7 +277,7 @@ int ossid_seg_tail_pack_weights(const float* w1, float* w1p, void* stream) {
 
 int ossid_seg_tail_fwd(const float* x, int batch, int src_height, int src_width, int in_channel_stride, int height,
                        int width, const float* w1p, const float* b1, const float* post_scale, const float* post_shift,
-                       const float* w2, float b2, float* out, void* stream) {
+                       const float* w2, const float* b2, float* out, void* stream) {
     if (batch < 0 || height <= 0 || width <= 0 || src_height <= 0 || src_width <= 0 || src_height > height ||
         src_width > width || in_channel_stride < ST_CIN || (in_channel_stride % 4) || batch > 65535)
         return OSSID_EINVAL;

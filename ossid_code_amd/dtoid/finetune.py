@@ -101,6 +101,7 @@ class FusedAMSGrad:
         self.exp_avg_sq = torch.zeros_like(self.exp_avg)
         self.max_exp_avg_sq = torch.zeros_like(self.exp_avg)
         self.step_count = 0
+        self._params = [p for _, p in flat.entries]
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
@@ -115,6 +116,9 @@ class FusedAMSGrad:
                                                self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                                                self.step_count, _lib.stream())
         _lib.check(rc, "ossid_amsgrad_step")
+        # the kernel wrote the parameters behind autograd's back: bump their version counters so that anything keyed on
+        # them (the packed test-time plans of dtoid.Network) notices the update
+        torch.autograd.graph.increment_version(self._params)
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,

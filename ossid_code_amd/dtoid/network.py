@@ -235,10 +235,16 @@ class FusedHead:
         self.reg = [P(getattr(reg, "conv%d" % i), act=True) for i in (1, 2, 3, 4)] + [P(reg.output)]
         self.num_classes = cls.num_classes
 
+    def refresh(self):
+        for pk in [self.dot, self.sub, self.dot3, self.cf, self.tail] + self.seg + self.cls + self.reg:
+            pk.refresh()
+
     @staticmethod
     def version_key(*mods):
-        return tuple(int(t._version) for m in mods for t in list(m.parameters()) + list(m.buffers())) + \
-            tuple(t.data_ptr() for m in mods for t in m.parameters())
+        """(storage identity, value versions): a change of the first means the parameters were re-homed (rebuild, and
+        drop captured graphs: they read the old addresses), of the second only that values changed (refresh in place)."""
+        return (tuple(t.data_ptr() for m in mods for t in m.parameters()),
+                tuple(int(t._version) for m in mods for t in list(m.parameters()) + list(m.buffers())))
 
     def correlation(self, image_feat, template_feat):
         corr = self.corr
@@ -296,6 +302,12 @@ class FusedBackbone:
             else:                                                # Transition: norm relu conv pool
                 self.stages.append(("trans", m, P(m.conv, pre_bn=m.norm, pre_relu=True)))
 
+    def refresh(self):
+        for kind, mod, packed in self.stages:
+            for pk in ([p for pair in packed for p in pair] if kind == "block" else [packed]):
+                pk.refresh()
+        self.final.refresh()
+
     def __call__(self, image, template_feat):
         ife = self.ife
         x0 = ife.backdense_0(image)
@@ -350,18 +362,26 @@ class Network(nn.Module):
     def _fused_backbone(self):
         key = FusedHead.version_key(self.image_feature_extractor)
         cached = self.__dict__.get("_fused_bb_cache")
-        if cached is None or cached[0] != key:
+        if cached is None or cached[0][0] != key[0]:
+            self.__dict__.pop("_graph_cache", None)
             cached = (key, FusedBackbone(self.image_feature_extractor))
-            self.__dict__["_fused_bb_cache"] = cached
+        elif cached[0] != key:           # parameters changed (finetune): re-pack in place, graphs stay valid
+            cached[1].refresh()
+            cached = (key, cached[1])
+        self.__dict__["_fused_bb_cache"] = cached
         return cached[1]
 
     def _fused_head(self):
         mods = (self.correlation_model, self.classification, self.regression)
         key = FusedHead.version_key(*mods)
         cached = self.__dict__.get("_fused_cache")
-        if cached is None or cached[0] != key:
+        if cached is None or cached[0][0] != key[0]:
+            self.__dict__.pop("_graph_cache", None)
             cached = (key, FusedHead(*mods))
-            self.__dict__["_fused_cache"] = cached
+        elif cached[0] != key:
+            cached[1].refresh()
+            cached = (key, cached[1])
+        self.__dict__["_fused_cache"] = cached
         return cached[1]
 
     def load(self, path):

@@ -113,14 +113,30 @@ class PackedConv:
         self.taps = k[0] * k[1]
         n = _lib.fn("ossid_conv_packed_floats")(self.cout, self.cin, self.taps)
         self.wpk = torch.empty(n, dtype=torch.float32, device=w.device)
+        self.bias = None if conv.bias is None else torch.empty_like(conv.bias, dtype=torch.float32)
+        self.act = 1 if act else 0
+        mk = lambda m: (None, None) if m is None else tuple(torch.empty_like(t) for t in _bn_affine(m))  # noqa: E731
+        self.scale, self.shift = mk(bn)
+        self.pre_scale, self.pre_shift = mk(pre_bn)
+        self.pre_relu = 1 if pre_relu else 0
+        self._src = (conv, bn, pre_bn)
+        self.refresh()
+
+    def refresh(self):
+        """(Re)read the source modules INTO THE SAME device buffers: a captured hipGraph that launches this layer stays
+        valid across parameter updates (the online loop finetunes the detector every few frames)."""
+        conv, bn, pre_bn = self._src
+        w = conv.weight.detach().float().contiguous()
         with torch.cuda.device(w.device):
             _lib.check(_lib.fn("ossid_conv_pack_weights")(w.data_ptr(), self.cout, self.cin, self.taps,
                                                           self.wpk.data_ptr(), _lib.stream()), "ossid_conv_pack_weights")
-        self.bias = None if conv.bias is None else conv.bias.detach().float().contiguous()
-        self.act = 1 if act else 0
-        self.scale, self.shift = _bn_affine(bn) if bn is not None else (None, None)
-        self.pre_scale, self.pre_shift = _bn_affine(pre_bn) if pre_bn is not None else (None, None)
-        self.pre_relu = 1 if pre_relu else 0
+        if self.bias is not None:
+            self.bias.copy_(conv.bias.detach())
+        for mod, sc, sh in ((bn, self.scale, self.shift), (pre_bn, self.pre_scale, self.pre_shift)):
+            if mod is not None:
+                a, b = _bn_affine(mod)
+                sc.copy_(a)
+                sh.copy_(b)
 
     def run(self, x_nhwc, B, H, W, out_nhwc, in_cs=0, out_cs=0, out_coff=0, src_hw=(0, 0)):
         """Raw call on physical [B][H][W][C] buffers (tensors only provide pointers)."""
@@ -165,14 +181,26 @@ class SegTail:
                 conv2.padding != (1, 1) or conv1.stride != (1, 1) or conv2.stride != (1, 1):
             raise ValueError("SegTail is the 32->16->1 tail of the DTOID decoder")
         self.w1p = torch.empty(_lib.fn("ossid_seg_tail_packed_floats")(), dtype=torch.float32, device=w1.device)
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=w1.device)  # noqa: E731
+        self.b1, self.scale, self.shift, self.w2, self.b2 = z(16), z(16), z(16), torch.empty(16, 9, device=w1.device), z(1)
+        self._src = (conv1, bn1, conv2)
+        self.refresh()
+
+    def refresh(self):
+        """Re-read the three source modules into the same device buffers (see PackedConv.refresh)."""
+        conv1, bn1, conv2 = self._src
+        w1 = conv1.weight.detach().float().contiguous()
         with torch.cuda.device(w1.device):
             _lib.check(_lib.fn("ossid_seg_tail_pack_weights")(w1.data_ptr(), self.w1p.data_ptr(), _lib.stream()),
                        "ossid_seg_tail_pack_weights")
-        z = lambda n: torch.zeros(n, dtype=torch.float32, device=w1.device)  # noqa: E731
-        self.b1 = z(16) if conv1.bias is None else conv1.bias.detach().float().contiguous()
-        self.scale, self.shift = _bn_affine(bn1)
-        self.w2 = w2.reshape(16, 9).contiguous()
-        self.b2 = 0.0 if conv2.bias is None else float(conv2.bias.detach().float().item())
+        if conv1.bias is not None:
+            self.b1.copy_(conv1.bias.detach())
+        a, b = _bn_affine(bn1)
+        self.scale.copy_(a)
+        self.shift.copy_(b)
+        self.w2.copy_(conv2.weight.detach().float().reshape(16, 9))
+        if conv2.bias is not None:
+            self.b2.copy_(conv2.bias.detach().reshape(1))
 
     def __call__(self, x, size):
         _lib.require_cuda(x)
@@ -187,7 +215,7 @@ class SegTail:
         with torch.cuda.device(x.device):
             rc = _lib.fn("ossid_seg_tail_fwd")(x.data_ptr(), B, Hs, Ws, 32, H, W, self.w1p.data_ptr(),
                                                self.b1.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
-                                               self.w2.data_ptr(), self.b2, out.data_ptr(), _lib.stream())
+                                               self.w2.data_ptr(), self.b2.data_ptr(), out.data_ptr(), _lib.stream())
         _lib.check(rc, "ossid_seg_tail_fwd")
         return out
 

@@ -218,7 +218,7 @@ def test_fused_head_matches_module_path(hiplib):
         net.classification.conv1.weight.mul_(1.5)
         cls2r = net.classification(x2r)[0]
         cls2 = net._fused_head().classification(x2)
-    assert net._fused_head() is not fused and rel(cls2, cls2r) < 1e-4 and rel(cls2, cls) > 1e-3
+    assert net._fused_head() is fused and rel(cls2, cls2r) < 1e-4 and rel(cls2, cls) > 1e-3
     # and the whole test-time call runs on it
     img = torch.rand(1, 3, 480, 640, device="cuda")
     tm = torch.rand(5, 4, 124, 124, device="cuda")
@@ -409,3 +409,48 @@ def test_seg_tail_fused_matches_torch(hiplib, B, Hs, Ws, H, W):
     assert torch.allclose(got, want, rtol=1e-4, atol=1e-4), float((got - want).abs().max())
     # a shape the fused kernel does not take (no up-sampling): the caller falls back
     assert tail(x, size=(Hs, Ws)) is None
+
+
+@pytest.mark.gpu
+def test_graphed_test_time_path_follows_a_finetune_step(hiplib):
+    """The packed plans and the captured hipGraph must see parameter updates made by the fused optimizer (a raw kernel on
+    the flat buffer): detect, take finetune steps, detect again == a fresh network loaded with the updated weights."""
+    cfg = dtoid.DtoidConfig()
+    torch.manual_seed(3)
+    m = dtoid.DtoidNet(cfg).cuda().eval()
+    with torch.no_grad():   # non-degenerate outputs (the reference zero-initialises the output layers)
+        for conv in (m.model.classification.output, m.model.regression.output, m.model.correlation_model.seg_final):
+            conv.weight.normal_(0, 0.01)
+    flat = finetune.FlatParams(m)
+    opt = finetune.FusedAMSGrad(flat, lr=1e-3)
+    g = torch.Generator().manual_seed(5)
+    test = {"img": torch.rand(1, 3, 480, 640, generator=g).cuda(), "obj_id": torch.tensor([1]),
+            "limg": torch.rand(1, 3, 3, 124, 124, generator=g).cuda(),
+            "lmask": (torch.rand(1, 3, 1, 124, 124, generator=g) > 0.5).float().cuda()}
+    net = m.model
+
+    def dense():
+        m.clearCache()
+        local, glob = m._template_features(test, 1, torch.device("cuda", 0))
+        from ossid_code_amd.dtoid.model import normalizeImageRange
+        outs = net._graphed_dense(normalizeImageRange(test["img"]), local, glob[0])
+        return [o.clone() for o in outs[:4]]
+    before = dense()
+    n_graphs = len(net.__dict__["_graph_cache"])
+    b = _batch(cfg, 2, "cuda")
+    m.train()
+    for _ in range(2):
+        finetune.finetune_step(m, b, opt)
+    m.eval()
+    after = dense()
+    assert len(net.__dict__["_graph_cache"]) == n_graphs            # same graph, re-packed weights
+    assert not torch.allclose(before[0], after[0])
+    fresh = dtoid.DtoidNet(cfg).cuda().eval()
+    fresh.load_state_dict(m.state_dict())
+    fnet = fresh.model
+    fnet.use_graph = False
+    from ossid_code_amd.dtoid.model import normalizeImageRange
+    local, glob = fresh._template_features(test, 1, torch.device("cuda", 0))
+    want = fnet._dense_all_templates(normalizeImageRange(test["img"]), local, glob[0])
+    for a, w in zip(after, want[:4]):
+        assert torch.allclose(a, w, rtol=1e-4, atol=1e-5), float((a - w).abs().max())
