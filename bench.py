@@ -119,6 +119,24 @@ def dtoid_leg(a, dev, dist, world):
             "limg": torch.rand(1, nt, 3, 124, 124, generator=g).to(dev),
             "lmask": (torch.rand(1, nt, 1, 124, 124, generator=g) > 0.5).float().to(dev)}
     t_fwd = timed(lambda: m.forwardTestTime(test), 3, 10)
+    cpu_fwd = None
+    if dist is None and not a.no_cpu_baseline:
+        # the same network through torch's CPU kernels (the nn.Module path of this build = the reference's structure),
+        # on a bounded sample: 1 image x 2 templates (0.13 TFLOP), all host cores
+        torch.manual_seed(0)
+        mc = dtoid.DtoidNet(cfg).eval()
+        tc = {"img": test["img"].cpu(), "obj_id": torch.tensor([1]), "limg": test["limg"][:, :2].cpu(),
+              "lmask": test["lmask"][:, :2].cpu()}
+        from oracle import dtoid_oracle     # the checker's CPU restatements of the three HIP ops (baseline leg only)
+        with dtoid_oracle.cpu_ops():
+            mc.forwardTestTime(tc)
+            t0 = time.perf_counter()
+            mc.forwardTestTime(tc)
+            t_cpu = time.perf_counter() - t0
+        cpu_fwd = {"value": 1.0 / t_cpu, "unit": "img/s at n_t = 2", "cores": torch.get_num_threads(), "kind": "port",
+                   "sample": "1 image x 2 local templates (131.6 GFLOP) through torch CPU kernels: %.2f s, %.3f TFLOP/s"
+                             % (t_cpu, (39.7e9 + 46.0e9 * 2) / t_cpu / 1e12)}
+        del mc
     flat = finetune.FlatParams(m)
     opt = finetune.FusedAMSGrad(flat, lr=1e-4, weight_decay=1e-6)
     sync = finetune.GradSync(flat) if dist is not None else None
@@ -147,7 +165,13 @@ def dtoid_leg(a, dev, dist, world):
     return {"forward": {"metric": "DTOID imgs/sec", "value": world / t_fwd, "unit": "img/s", "ms_per_image": 1e3 * t_fwd,
                         "config": "forward_all_templates, 1 image x %d local templates per rank, 480x640, topk 500, f32; "
                                   "hand-written MFMA conv head + hipGraph" % nt,
-                        "tflops": world * (39.7e9 + 46.0e9 * nt) / t_fwd / 1e12},
+                        "tflops": world * (39.7e9 + 46.0e9 * nt) / t_fwd / 1e12,
+                        "roofline": {"bound": "mfma", "achieved": (39.7e9 + 46.0e9 * nt) / t_fwd / 1e12,
+                                     "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": (39.7e9 + 46.0e9 * nt) / t_fwd / 1e12 / PEAK_F32_MATRIX_TFLOPS,
+                                     "note": "whole frame incl. top-k / NMS / host latency; per-layer rates in "
+                                             "profiles/r01_e_conv_layers.json"},
+                        "cpu_baseline": cpu_fwd},
             "finetune": {"metric": "DTOID finetune samples/sec", "value": world * B / t_ft, "unit": "sample/s",
                          "ms_per_step": 1e3 * t_ft, "ms_per_step_eager": 1e3 * t_ft_eager,
                          "ms_per_step_head_convs_hand_written": 1e3 * t_ft_hip, "global_batch": world * B,
