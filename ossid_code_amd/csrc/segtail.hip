@@ -9,7 +9,7 @@
 // tensor (21 x 480 x 640 x 16 floats) never exists: a workgroup owns a 14 x 30 pixel output tile, stages the SOURCE
 // pixels under its (18 x 34)-pixel up-sampled footprint once, runs the first conv for the 16 x 32 pixels the second conv
 // needs on v_mfma_f32_16x16x4_f32 (16 output channels = one tile, no padding waste) into LDS, and finishes with the
-// 144-tap second conv on the vector ALUs (weights as scalar operands).
+// 144-tap second conv on the vector ALUs (weights broadcast from LDS).
 //
 // MFMA operand layout (16x16x4, one block): A = weights, lane l holds W[co = l%16][k = l/16]; B = activations, lane l
 // holds X[k = l/16][px = l%16]; D: lane l holds rows co = 4*(l/16)+r (r = 0..3) of column px = l%16. A lane's B quad is
@@ -154,9 +154,7 @@ __global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A, c
                 n0 = *(const float4*)(patch + off[0][tn] + 16 * cbn);
                 n1 = *(const float4*)(patch + off[1][tn] + 16 * cbn);
             }
-#ifndef ST_NOPIN
             __builtin_amdgcn_sched_barrier(0);
-#endif
             const float4 a = wq[st];
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, p0.x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, p1.x, acc1, 0, 0, 0);
@@ -166,9 +164,7 @@ __global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A, c
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, p1.z, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, p0.w, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, p1.w, acc1, 0, 0, 0);
-#ifndef ST_NOPIN
             __builtin_amdgcn_sched_barrier(0);
-#endif
             p0 = n0, p1 = n1;
         }
         // ELU -> BatchNorm; a mid pixel outside the image is the second conv's zero padding
@@ -188,8 +184,8 @@ __global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A, c
     }
     __syncthreads();
 
-#ifndef ST_CONV2_SCALAR
-    // ---- second conv (16 -> 1) on the vector ALUs: one output pixel per thread, two passes ------------------------------
+    // ---- second conv (16 -> 1) on the vector ALUs: one output pixel per thread, two passes; weights broadcast from LDS
+    // (measured alternatives: weights through scalar loads, two rows per thread -- both slower) ---------------------------
 #ifdef ST_ABL_NOCONV2
     for (int p = tid; p < 1; p += 256) {
 #else
@@ -217,40 +213,6 @@ __global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A, c
         A.out[((size_t)b * H + y) * W + x] = s;
     }
 }
-#else
-    // ---- second conv (16 -> 1) on the vector ALUs: two vertically adjacent output pixels per thread (their 3x3 windows
-    // share two of three mid rows: 48 LDS reads for both instead of 72), weights through the scalar unit ----------------
-    {
-        const int p = tid;                                   // 7 row pairs x 30 columns = 210 threads
-        if (p < (ST_TH / 2) * ST_TW) {
-            const int oy = 2 * (p / ST_TW), ox = p % ST_TW;
-            float s0 = A.b2 ? A.b2[0] : 0.0f, s1 = s0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float* m = mid + (size_t)((oy + r) * ST_MW + ox + dx) * ST_MSTRIDE;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 v = *(const float4*)(m + 4 * q);
-                        const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int ci = 4 * q + e;
-                            if (r < 3) s0 = fmaf(vv[e], w2[ci * 9 + r * 3 + dx], s0);
-                            if (r > 0) s1 = fmaf(vv[e], w2[ci * 9 + (r - 1) * 3 + dx], s1);
-                        }
-                    }
-                }
-            const int y = y0 + oy, x = x0 + ox;
-            if (x < W) {
-                if (y < H) A.out[((size_t)b * H + y) * W + x] = s0;
-                if (y + 1 < H) A.out[((size_t)b * H + y + 1) * W + x] = s1;
-            }
-        }
-    }
-}
-#endif
 
 // w1 [16][32][3][3] (torch) -> [tap][cb][lane = g*16 + co] float4 of channels 16cb + 4g + 0..3
 __global__ __launch_bounds__(256) void seg_tail_pack_kernel(const float* __restrict__ w1, float4* __restrict__ w1p) {
