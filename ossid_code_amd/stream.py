@@ -98,7 +98,7 @@ class OnlineStream:
         data = {k: frame[k] for k in ("img", "depth", "cam_K", "model_points", "model_normals", "model_colors",
                                       "pose_hypos")}
         data["pp_err"] = pp_err
-        poses, scores, errs, uv = self._timed("score", lambda: networkInference(self.scorer, self.dataset, data))
+        poses, scores, errs, _uv = self._timed("score", lambda: networkInference(self.scorer, self.dataset, data))
         best = int(scores.argmax())
         pred_pose, pred_score = poses[best], float(scores.max())
         H, W = frame["depth"].shape
@@ -106,7 +106,7 @@ class OnlineStream:
         def pseudo():
             pred_depth = pipeline.render_depth_points(pred_pose, frame["model_points"], frame["cam_K"], (H, W), radius=1)
             return pipeline.visibility_and_iou(frame["depth"], pred_depth)[:2]
-        pred_mask, pred_mask_visib = self._timed("pseudo_label", pseudo)
+        _pred_mask, pred_mask_visib = self._timed("pseudo_label", pseudo)
         confident = pred_score > self.threshold
         sample = None
         if confident:
@@ -148,9 +148,7 @@ def run_speculative(frames, process_fn, finetune_fn, finetune_interval, dist=Non
         confident, sample = process_fn(frames[mine]) if mine is not None else (False, None)
         if world > 1:
             flag = torch.tensor([1 if confident else 0], dtype=torch.int32)
-            dev = next((v.device for v in (sample or {}).values() if torch.is_tensor(v)), None)
-            backend_cuda = dist.get_backend(group) == "nccl"
-            if backend_cuda:
+            if dist.get_backend(group) == "nccl":
                 flag = flag.cuda()
             flags = [torch.zeros_like(flag) for _ in range(world)]
             dist.all_gather(flags, flag, group=group)

@@ -48,7 +48,6 @@ def main():
     for s, e, n in step:
         short = re.sub(r"<.*", "", n)[:90]
         if "elementwise" in short or "reduce_kernel" in short:      # keep the functor: it says which torch op this is
-            m = re.search(r"at::native::(?:\(anonymous namespace\)::)?(\w+(?:<[^<>]*>)?)(?:\(|,|>| )", n[n.find("<"):])
             inner = re.findall(r"at::native::(?:\(anonymous namespace\)::)?([A-Za-z_0-9]+)", n[n.find("<"):])
             short = short.split("::")[-1] + " : " + ",".join(inner[:3])
         by[short] += (e - s) * 1e-6
