@@ -162,6 +162,12 @@ def test_full_network_shapes_and_finetune_step_480x640(hiplib):
     (1, 128, 64, 116, 156),    # decoder s3 (ROWSEG, WM=2)
     (1, 32, 16, 480, 640),     # decoder s5 (ROWSEG, single channel tile)
     (2, 16, 32, 5, 7),         # tiny image, one chunk
+    (21, 64, 32, 37, 150),     # 2-D pixel tiles with ragged rows and columns, XCD-contiguous block runs
+    (4, 64, 640, 29, 39),      # 20 channel tiles = 5 groups: the plain (non XCD-aware) block mapping
+    (3, 64, 1024, 29, 39),     # 8 channel-tile groups: one per XCD
+    (64, 64, 256, 29, 39),     # many workgroups: the round-aware choice goes to the widest pixel tile
+    (5, 64, 128, 29, 39),      # ... and here to a narrow one
+    (1, 48, 32, 30, 40),       # split-K small path with a ragged last 128-channel chunk
     (1, 64, 32, 1, 1),         # degenerate spatial size
 ])
 def test_conv3x3_mfma_matches_torch(hiplib, B, Cin, Cout, H, W):
