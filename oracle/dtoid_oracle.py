@@ -22,7 +22,7 @@ def dw_xcorr(x, kernel):
     return y.view(B, C, y.size(2), y.size(3))
 
 
-def nms(boxes, scores, thr):
+def nms(boxes, scores, thr, sorted_desc=False):
     """torchvision.ops.nms (network.py:563): greedy, by decreasing score, suppress IoU > thr."""
     b = boxes.detach().cpu().double().numpy()
     order = torch.sort(scores.detach().cpu(), descending=True, stable=True).indices.numpy()

@@ -484,7 +484,7 @@ class Network(nn.Module):
             max_score, max_id = torch.topk(cls_all.reshape(-1, 2)[:, 1], k)      # class 1 = object
             anchors_pred = boxes[max_id]
             obj_indices = (max_id // A).to(torch.float32)[:, None]                # which local template fired
-            keep = ops.nms(anchors_pred, max_score, 0.5)[:topk]
+            keep = ops.nms(anchors_pred, max_score, 0.5, sorted_desc=True)[:topk]   # topk returns them sorted
             max_score, anchors_pred, obj_indices = max_score[keep], anchors_pred[keep], obj_indices[keep]
             tid = obj_indices.reshape(-1).long()
             return [max_score, anchors_pred, obj_indices, seg_all[:, 0][tid], heat_all[:, 0][tid]]

@@ -59,14 +59,18 @@ def dw_xcorr(x, kernel):
     return _DwXcorr.apply(x, kernel)
 
 
-def nms(boxes, scores, iou_threshold):
-    """torchvision.ops.nms semantics: indices of the kept boxes, by decreasing score."""
+def nms(boxes, scores, iou_threshold, sorted_desc=False):
+    """torchvision.ops.nms semantics: indices of the kept boxes, by decreasing score. sorted_desc=True: the caller
+    guarantees scores are already in decreasing order (the output of torch.topk) and the sort + gather are skipped."""
     _lib.require_cuda(boxes, scores)
     n = int(boxes.shape[0])
     if n == 0:
         return torch.zeros(0, dtype=torch.long, device=boxes.device)
-    order = torch.sort(scores, descending=True, stable=True).indices
-    sb = boxes.float()[order].contiguous()
+    if sorted_desc:
+        order, sb = None, boxes.float().contiguous()
+    else:
+        order = torch.sort(scores, descending=True, stable=True).indices
+        sb = boxes.float()[order].contiguous()
     keep = torch.empty(n, dtype=torch.int32, device=boxes.device)
     nkeep = torch.empty(1, dtype=torch.int32, device=boxes.device)
     nbytes = _lib.fn("ossid_nms_workspace_bytes")(n)
@@ -74,7 +78,8 @@ def nms(boxes, scores, iou_threshold):
     with torch.cuda.device(boxes.device):
         _lib.check(_lib.fn("ossid_nms")(sb.data_ptr(), n, float(iou_threshold), ws.data_ptr(), nbytes, keep.data_ptr(),
                                         nkeep.data_ptr(), _lib.stream()), "ossid_nms")
-    return order[keep[: int(nkeep.item())].long()]
+    kept = keep[: int(nkeep.item())].long()
+    return kept if order is None else order[kept]
 
 
 def decode_clip_boxes(anchors, deltas, img_w, img_h):
