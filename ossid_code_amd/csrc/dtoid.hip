@@ -131,6 +131,30 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
     if (threadIdx.x == 0) *nkeep = cnt;
 }
 
+// Up to 1 024 boxes (words <= 16: the test-time case, top-1000 candidates): the whole suppression matrix is staged in LDS
+// (<= 128 KB) by 256 threads, then ONE wave runs the greedy scan with the removed-set in registers (lane w owns word
+// w) -- no barrier and no global-memory round trip per kept box (the general kernel pays ~1 us for each).
+__global__ __launch_bounds__(256) void nms_scan_small_kernel(const unsigned long long* __restrict__ mask, int n, int words,
+                                                             int* __restrict__ keep, int* __restrict__ nkeep) {
+    extern __shared__ unsigned long long lmask[];
+    const int total = n * words;
+    for (int i = threadIdx.x; i < total; i += 256) lmask[i] = mask[i];
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    unsigned long long remv = 0;                     // word `lane` of the removed set (lanes >= words stay 0)
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        const unsigned long long wv = __shfl(remv, i >> 6);
+        if (!((wv >> (i & 63)) & 1ull)) {            // wave-uniform
+            if (lane == 0) keep[cnt] = i;
+            ++cnt;
+            if (lane < words) remv |= lmask[i * words + lane];
+        }
+    }
+    if (lane == 0) *nkeep = cnt;
+}
+
 // ---- anchor decode + clip ------------------------------------------------------------------------------------------
 // anchors [A][4] shared by every batch row, deltas [R][A][4] -> boxes [R][A][4]; std (.1,.1,.2,.2), mean 0.
 __global__ __launch_bounds__(256) void decode_clip_kernel(const float4* __restrict__ anchors,
@@ -240,7 +264,15 @@ int ossid_nms(const float* boxes, int n, float iou_threshold, void* workspace, s
     if (hipMemsetAsync(mask, 0, (size_t)n * words * 8, s) != hipSuccess) return OSSID_ELAUNCH;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words), dim3(64), 0, s, (const float4*)boxes, n, iou_threshold,
                        mask, words);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)words * 8, s, mask, n, words, keep, num_keep);
+    if (words <= 16) {
+        const int lds = n * words * 8;
+        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)nms_scan_small_kernel,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return OSSID_ELAUNCH;
+        hipLaunchKernelGGL(nms_scan_small_kernel, dim3(1), dim3(256), lds, s, mask, n, words, keep, num_keep);
+    } else {
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)words * 8, s, mask, n, words, keep, num_keep);
+    }
     return ossid_launch_status();
 }
 

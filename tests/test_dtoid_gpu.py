@@ -38,7 +38,7 @@ def test_dw_xcorr_broadcasts_one_image_over_templates(hiplib):
     assert close(got, dtoid_oracle.dw_xcorr(x.cpu(), k.cpu()).numpy(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 3000])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 1024, 1025, 3000])
 def test_nms_matches_greedy_oracle(hiplib, n):
     g = torch.Generator().manual_seed(n)
     ctr = torch.rand(n, 2, generator=g) * 200
