@@ -205,6 +205,13 @@ size_t ossid_nms_workspace_bytes(int n);
 int ossid_nms(const float* boxes, int n, float iou_threshold, void* workspace, size_t workspace_bytes,
               int32_t* keep, int32_t* num_keep, void* stream);
 
+/* D12/D13  out[j][:] = src[idx[j]][:] for j < k, rows of row_floats (% 4 == 0) floats, with sigmoid applied on the way
+ * when apply_sigmoid != 0: the per-detection segmentation maps gathered from the per-template ones
+ * (network.py:575-579) + `torch.sigmoid(seg)` (models/dtoid/__init__.py:147) in one pass. idx: int64, each in
+ * [0, n_src_rows) (caller-checked). */
+int ossid_gather_rows(const float* src, int n_src_rows, long long row_floats, const long long* idx, int k,
+                      int apply_sigmoid, float* out, void* stream);
+
 /* D10  BBoxTransform.forward + ClipBoxes.forward      network.py:42-70, :78-88
  * anchors [A][4] (shared by all rows), deltas [rows][A][4] -> boxes [rows][A][4]; std (.1,.1,.2,.2), mean 0. */
 int ossid_decode_clip_boxes(const float* anchors, const float* deltas, int rows, int A, float img_w, float img_h,

@@ -155,6 +155,25 @@ __global__ __launch_bounds__(256) void nms_scan_small_kernel(const unsigned long
     if (lane == 0) *nkeep = cnt;
 }
 
+// ---- row gather (+ sigmoid): out[k][:] = f(src[idx[k]][:]) -- the per-detection segmentation maps picked out of the
+// per-template ones (network.py:575-579) with the sigmoid of dtoid/__init__.py:147 applied on the way, one pass instead of
+// a gather and an elementwise kernel over up to 500 x 480 x 640 floats
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float4* __restrict__ src, size_t row4,
+                                                          const long long* __restrict__ idx, int apply_sigmoid,
+                                                          float4* __restrict__ out) {
+    const size_t k = blockIdx.y;
+    const float4* s = src + (size_t)idx[k] * row4;
+    float4* o = out + k * row4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < row4; i += (size_t)gridDim.x * 256) {
+        float4 v = s[i];
+        if (apply_sigmoid) {
+            v.x = 1.0f / (1.0f + expf(-v.x)), v.y = 1.0f / (1.0f + expf(-v.y));
+            v.z = 1.0f / (1.0f + expf(-v.z)), v.w = 1.0f / (1.0f + expf(-v.w));
+        }
+        o[i] = v;
+    }
+}
+
 // ---- anchor decode + clip ------------------------------------------------------------------------------------------
 // anchors [A][4] shared by every batch row, deltas [R][A][4] -> boxes [R][A][4]; std (.1,.1,.2,.2), mean 0.
 __global__ __launch_bounds__(256) void decode_clip_kernel(const float4* __restrict__ anchors,
@@ -273,6 +292,19 @@ int ossid_nms(const float* boxes, int n, float iou_threshold, void* workspace, s
     } else {
         hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)words * 8, s, mask, n, words, keep, num_keep);
     }
+    return ossid_launch_status();
+}
+
+int ossid_gather_rows(const float* src, int n_src_rows, long long row_floats, const long long* idx, int k,
+                      int apply_sigmoid, float* out, void* stream) {
+    if (k < 0 || n_src_rows < 0 || row_floats <= 0 || (row_floats % 4) || k > 65535) return OSSID_EINVAL;
+    if (k == 0) return OSSID_OK;
+    if (!src || !idx || !out || n_src_rows == 0) return OSSID_EINVAL;
+    const size_t row4 = (size_t)row_floats / 4;
+    unsigned gx = (unsigned)((row4 + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, k), dim3(256), 0, (hipStream_t)stream, (const float4*)src, row4, idx,
+                       apply_sigmoid, (float4*)out);
     return ossid_launch_status();
 }
 

@@ -121,7 +121,8 @@ class DtoidNet(nn.Module):
         obj_id = int(input["obj_id"][0])
         local, glob = self._template_features(input, obj_id, image.device)
         with torch.no_grad():
-            scores, boxes, tids, seg, heat = self.model.forward_all_templates(image, local, glob, topk=self.TOP_K)
+            scores, boxes, tids, seg, heat = self.model.forward_all_templates(image, local, glob, topk=self.TOP_K,
+                                                                               seg_sigmoid=True)   # reference :147
             if "template_z_values" in input and getattr(self.cfg, "filter_z", False):
                 z = input["template_z_values"].to(boxes.device)[0, tids[:, 0].long()]
                 size = torch.maximum(boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1])
@@ -131,7 +132,6 @@ class DtoidNet(nn.Module):
                     ok = torch.zeros(1, dtype=torch.long, device=boxes.device)
                 scores, boxes, tids, seg, heat = scores[ok], boxes[ok], tids[ok], seg[ok], heat[ok]
             tids = tids[:, 0]
-            seg = torch.sigmoid(seg)
         out = {"pred_bbox": boxes, "pred_scores": scores, "pred_template_ids": tids, "segmentation": seg.unsqueeze(1),
                "heat_map": heat.unsqueeze(1), "final_bbox": [boxes], "final_score": [scores]}
         if "heatmap" in input:

@@ -467,7 +467,7 @@ class Network(nn.Module):
         graph.replay()
         return outs
 
-    def forward_all_templates(self, image, template_features, template_features_global, topk=1):
+    def forward_all_templates(self, image, template_features, template_features_global, topk=1, seg_sigmoid=False):
         """image [1,3,H,W]; template_features: list of [n_i,640,7,7] chunks; template_features_global: [[1,64,3,3]]
         -> [max_score [k], anchors_pred [k,4], obj_indices [k,1], seg_pred [k,H,W], heatmap_pred [k,hh,hw]]"""
         with torch.no_grad():
@@ -487,4 +487,8 @@ class Network(nn.Module):
             keep = ops.nms(anchors_pred, max_score, 0.5, sorted_desc=True)[:topk]   # topk returns them sorted
             max_score, anchors_pred, obj_indices = max_score[keep], anchors_pred[keep], obj_indices[keep]
             tid = obj_indices.reshape(-1).long()
-            return [max_score, anchors_pred, obj_indices, seg_all[:, 0][tid], heat_all[:, 0][tid]]
+            if image.is_cuda:    # seg_sigmoid (additive argument): the sigmoid DtoidNet applies afterwards, folded into the gather
+                seg = ops.gather_rows(seg_all[:, 0], tid, sigmoid=seg_sigmoid)
+            else:
+                seg = torch.sigmoid(seg_all[:, 0][tid]) if seg_sigmoid else seg_all[:, 0][tid]
+            return [max_score, anchors_pred, obj_indices, seg, heat_all[:, 0][tid]]

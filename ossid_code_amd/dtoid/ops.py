@@ -82,6 +82,24 @@ def nms(boxes, scores, iou_threshold, sorted_desc=False):
     return kept if order is None else order[kept]
 
 
+def gather_rows(src, idx, sigmoid=False):
+    """src [R, ...] float32, idx [k] int64 -> src[idx] (optionally through a sigmoid), one pass over the data."""
+    _lib.require_cuda(src, idx)
+    src = src.float().contiguous()
+    idx = idx.long().contiguous()
+    k, row = int(idx.shape[0]), int(src[0].numel()) if src.shape[0] else 0
+    out = torch.empty((k,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    if k == 0 or row == 0:
+        return out
+    if row % 4:
+        g = src[idx]
+        return torch.sigmoid(g) if sigmoid else g
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.fn("ossid_gather_rows")(src.data_ptr(), int(src.shape[0]), row, idx.data_ptr(), k,
+                                                1 if sigmoid else 0, out.data_ptr(), _lib.stream()), "ossid_gather_rows")
+    return out
+
+
 def decode_clip_boxes(anchors, deltas, img_w, img_h):
     """anchors [1,A,4] or [A,4], deltas [R,A,4] -> clipped boxes [R,A,4] (BBoxTransform + ClipBoxes, no autograd)."""
     _lib.require_cuda(anchors, deltas)

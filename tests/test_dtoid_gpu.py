@@ -460,3 +460,14 @@ def test_graphed_test_time_path_follows_a_finetune_step(hiplib):
     want = fnet._dense_all_templates(normalizeImageRange(test["img"]), local, glob[0])
     for a, w in zip(after, want[:4]):
         assert torch.allclose(a, w, rtol=1e-4, atol=1e-5), float((a - w).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [0, 1, 37])
+def test_gather_rows_with_sigmoid(hiplib, k):
+    g = torch.Generator().manual_seed(k)
+    src = torch.randn(9, 48, 64, generator=g).cuda()
+    idx = torch.randint(0, 9, (k,), generator=g).cuda()
+    assert torch.equal(ops.gather_rows(src, idx), src[idx])
+    got = ops.gather_rows(src, idx, sigmoid=True)
+    assert got.shape == (k, 48, 64) and torch.allclose(got, torch.sigmoid(src[idx]), rtol=1e-6, atol=1e-6)
