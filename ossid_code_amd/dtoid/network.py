@@ -239,12 +239,21 @@ class FusedHead:
         for pk in [self.dot, self.sub, self.dot3, self.cf, self.tail] + self.seg + self.cls + self.reg:
             pk.refresh()
 
+    _TENSORS = {}
+
     @staticmethod
     def version_key(*mods):
         """(storage identity, value versions): a change of the first means the parameters were re-homed (rebuild, and
-        drop captured graphs: they read the old addresses), of the second only that values changed (refresh in place)."""
-        return (tuple(t.data_ptr() for m in mods for t in m.parameters()),
-                tuple(int(t._version) for m in mods for t in list(m.parameters()) + list(m.buffers())))
+        drop captured graphs: they read the old addresses), of the second only that values changed (refresh in place).
+        Runs once per frame, so the walk over the module tree (~1 ms for DenseNet-121: it was 8 % of a frame) is done
+        once per module set and only the tensors' pointers and version counters are read afterwards."""
+        ent = FusedHead._TENSORS.get(tuple(id(m) for m in mods))
+        if ent is None or any(r() is not m for r, m in zip(ent[0], mods)):
+            import weakref
+            params = [t for m in mods for t in m.parameters()]
+            ent = ([weakref.ref(m) for m in mods], params, params + [t for m in mods for t in m.buffers()])
+            FusedHead._TENSORS[tuple(id(m) for m in mods)] = ent
+        return (tuple(t.data_ptr() for t in ent[1]), tuple(t._version for t in ent[2]))
 
     def correlation(self, image_feat, template_feat):
         corr = self.corr

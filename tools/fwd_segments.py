@@ -29,3 +29,15 @@ print("forward_all_templates      %.3f ms" % t(lambda: net.forward_all_templates
 print("dense graph replay only    %.3f ms" % t(lambda: net._graphed_dense(img, local, glob[0])))
 ent = list(net.__dict__["_graph_cache"].values())[0]
 print("bare graph.replay()        %.3f ms" % t(lambda: ent[0].replay()))
+def t_sync(fn, n=20):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        fn(); torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+print("bare replay + sync each    %.3f ms" % t_sync(lambda: ent[0].replay()))
+t0 = time.perf_counter()
+for _ in range(20):
+    ent[0].replay()
+host = (time.perf_counter() - t0) / 20 * 1e3
+torch.cuda.synchronize()
+print("host time of replay() call %.3f ms" % host)
