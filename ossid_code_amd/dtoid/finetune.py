@@ -142,10 +142,19 @@ class GradSync:
             return
         g = self.flat.used_grad()
         g.mul_(1.0 / self.world)          # pre-scale once; SUM of the scaled buffers is the mean
+        host_staged = g.is_cuda and self.dist.get_backend(self.group) != "nccl"
+        if host_staged:
+            # gloo moves device tensors through host memory and makes the stream wait on a HOST-signalled event. With
+            # several ranks sharing one GPU (the rehearsal set-up, never the product one) such a device-side wait can
+            # hold the hardware queue the other rank needs to get its half done: seconds per step until the scheduler
+            # preempts (measured: 24 s/step). Draining the device first keeps the wait on the host.
+            torch.cuda.synchronize(g.device)
         works = [self.dist.all_reduce(g[a:b], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
                  for a, b in self.bounds]
         for w in works:
             w.wait()
+        if host_staged:
+            torch.cuda.synchronize(g.device)
 
     def broadcast_params(self, src=0):
         """Make every replica start from rank `src`'s weights (DDP's constructor does the same)."""

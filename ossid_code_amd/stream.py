@@ -76,6 +76,7 @@ class OnlineStream:
         self.detector, self.scorer, self.dataset = detector, scorer, score_dataset
         self.threshold, self.symmetric, self.finetune_fn = confident_threshold, symmetric, finetune_fn
         self.times = {k: 0.0 for k in ("detect", "pose_err", "score", "pseudo_label")}
+        self.n_processed = 0
 
     def _timed(self, key, fn):
         torch.cuda.synchronize()
@@ -89,6 +90,7 @@ class OnlineStream:
         """frame: dict with img uint8 [H,W,3], depth [H,W], cam_K, limg [n_t,3,124,124], lmask [n_t,1,124,124], obj_id,
         pose_hypos [N,4,4], pose_gt [4,4], model_points/normals/colors [M,3]. Returns the per-frame result dict."""
         dev = next(self.detector.parameters()).device
+        self.n_processed += 1
         img_t = torch.from_numpy(np.ascontiguousarray(frame["img"])).to(dev).permute(2, 0, 1).float().div_(255.0)[None]
         batch = {"img": img_t, "obj_id": torch.tensor([int(frame["obj_id"])]), "limg": frame["limg"][None].to(dev),
                  "lmask": frame["lmask"][None].to(dev)}
@@ -176,14 +178,13 @@ def _broadcast_sample(sample, src, dist, group):
     tensor broadcasts on the group's device."""
     header = [None]
     if sample is not None:
-        header = [[(k, tuple(v.shape), v.dtype) for k, v in sample.items() if torch.is_tensor(v)]]
+        header = [[(k, tuple(v.shape), v.dtype, v.is_cuda) for k, v in sample.items() if torch.is_tensor(v)]]
     dist.broadcast_object_list(header, src=src, group=group)
-    on_gpu = dist.get_backend(group) == "nccl"
     out = {}
-    for k, shape, dtype in header[0]:
+    for k, shape, dtype, on_gpu in header[0]:
         if sample is not None:
             t = sample[k].contiguous()
-        else:
+        else:           # same device kind as the sender's tensor (device tensors stay on the device: RCCL, or gloo's CUDA path)
             t = torch.empty(shape, dtype=dtype, device="cuda" if on_gpu else "cpu")
         dist.broadcast(t, src=src, group=group)
         out[k] = t

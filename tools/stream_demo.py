@@ -28,11 +28,20 @@ def main():
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8)
     a = ap.parse_args()
-    dev = torch.device("cuda:0")
+    t_start = time.perf_counter()
+    from ossid_code_amd import parallel
+    from ossid_code_amd.stream import run_speculative
+    rank, world, local, dist = parallel.init_from_env(os.environ.get("OSSID_BENCH_BACKEND", "nccl"))
+    local %= max(1, torch.cuda.device_count())       # gloo rehearsal: ranks may share a device
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     torch.manual_seed(0)
     det = dtoid.DtoidNet(dtoid.DtoidConfig()).to(dev).eval()
     flat = finetune.FlatParams(det)
     opt = finetune.FusedAMSGrad(flat, lr=1e-4, weight_decay=1e-6)
+    sync = finetune.GradSync(flat) if dist is not None else None
+    if sync is not None:
+        sync.broadcast_params(0)
     class Args:
         dataset, no_valid_proj, no_valid_depth, inconst_ratio_th, interp = "HSVD_diff_uv_norm", True, True, 100, 0
 
@@ -50,6 +59,9 @@ def main():
         frames.append(d)
     ft_time, ft_steps = [0.0], [0]
 
+    def note(msg):
+        print("[stream_demo rank %d %.1fs] %s" % (rank, time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
     def finetune_fn(samples):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -62,8 +74,31 @@ def main():
         for _ in range(a.epochs):
             order = rng.permutation(len(items))
             for b0 in range(0, len(order), a.batch):
-                batch = pipeline.collate([items[i] for i in order[b0:b0 + a.batch]])
-                finetune.finetune_step(det, batch, opt)
+                mine = order[b0:b0 + a.batch][rank::world]       # this rank's slice of the global batch
+                if len(mine) == 0:
+                    mine = order[b0:b0 + 1]                      # every rank must take part in the gradient all-reduce
+                batch = pipeline.collate([items[i] for i in mine])
+                if os.environ.get("OSSID_STREAM_DEBUG"):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    out = det(batch)
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    flat.detach_grads()
+                    out["loss"].backward()
+                    flat.gather_grads()
+                    torch.cuda.synchronize()
+                    t3 = time.perf_counter()
+                    if sync is not None:
+                        sync.sync()
+                    torch.cuda.synchronize()
+                    t4 = time.perf_counter()
+                    opt.step()
+                    torch.cuda.synchronize()
+                    note("step B=%d: fwd %.2f s, bwd %.2f s, sync %.2f s, opt %.3f s" %
+                         (len(mine), t2 - t1, t3 - t2, t4 - t3, time.perf_counter() - t4))
+                else:
+                    finetune.finetune_step(det, batch, opt, sync)
                 ft_steps[0] += 1
         det.eval()
         det.clearCache()                       # template features depend on the weights that just changed
@@ -71,12 +106,15 @@ def main():
         ft_time[0] += time.perf_counter() - t0
 
     stream = OnlineStream(det, scorer, dataset, confident_threshold=-1e30, finetune_fn=finetune_fn)
+    note("models and %d frames ready" % len(frames))
     r0 = stream.process(frames[0])             # warm-up: graph capture, workspace allocation ...
+    note("warm-up frame done")
     snap_p, snap_b = flat.param.clone(), [b.clone() for b in det.buffers()]
     epochs, a.epochs = a.epochs, 1                # ... and MIOpen's per-shape algorithm search for the training convs
     for nb in sorted({a.batch, a.interval % a.batch or a.batch}):
         finetune_fn([(frames[0], r0["sample"])] * nb)
     a.epochs = epochs
+    note("warm-up finetune done")
     with torch.no_grad():
         flat.param.copy_(snap_p)
         for b, s0 in zip(det.buffers(), snap_b):
@@ -87,19 +125,42 @@ def main():
     det.clearCache()
     for k in stream.times:
         stream.times[k] = 0.0
+    stream.n_processed = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    results, win = stream.run(frames, a.interval)
+    if dist is None:
+        results, win = stream.run(frames, a.interval)
+    else:
+        samples = []
+
+        def process_fn(frame):
+            r = stream.process(frame)
+            if stream.n_processed % 4 == 0:
+                note("processed %d frames" % stream.n_processed)
+            return r["confident"], r["sample"]
+
+        def ft(train):          # identical frame-ordered (frame id, sample) list on every rank
+            note("finetune on %d samples" % len(train))
+            finetune_fn([(frames[f], smp) for f, smp in train])
+        committed, win = run_speculative(frames, process_fn, ft, a.interval, dist)
     torch.cuda.synchronize()
     total = time.perf_counter() - t0
-    per = {k: 1e3 * v / a.frames for k, v in stream.times.items()}
-    print(json.dumps({"metric": "online stream frames/sec", "value": a.frames / total, "unit": "frames/s", "n_gpus": 1,
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    per = {k: 1e3 * v / max(1, stream.n_processed) for k, v in stream.times.items()}   # frames THIS rank processed
+    print(json.dumps({"metric": "online stream frames/sec", "value": a.frames / total, "unit": "frames/s", "n_gpus": world,
+                      "speculated_frames_discarded": win.discarded,
                       "frames": a.frames, "hypotheses_per_frame": a.hypos, "points": a.points,
                       "templates": a.templates, "finetunes": len(win.train_set) // a.interval,
                       "finetune_steps": ft_steps[0], "finetune_ms_per_step": 1e3 * ft_time[0] / max(1, ft_steps[0]),
                       "ms_per_frame_excl_finetune": 1e3 * (total - ft_time[0]) / a.frames,
+                      "frames_processed_by_rank0": stream.n_processed,
                       "stage_ms_per_frame": per, "hyp_per_sec_in_stream": a.hypos / (per["score"] * 1e-3),
                       "data": "synthetic", "weights": "random-init"}))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
