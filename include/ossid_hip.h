@@ -168,6 +168,11 @@ typedef struct ossid_conv_desc {
     float* out;
     int32_t batch, height, width, cin, cout, taps, act, pre_relu;
     int32_t src_height, src_width, in_channel_stride, out_channel_stride, out_channel_offset;
+    int32_t pre_batch_stride;   /* floats between the pre_scale / pre_shift rows of consecutive images; 0 = one row */
+    int64_t in_batch_stride;    /* floats between consecutive images of x; < 0 = dense (src_h * src_w * channel stride);
+                                   0 = ONE image shared by the whole batch (a per-image pre-affine then makes each
+                                   batch entry a different affine view of it: image_feat * avg_t, image_feat - avg_t
+                                   of network.py:344-347 without materialising them) */
 } ossid_conv_desc;
 size_t ossid_conv_packed_floats(int Cout, int Cin, int taps);
 int ossid_conv_pack_weights(const float* w, int Cout, int Cin, int taps, float* wpk, void* stream);

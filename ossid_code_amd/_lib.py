@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, _vp) for n in ("x", "wpk", "bias", "pre_scale", "pre_shift", "post_scale", "post_shift", "out")] + \
                [(n, C.c_int32) for n in ("batch", "height", "width", "cin", "cout", "taps", "act", "pre_relu",
                                          "src_height", "src_width", "in_channel_stride", "out_channel_stride",
-                                         "out_channel_offset")]
+                                         "out_channel_offset", "pre_batch_stride")] + [("in_batch_stride", C.c_int64)]
 
 
 _PROTOS = {

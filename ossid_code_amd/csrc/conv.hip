@@ -43,6 +43,8 @@ struct ConvArgs {
     const float *bias, *bn_scale, *bn_shift, *pre_scale, *pre_shift;
     float* out;
     int H, W, Cin, Cout, n_cotiles, act, buf_pos, Hs, Ws, in_cs, out_cs, out_coff, pre_relu;
+    long long in_bs;          // floats between consecutive images of x (0: one image shared by the whole batch)
+    int pre_bs;               // floats between consecutive images' pre_scale / pre_shift rows (0: one row for all)
     int gx, gy, gz;   // logical grid: pixel blocks x channel-tile groups x images (the launch itself is 1-D)
     float scale_h, scale_w;
 };
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         if (TAPS == 1) {
             const int px = bx * BPX + pos;
             const bool ok = pos < npos && px < HW;
-            goff[e] = ok ? ((b * HW + px) * A.in_cs + 4 * j) : -1;
+            goff[e] = ok ? (px * A.in_cs + 4 * j) : -1;
         } else {
             const int pr = pos / PW, pc = pos - pr * PW;
             const int yy = y_first - 1 + pr, xx = x_first - 1 + pc;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
             // its [H][W] input straight from the [Hs][Ws] source, index = min(floor(dst * in/out), in-1)
             const int sy = (A.Hs == H) ? yy : min((int)floorf((float)yy * A.scale_h), A.Hs - 1);
             const int sx = (A.Ws == W) ? xx : min((int)floorf((float)xx * A.scale_w), A.Ws - 1);
-            goff[e] = ok ? (((b * A.Hs + sy) * A.Ws + sx) * A.in_cs + 4 * j) : -1;
+            goff[e] = ok ? ((sy * A.Ws + sx) * A.in_cs + 4 * j) : -1;
         }
         lidx[e] = pos < npos ? idx : -1;
     }
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     }
 
     float4 st[NLD];
+    const float* xb = A.x + (size_t)b * A.in_bs;          // this image (in_bs = 0: every batch entry reads the same one)
     const int jch = 4 * (tid % F4);   // this thread always stages channels ci0 + jch .. +3 (256 % F4 == 0)
     auto stage_load = [&](int ci0) {
         // a ragged LAST chunk (Cin no multiple of KCH) stages zeros for the channels past Cin; their weight quads are
@@ -196,9 +199,10 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         const bool chan_ok = ci0 + jch < A.Cin;
 #pragma unroll
         for (int e = 0; e < NLD; ++e)
-            st[e] = (goff[e] >= 0 && chan_ok) ? *(const float4*)(A.x + (size_t)goff[e] + ci0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            st[e] = (goff[e] >= 0 && chan_ok) ? *(const float4*)(xb + (size_t)goff[e] + ci0) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (A.pre_scale && chan_ok) {   // BN(eval) (+ReLU) of the INPUT, on real pixels only: the zero halo stays zero
-            const float4 ps = *(const float4*)(A.pre_scale + ci0 + jch), pt = *(const float4*)(A.pre_shift + ci0 + jch);
+            const float4 ps = *(const float4*)(A.pre_scale + (size_t)b * A.pre_bs + ci0 + jch),
+                         pt = *(const float4*)(A.pre_shift + (size_t)b * A.pre_bs + ci0 + jch);
 #pragma unroll
             for (int e = 0; e < NLD; ++e) {
                 if (goff[e] < 0) continue;
@@ -429,10 +433,12 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
     a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout, a.n_cotiles = (Cout + 31) / 32, a.act = d->act, a.buf_pos = 0;
     a.Hs = d->src_height > 0 ? d->src_height : H, a.Ws = d->src_width > 0 ? d->src_width : W;
     a.in_cs = d->in_channel_stride > 0 ? d->in_channel_stride : Cin;
+    a.in_bs = d->in_batch_stride >= 0 ? d->in_batch_stride : (long long)a.Hs * a.Ws * a.in_cs;
+    a.pre_bs = d->pre_batch_stride;
     a.out_cs = d->out_channel_stride > 0 ? d->out_channel_stride : Cout;
     a.out_coff = d->out_channel_offset;
     if (a.Hs > H || a.Ws > W || a.in_cs < Cin || a.out_cs < a.out_coff + Cout || (a.in_cs % 4) || (a.out_cs % 4) ||
-        (a.out_coff % 4) || (a.pre_scale && !a.pre_shift) || (d->taps == 1 && (a.Hs != H || a.Ws != W)))
+        (a.out_coff % 4) || (a.pre_scale && !a.pre_shift) || (a.in_bs % 4) || a.pre_bs < 0 || (a.pre_bs % 4) || (d->taps == 1 && (a.Hs != H || a.Ws != W)))
         return OSSID_EINVAL;
     a.scale_h = (float)a.Hs / (float)H, a.scale_w = (float)a.Ws / (float)W;
     hipStream_t s = (hipStream_t)stream;

@@ -260,7 +260,24 @@ class FusedHead:
         t2 = corr._cab(corr.c2, corr.n2, corr._cab(corr.c1, corr.n1, template_feat))
         dot3x3 = ops.dw_xcorr(image_feat, t2)
         avg = F.avg_pool2d(template_feat, 7)
-        x = torch.cat([self.dot(image_feat * avg), self.sub(image_feat - avg), self.dot3(dot3x3)], dim=1)
+        if image_feat.shape[0] == 1 and image_feat.is_cuda:
+            # ONE image against B templates: `image_feat * avg_t` and `image_feat - avg_t` (network.py:344-347) are per-template
+            # affine views of the same feature map, so the two convolutions read the single image (batch stride 0, it stays
+            # in L2) and apply avg_t as a per-(template, channel) input scale / shift while staging; the three results land
+            # in channel slices of one buffer (no torch.cat). Saves two 61 MB elementwise passes and a 73 MB copy per frame.
+            B, C = int(template_feat.shape[0]), int(image_feat.shape[1])
+            H, W = int(image_feat.shape[2]), int(image_feat.shape[3])
+            xin = image_feat.float().contiguous(memory_format=torch.channels_last)
+            a2 = avg.reshape(B, C).float().contiguous()
+            ones, zeros = torch.ones_like(a2), torch.zeros_like(a2)
+            ctot = self.dot.cout + self.sub.cout + self.dot3.cout
+            x = torch.empty((B, ctot, H, W), dtype=torch.float32, device=xin.device, memory_format=torch.channels_last)
+            self.dot.run(xin, B, H, W, x, out_cs=ctot, out_coff=0, in_bs=0, pre=(a2, zeros))
+            self.sub.run(xin, B, H, W, x, out_cs=ctot, out_coff=self.dot.cout, in_bs=0, pre=(ones, -a2))
+            d3 = dot3x3.float().contiguous(memory_format=torch.channels_last)
+            self.dot3.run(d3, B, H, W, x, out_cs=ctot, out_coff=self.dot.cout + self.sub.cout)
+        else:
+            x = torch.cat([self.dot(image_feat * avg), self.sub(image_feat - avg), self.dot3(dot3x3)], dim=1)
         x2 = self.cf(x)
         heat_map = torch.sigmoid(corr.corr_conv_heatmap(x2))
         # decoder: each F.interpolate(mode="nearest") is folded into the NEXT conv's patch staging, so the up-sampled

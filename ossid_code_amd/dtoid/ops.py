@@ -161,12 +161,16 @@ class PackedConv:
                 sc.copy_(a)
                 sh.copy_(b)
 
-    def run(self, x_nhwc, B, H, W, out_nhwc, in_cs=0, out_cs=0, out_coff=0, src_hw=(0, 0)):
-        """Raw call on physical [B][H][W][C] buffers (tensors only provide pointers)."""
+    def run(self, x_nhwc, B, H, W, out_nhwc, in_cs=0, out_cs=0, out_coff=0, src_hw=(0, 0), in_bs=-1, pre=None):
+        """Raw call on physical [B][H][W][C] buffers (tensors only provide pointers). in_bs = 0: x is ONE image shared by
+        the whole batch; pre = (scale [B,Cin], shift [B,Cin]): a per-image input affine instead of the stored one."""
         d = _lib.ConvDesc()
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         d.x, d.wpk, d.bias, d.out = x_nhwc.data_ptr(), self.wpk.data_ptr(), p(self.bias), out_nhwc.data_ptr()
         d.pre_scale, d.pre_shift, d.post_scale, d.post_shift = p(self.pre_scale), p(self.pre_shift), p(self.scale), p(self.shift)
+        d.in_batch_stride, d.pre_batch_stride = in_bs, 0
+        if pre is not None:
+            d.pre_scale, d.pre_shift, d.pre_batch_stride = pre[0].data_ptr(), pre[1].data_ptr(), self.cin
         d.batch, d.height, d.width, d.cin, d.cout, d.taps = B, H, W, self.cin, self.cout, self.taps
         d.act, d.pre_relu = self.act, self.pre_relu
         d.src_height, d.src_width = int(src_hw[0]), int(src_hw[1])
