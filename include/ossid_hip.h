@@ -141,6 +141,10 @@ const char* ossid_pn2_kernel_names(void);
  * _bwd_x: gradient w.r.t. x; _bwd_k: gradient w.r.t. the kernel (gradients flow to both operands). */
 int ossid_dw_xcorr_fwd(const float* x, int x_planes, const float* k, int planes, int H, int W, float* out,
                        void* stream);   /* x_planes = planes, or C when ONE image [C][H][W] is shared by all B kernels */
+/* the same correlation, channels-last, ONE image x [H][W][channels] against `batch` kernel sets k [batch][channels][3][3]
+ * (test time: the image broadcast over the templates) -> out [batch][H][W][channels]; channels % 4 == 0 */
+int ossid_dw_xcorr_nhwc_bcast(const float* x, const float* k, int batch, int channels, int H, int W, float* out,
+                              void* stream);
 int ossid_dw_xcorr_bwd_x(const float* dout, const float* k, int planes, int H, int W, float* dx, void* stream);
 int ossid_dw_xcorr_bwd_k(const float* x, const float* dout, int planes, int H, int W, float* dk, void* stream);
 

@@ -52,6 +52,7 @@ _PROTOS = {
     "ossid_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(_f)]),
     "ossid_pn2_kernel_names": (C.c_char_p, []),
     "ossid_dw_xcorr_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "ossid_dw_xcorr_nhwc_bcast": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ossid_dw_xcorr_bwd_x": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ossid_dw_xcorr_bwd_k": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ossid_conv_packed_floats": (_sz, [_i, _i, _i]),

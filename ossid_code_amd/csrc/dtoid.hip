@@ -155,6 +155,40 @@ __global__ __launch_bounds__(256) void nms_scan_small_kernel(const unsigned long
     if (lane == 0) *nkeep = cnt;
 }
 
+// ---- depthwise cross-correlation, channels-last, ONE image against B kernels (the test-time correlation of
+// network.py:365-371 with the image broadcast over the templates): out[b][y][x][c] = sum_taps x[y+dy][x+dx][c] * k[b][c][tap].
+// A thread owns 4 consecutive channels of one output pixel: nine 16-byte reads of the (L2-resident) image, 36 kernel
+// taps from consecutive addresses, one 16-byte store -- the result is born in the layout the next convolution stages from.
+__global__ __launch_bounds__(256) void dw_xcorr_nhwc_kernel(const float4* __restrict__ x, const float* __restrict__ k,
+                                                            int C4, int H, int W, size_t total, float4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int xx = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H), b = (int)(r / H);
+    const float* kk = k + ((size_t)b * C4 + c4) * 36;          // [4 channels][9 taps]
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int y = yy + dy - 1;
+        if (y < 0 || y >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xq = xx + dx - 1;
+            if (xq < 0 || xq >= W) continue;
+            const float4 v = x[((size_t)y * W + xq) * C4 + c4];
+            const int t = dy * 3 + dx;
+            acc.x = fmaf(v.x, kk[t], acc.x);
+            acc.y = fmaf(v.y, kk[9 + t], acc.y);
+            acc.z = fmaf(v.z, kk[18 + t], acc.z);
+            acc.w = fmaf(v.w, kk[27 + t], acc.w);
+        }
+    }
+    out[i] = acc;
+}
+
 // ---- row gather (+ sigmoid): out[k][:] = f(src[idx[k]][:]) -- the per-detection segmentation maps picked out of the
 // per-template ones (network.py:575-579) with the sigmoid of dtoid/__init__.py:147 applied on the way, one pass instead of
 // a gather and an elementwise kernel over up to 500 x 480 x 640 floats
@@ -243,6 +277,18 @@ int ossid_dw_xcorr_fwd(const float* x, int x_planes, const float* k, int planes,
         hipLaunchKernelGGL(dw_xcorr_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, k + (size_t)p0 * 9, H, W, 0,
                            out + (size_t)p0 * H * W, x_planes, p0);
     }
+    return ossid_launch_status();
+}
+
+int ossid_dw_xcorr_nhwc_bcast(const float* x, const float* k, int batch, int channels, int H, int W, float* out,
+                              void* stream) {
+    if (batch < 0 || channels <= 0 || (channels % 4) || H <= 0 || W <= 0) return OSSID_EINVAL;
+    if (batch == 0) return OSSID_OK;
+    if (!x || !k || !out) return OSSID_EINVAL;
+    const size_t total = (size_t)batch * H * W * (channels / 4);
+    if ((total + 255) / 256 > 0x7fffffffull) return OSSID_EINVAL;
+    hipLaunchKernelGGL(dw_xcorr_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x, k, channels / 4, H, W, total, (float4*)out);
     return ossid_launch_status();
 }
 

@@ -258,9 +258,10 @@ class FusedHead:
     def correlation(self, image_feat, template_feat):
         corr = self.corr
         t2 = corr._cab(corr.c2, corr.n2, corr._cab(corr.c1, corr.n1, template_feat))
-        dot3x3 = ops.dw_xcorr(image_feat, t2)
         avg = F.avg_pool2d(template_feat, 7)
-        if image_feat.shape[0] == 1 and image_feat.is_cuda:
+        bcast = image_feat.shape[0] == 1 and image_feat.is_cuda and image_feat.shape[1] % 4 == 0
+        dot3x3 = None if bcast else ops.dw_xcorr(image_feat, t2)
+        if bcast:
             # ONE image against B templates: `image_feat * avg_t` and `image_feat - avg_t` (network.py:344-347) are per-template
             # affine views of the same feature map, so the two convolutions read the single image (batch stride 0, it stays
             # in L2) and apply avg_t as a per-(template, channel) input scale / shift while staging; the three results land
@@ -274,7 +275,7 @@ class FusedHead:
             x = torch.empty((B, ctot, H, W), dtype=torch.float32, device=xin.device, memory_format=torch.channels_last)
             self.dot.run(xin, B, H, W, x, out_cs=ctot, out_coff=0, in_bs=0, pre=(a2, zeros))
             self.sub.run(xin, B, H, W, x, out_cs=ctot, out_coff=self.dot.cout, in_bs=0, pre=(ones, -a2))
-            d3 = dot3x3.float().contiguous(memory_format=torch.channels_last)
+            d3 = ops.dw_xcorr_nhwc_bcast(xin, t2)             # born channels-last: no transposing copy
             self.dot3.run(d3, B, H, W, x, out_cs=ctot, out_coff=self.dot.cout + self.sub.cout)
         else:
             x = torch.cat([self.dot(image_feat * avg), self.sub(image_feat - avg), self.dot3(dot3x3)], dim=1)

@@ -59,6 +59,21 @@ def dw_xcorr(x, kernel):
     return _DwXcorr.apply(x, kernel)
 
 
+def dw_xcorr_nhwc_bcast(x, kernel):
+    """x [1,C,H,W] (channels_last memory), kernel [B,C,3,3] -> [B,C,H,W] in channels_last memory: dw_xcorr with the one
+    image broadcast over the B kernel sets, produced directly in the layout the next convolution reads. No autograd."""
+    _lib.require_cuda(x, kernel)
+    B, C = int(kernel.shape[0]), int(kernel.shape[1])
+    H, W = int(x.shape[2]), int(x.shape[3])
+    x = x.float().contiguous(memory_format=torch.channels_last)
+    k = kernel.detach().float().contiguous()
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.fn("ossid_dw_xcorr_nhwc_bcast")(x.data_ptr(), k.data_ptr(), B, C, H, W, out.data_ptr(),
+                                                        _lib.stream()), "ossid_dw_xcorr_nhwc_bcast")
+    return out
+
+
 def nms(boxes, scores, iou_threshold, sorted_desc=False):
     """torchvision.ops.nms semantics: indices of the kept boxes, by decreasing score. sorted_desc=True: the caller
     guarantees scores are already in decreasing order (the output of torch.topk) and the sort + gather are skipped."""

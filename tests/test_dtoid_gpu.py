@@ -471,3 +471,14 @@ def test_gather_rows_with_sigmoid(hiplib, k):
     assert torch.equal(ops.gather_rows(src, idx), src[idx])
     got = ops.gather_rows(src, idx, sigmoid=True)
     assert got.shape == (k, 48, 64) and torch.allclose(got, torch.sigmoid(src[idx]), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_dw_xcorr_channels_last_broadcast_matches_grouped_conv(hiplib):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 24, 9, 13, generator=g).cuda()
+    k = torch.randn(5, 24, 3, 3, generator=g).cuda()
+    got = ops.dw_xcorr_nhwc_bcast(x.contiguous(memory_format=torch.channels_last), k)
+    want = dtoid_oracle.dw_xcorr(x.cpu().expand(5, -1, -1, -1), k.cpu())
+    assert got.shape == (5, 24, 9, 13) and got.is_contiguous(memory_format=torch.channels_last)
+    assert close(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
