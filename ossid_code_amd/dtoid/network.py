@@ -255,10 +255,19 @@ class FusedHead:
             FusedHead._TENSORS[tuple(id(m) for m in mods)] = ent
         return (tuple(t.data_ptr() for t in ent[1]), tuple(t._version for t in ent[2]))
 
-    def correlation(self, image_feat, template_feat):
+    def template_side(self, template_feat):
+        """Everything the correlation needs from the templates alone (network.py:333-343: the two valid 3x3 convs on the
+        7x7 template features and the global average): constant across frames for an object, so the graphed path computes
+        it once per (templates, weights) instead of once per frame."""
         corr = self.corr
-        t2 = corr._cab(corr.c2, corr.n2, corr._cab(corr.c1, corr.n1, template_feat))
+        t2 = corr._cab(corr.c2, corr.n2, corr._cab(corr.c1, corr.n1, template_feat)).contiguous()
         avg = F.avg_pool2d(template_feat, 7)
+        a2 = avg.reshape(avg.shape[0], avg.shape[1]).float().contiguous()
+        return [t2, avg, a2, -a2]
+
+    def correlation(self, image_feat, template_feat, side=None):
+        corr = self.corr
+        t2, avg, a2, neg_a2 = self.template_side(template_feat) if side is None else side
         bcast = image_feat.shape[0] == 1 and image_feat.is_cuda and image_feat.shape[1] % 4 == 0
         dot3x3 = None if bcast else ops.dw_xcorr(image_feat, t2)
         if bcast:
@@ -266,15 +275,14 @@ class FusedHead:
             # affine views of the same feature map, so the two convolutions read the single image (batch stride 0, it stays
             # in L2) and apply avg_t as a per-(template, channel) input scale / shift while staging; the three results land
             # in channel slices of one buffer (no torch.cat). Saves two 61 MB elementwise passes and a 73 MB copy per frame.
-            B, C = int(template_feat.shape[0]), int(image_feat.shape[1])
+            B = int(template_feat.shape[0])
             H, W = int(image_feat.shape[2]), int(image_feat.shape[3])
             xin = image_feat.float().contiguous(memory_format=torch.channels_last)
-            a2 = avg.reshape(B, C).float().contiguous()
-            ones, zeros = torch.ones_like(a2), torch.zeros_like(a2)
+            ones, zeros = self._const(a2)
             ctot = self.dot.cout + self.sub.cout + self.dot3.cout
             x = torch.empty((B, ctot, H, W), dtype=torch.float32, device=xin.device, memory_format=torch.channels_last)
             self.dot.run(xin, B, H, W, x, out_cs=ctot, out_coff=0, in_bs=0, pre=(a2, zeros))
-            self.sub.run(xin, B, H, W, x, out_cs=ctot, out_coff=self.dot.cout, in_bs=0, pre=(ones, -a2))
+            self.sub.run(xin, B, H, W, x, out_cs=ctot, out_coff=self.dot.cout, in_bs=0, pre=(ones, neg_a2))
             d3 = ops.dw_xcorr_nhwc_bcast(xin, t2)             # born channels-last: no transposing copy
             self.dot3.run(d3, B, H, W, x, out_cs=ctot, out_coff=self.dot.cout + self.sub.cout)
         else:
@@ -290,6 +298,13 @@ class FusedHead:
         if seg is None:
             seg = corr.seg_final(self.seg[4](s, size=corr.img_size))
         return x2, heat_map, seg
+
+    def _const(self, like):
+        key = (tuple(like.shape), str(like.device))
+        c = self.__dict__.setdefault("_consts", {})
+        if key not in c:
+            c[key] = (torch.ones_like(like), torch.zeros_like(like))
+        return c[key]
 
     @staticmethod
     def _trunk(convs, x):
@@ -405,9 +420,11 @@ class Network(nn.Module):
         if cached is None or cached[0][0] != key[0]:
             self.__dict__.pop("_graph_cache", None)
             cached = (key, FusedHead(*mods))
+            self.__dict__["_plan_epoch"] = self.__dict__.get("_plan_epoch", 0) + 1
         elif cached[0] != key:
             cached[1].refresh()
             cached = (key, cached[1])
+            self.__dict__["_plan_epoch"] = self.__dict__.get("_plan_epoch", 0) + 1
         self.__dict__["_fused_cache"] = cached
         return cached[1]
 
@@ -437,7 +454,7 @@ class Network(nn.Module):
         classifications, _ = self.classification(xcors)
         return classifications, self.regression(xcors), anchors, heat_map, segmentation
 
-    def _dense_all_templates(self, image, template_features, template_global):
+    def _dense_all_templates(self, image, template_features, template_global, sides=None):
         """Backbone once + head per template chunk -> dense (cls [n_t,A,2], reg [n_t,A,4], seg [n_t,1,H,W],
         heat [n_t,1,hh,hw], feature-map shape). No host syncs, no data-dependent shapes: capturable in a hipGraph."""
         if self.use_fused_backbone and image.is_cuda and not self.training:
@@ -446,9 +463,9 @@ class Network(nn.Module):
             features = self.image_feature_extractor(image, template_global)
         fused = self._fused_head() if (self.use_fused_head and features.is_cuda and not self.training) else None
         cls_out, reg_out, seg_out, heat_out = [], [], [], []
-        for chunk in template_features:
+        for ci, chunk in enumerate(template_features):
             if fused is not None:
-                xc, heat, seg = fused.correlation(features, chunk)
+                xc, heat, seg = fused.correlation(features, chunk, None if sides is None else sides[ci])
                 cls_out.append(fused.classification(xc))
                 reg_out.append(fused.regression(xc))
             else:
@@ -457,8 +474,8 @@ class Network(nn.Module):
                 reg_out.append(self.regression(xc))
             seg_out.append(seg)
             heat_out.append(heat)
-        return (torch.cat(cls_out, 0), torch.cat(reg_out, 0), torch.cat(seg_out, 0), torch.cat(heat_out, 0),
-                (xc.size(2), xc.size(3)))
+        cat = lambda parts: parts[0] if len(parts) == 1 else torch.cat(parts, 0)   # noqa: E731  (one chunk: no copy)
+        return (cat(cls_out), cat(reg_out), cat(seg_out), cat(heat_out), (xc.size(2), xc.size(3)))
 
     def _graphed_dense(self, image, template_features, template_global):
         """The dense part replayed from a captured hipGraph (the B=1 backbone alone is ~500 launches and otherwise
@@ -477,20 +494,30 @@ class Network(nn.Module):
             s_g = template_global.clone()
             side = torch.cuda.Stream(device=image.device)
             side.wait_stream(torch.cuda.current_stream())
+            # the template-only part of the correlation lives OUTSIDE the graph, in static buffers refreshed only when the
+            # templates or the weights change (below)
+            s_sides = [fused.template_side(c) for c in s_tf] if fused is not None else None
             with torch.cuda.stream(side):           # warm-up off the capture: MIOpen picks its kernels here
                 for _ in range(2):
-                    self._dense_all_templates(s_img, s_tf, s_g)
+                    self._dense_all_templates(s_img, s_tf, s_g, s_sides)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                outs = self._dense_all_templates(s_img, s_tf, s_g)
-            entry = (graph, s_img, s_tf, s_g, outs, (fused, fused_bb))
+                outs = self._dense_all_templates(s_img, s_tf, s_g, s_sides)
+            entry = [graph, s_img, s_tf, s_g, outs, (fused, fused_bb), s_sides, None]
             cache[key] = entry
-        graph, s_img, s_tf, s_g, outs, _ = entry
+        graph, s_img, s_tf, s_g, outs, _, s_sides, last = entry
         s_img.copy_(image)
         s_g.copy_(template_global)
-        for dst, src in zip(s_tf, template_features):
-            dst.copy_(src)
+        src_key = (tuple((c.data_ptr(), c._version) for c in template_features), self.__dict__.get("_plan_epoch", 0))
+        if src_key != last:
+            for dst, src in zip(s_tf, template_features):
+                dst.copy_(src)
+            if s_sides is not None:
+                for bufs, c in zip(s_sides, s_tf):
+                    for dst, src in zip(bufs, fused.template_side(c)):
+                        dst.copy_(src)
+            entry[7] = src_key
         graph.replay()
         return outs
 
