@@ -555,30 +555,50 @@ __global__ __launch_bounds__(256, 2) void sa1_kernel(const float* __restrict__ p
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
     const int row = scatter_row(lane);
+    // The gather of a centre's 64 samples is two dependent global loads (ball index -> feature row): it is issued one
+    // centre AHEAD -- the indices under the current centre's first layers, the rows under its last layer -- so that a
+    // wave never sits on ~2 memory latencies between centres.
+    const int centre0 = (blockIdx.x * 4 + wave) * SA1_CPW;
+    if (centre0 >= total) return;
+    int i_n[2];
+    float4 r_n[2];
+    float cn[3];
+    auto fetch_index = [&](int ce) {
+        i_n[0] = ball[(size_t)ce * 64 + c];
+        i_n[1] = ball[(size_t)ce * 64 + 32 + c];
+        cn[0] = cxyz[(size_t)ce * 3], cn[1] = cxyz[(size_t)ce * 3 + 1], cn[2] = cxyz[(size_t)ce * 3 + 2];
+    };
+    auto fetch_rows = [&](int ce) {
+        const size_t base = (size_t)(ce / np) * M;
+        r_n[0] = *(const float4*)(point_x + (base + i_n[0]) * 8 + 4 * h);
+        r_n[1] = *(const float4*)(point_x + (base + i_n[1]) * 8 + 4 * h);
+    };
+    fetch_index(centre0);
+    fetch_rows(centre0);
 #pragma unroll 1
     for (int cw = 0; cw < SA1_CPW; ++cw) {
-        const int centre = (blockIdx.x * 4 + wave) * SA1_CPW + cw;
+        const int centre = centre0 + cw;
         if (centre >= total) break;
-        const int n = centre / np;
-        const float cx = cxyz[(size_t)centre * 3], cy = cxyz[(size_t)centre * 3 + 1], cz = cxyz[(size_t)centre * 3 + 2];
+        const int next = min(centre + 1, total - 1);          // (the last centre prefetches itself: harmless)
         const float* w = wl + opaque_zero();   // per-iteration laundering (see opaque_zero)
         float4 x[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #ifdef OSSID_ABL_NOGATHER
             float4 r = make_float4(lane * 1e-3f + t, 0.1f * cw, 0.2f, 0.3f);
-            (void)n;
 #else
-            int i = ball[(size_t)centre * 64 + t * 32 + c];
-            float4 r = *(const float4*)(point_x + ((size_t)n * M + i) * 8 + 4 * h);
+            float4 r = r_n[t];
 #endif
             if (h == 0) {
-                r.x = r.x - cx;
-                r.y = r.y - cy;
-                r.z = r.z - cz;
+                r.x = r.x - cn[0];
+                r.y = r.y - cn[1];
+                r.z = r.z - cn[2];
             }
             x[t] = r;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_index(next);
+        __builtin_amdgcn_sched_barrier(0);
         v16f Y1[2][2], Y2[2][2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -598,6 +618,9 @@ __global__ __launch_bounds__(256, 2) void sa1_kernel(const float* __restrict__ p
             Y2[1][mt] = relu16(acc[1]);
         });
         float* out = feat + (size_t)centre * 128 + c;
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_rows(next);
+        __builtin_amdgcn_sched_barrier(0);
         stream_last_layer<2, 2, 4>((const float4*)(w + SA1_W3) + lane, w + SA1_B3, Y2, c, 4,
                                    [&](int mt, v16f(&acc)[2]) {
 #ifdef OSSID_ABL_NOEPI
