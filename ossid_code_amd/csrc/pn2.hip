@@ -185,7 +185,10 @@ __device__ __forceinline__ float pool_swapped(const v16f& a) {
     float m2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11]));
     float m3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
     float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-    m = fmaxf(m, __shfl_xor(m, 32));
+    // the other lane half's value: v_permlane32_swap (gfx950) is a plain VALU op; __shfl_xor(m, 32) goes through the LDS
+    // crossbar (ds_bpermute: address VGPR, lgkmcnt wait) in the middle of an MFMA stream
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
     return fmaxf(m, 0.0f);
 }
 
