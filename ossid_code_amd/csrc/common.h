@@ -23,3 +23,18 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
     return v;
 }
+
+// LDS-DMA of one 1 KB quad image, issued from INLINE ASM: through the builtin hipcc knows an LDS write is in flight and
+// puts s_waitcnt vmcnt(0) in front of the next ds_read of ANY LDS address -- draining the chunk that was just issued
+// and exposing its whole L2 latency every step. The asm form is invisible to that bookkeeping (and to its vmcnt counts,
+// which stay conservative); completion is waited for by hand (lds_dma_wait_all) before the barrier that publishes it.
+__device__ __forceinline__ void lds_dma_quad(const void* g, float* lds_wave_base) {
+    unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+    dst = __builtin_amdgcn_readfirstlane(dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(dst)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

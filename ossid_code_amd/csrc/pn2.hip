@@ -693,10 +693,6 @@ constexpr int SA2_W3 = 0, SA2_B3 = 32768, SA2_B2 = SA2_B3 + 256, SA2_WX = SA2_B2
               SA2_KEEP = SA2_RING + 2 * SA2_CHUNK,
               SA2_LDS_FLOATS = SA2_KEEP + 8 * 256;   // W3p 128 KB | b3 | b2 | wxyz | ring 16 KB | keep 8 KB = 158 720 B
 
-__device__ __forceinline__ void lds_dma_quad(const float4* g, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 __global__ __launch_bounds__(SA2_THREADS, 2) void sa2_kernel(const float* __restrict__ P, const float* __restrict__ xyz1,
                                                              int np1, const int* __restrict__ ball,
@@ -749,8 +745,8 @@ __global__ __launch_bounds__(SA2_THREADS, 2) void sa2_kernel(const float* __rest
         v16f acc;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            __syncthreads();          // chunk g has landed in slot g&1 (every wave waited for its own piece) and
-                                      // nobody reads slot (g+1)&1 any more
+            lds_dma_wait_all();       // this wave's piece of chunk g (issued a chunk ago) has landed ...
+            __syncthreads();          // ... everyone's has, and nobody reads slot (g+1)&1 any more
             if (!(it == NTILE - 1 && g == 7))
                 lds_dma_quad(W2q + (size_t)(((g + 1) & 7) * 8) * 64, ring_mine + ((g + 1) & 1) * SA2_CHUNK);
             if (g == 0) {

@@ -37,6 +37,10 @@ def main():
         B = a.nt
         x = torch.randn(B, ci, h, w, device="cuda").contiguous(memory_format=torch.channels_last)
         cv = torch.nn.Conv2d(ci, co, 3, padding=1).cuda()
+        if os.environ.get("OSSID_AB_ZEROS"):          # all-zero operands: how much of the rate is a power / clock matter?
+            x.zero_()
+            with torch.no_grad():
+                cv.weight.zero_()
         pk = ops.PackedConv3x3(cv)
         t = timeit(lambda: pk(x))
         fl = 2.0 * B * h * w * co * ci * 9
