@@ -482,3 +482,32 @@ def test_dw_xcorr_channels_last_broadcast_matches_grouped_conv(hiplib):
     want = dtoid_oracle.dw_xcorr(x.cpu().expand(5, -1, -1, -1), k.cpu())
     assert got.shape == (5, 24, 9, 13) and got.is_contiguous(memory_format=torch.channels_last)
     assert close(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_c_abi_rejects_bad_arguments_without_launching(hiplib):
+    """The boundary's error convention (include/ossid_hip.h): a negative status for arguments a kernel could not take --
+    checked on the host, before anything is launched -- and OK for empty work."""
+    from ctypes import byref as C_byref
+    from ossid_code_amd import _lib
+    buf = torch.zeros(1 << 16, device="cuda")
+    p, s = buf.data_ptr(), _lib.stream()
+    d = _lib.ConvDesc()
+    d.x = d.wpk = d.out = p
+    d.batch, d.height, d.width, d.cin, d.cout, d.taps, d.in_batch_stride = 1, 8, 8, 24, 32, 9, -1     # cin % 16 != 0
+    assert _lib.fn("ossid_conv_nhwc_fwd")(C_byref(d), s) < 0
+    d.cin, d.taps = 32, 4                                                                               # 2x2 kernels: not built
+    assert _lib.fn("ossid_conv_nhwc_fwd")(C_byref(d), s) < 0
+    d.taps, d.out = 9, None                                                                             # null output
+    assert _lib.fn("ossid_conv_nhwc_fwd")(C_byref(d), s) < 0
+    d.out, d.batch = p, 0                                                                               # empty batch: fine
+    assert _lib.fn("ossid_conv_nhwc_fwd")(C_byref(d), s) == 0
+    # fused decoder tail: no up-sampling -> the source footprint does not fit the staged patch
+    assert _lib.fn("ossid_seg_tail_fwd")(p, 1, 32, 32, 32, 32, 32, p, p, p, p, p, p, p, s) < 0
+    assert _lib.fn("ossid_seg_tail_fwd")(p, 0, 16, 16, 32, 32, 32, p, p, p, p, p, p, p, s) == 0
+    assert _lib.fn("ossid_gather_rows")(p, 4, 6, p, 2, 0, p, s) < 0                                     # rows % 4 != 0
+    assert _lib.fn("ossid_gather_rows")(p, 4, 8, p, 0, 0, p, s) == 0
+    assert _lib.fn("ossid_dw_xcorr_nhwc_bcast")(p, p, 2, 6, 4, 4, p, s) < 0                             # channels % 4 != 0
+    assert _lib.fn("ossid_nms")(p, -1, 0.5, p, 1 << 16, p, p, s) < 0
+    assert _lib.fn("ossid_nms")(p, 100, 0.5, p, 8, p, p, s) < 0                                         # workspace too small
+    torch.cuda.synchronize()
