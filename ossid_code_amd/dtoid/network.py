@@ -514,8 +514,16 @@ class Network(nn.Module):
             for dst, src in zip(s_tf, template_features):
                 dst.copy_(src)
             if s_sides is not None:
-                for bufs, c in zip(s_sides, s_tf):
-                    for dst, src in zip(bufs, fused.template_side(c)):
+                # per object (= per set of template tensors) the template-only tensors are computed once and kept: a loop
+                # over the objects of a scene only pays the small copies into the graph's static buffers
+                sc = self.__dict__.setdefault("_side_cache", {})
+                sides = sc.get(src_key)
+                if sides is None:
+                    if len(sc) >= 64:
+                        sc.clear()
+                    sides = sc[src_key] = [[t.clone() for t in fused.template_side(c)] for c in template_features]
+                for bufs, vals in zip(s_sides, sides):
+                    for dst, src in zip(bufs, vals):
                         dst.copy_(src)
             entry[7] = src_key
         graph.replay()
