@@ -511,3 +511,30 @@ def test_c_abi_rejects_bad_arguments_without_launching(hiplib):
     assert _lib.fn("ossid_nms")(p, -1, 0.5, p, 1 << 16, p, p, s) < 0
     assert _lib.fn("ossid_nms")(p, 100, 0.5, p, 8, p, p, s) < 0                                         # workspace too small
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_fused_test_time_path_at_the_reference_default_480x480(hiplib):
+    """Network's own default geometry (network.py:381: img 480x480, heat map 29x29 -> 20 184 anchors): the fused + graphed
+    dense path against the nn.Module path, two template chunks, the decoder tail at a different up-sampling ratio."""
+    torch.manual_seed(9)
+    net = dtoid.Network().cuda().eval()
+    assert net.img_size == (480, 480) and net.heatmap_size == (29, 29)
+    with torch.no_grad():
+        for conv in (net.classification.output, net.regression.output, net.correlation_model.seg_final,
+                     net.correlation_model.corr_conv_heatmap):
+            conv.weight.normal_(0, 0.05)
+        img = torch.rand(1, 3, 480, 480, device="cuda")
+        tm = torch.rand(5, 4, 124, 124, device="cuda")
+        g = net.compute_template_global(tm[:1])
+        loc = [net.compute_template_local(tm[:3]), net.compute_template_local(tm[3:])]
+        net.use_fused_head = net.use_fused_backbone = net.use_graph = False
+        ref = net._dense_all_templates(img, loc, g)
+        net.use_fused_head = net.use_fused_backbone = net.use_graph = True
+        got = net._graphed_dense(img, loc, g)
+        got2 = net._graphed_dense(img, loc, g)                 # replay with unchanged templates: cached template side
+    assert got[0].shape == (5, 20184, 2) and got[2].shape == (5, 1, 480, 480) and got[3].shape == (5, 1, 29, 29)
+    for name, a, b, c in zip(("cls", "reg", "seg", "heat"), got[:4], ref[:4], got2[:4]):
+        scale = float(b.abs().max().clamp(min=1e-6))
+        assert float((a - b).abs().max()) / scale < 2e-4, name
+        assert torch.equal(a, c), name
