@@ -214,6 +214,15 @@ size_t ossid_nms_workspace_bytes(int n);
 int ossid_nms(const float* boxes, int n, float iou_threshold, void* workspace, size_t workspace_bytes,
               int32_t* keep, int32_t* num_keep, void* stream);
 
+/* D6  `norm(F.elu(conv(image_feat - avg_t)))` (network.py:346) for ONE image against all templates without a convolution
+ * per template: conv is linear, so conv(x - a_t) = conv(x) - conv(a_t). S [H][W][channels] = conv(x) + bias, computed
+ * once per frame; csub [templates][9][channels] = the response to the per-channel constant image a_t for each of the 9
+ * border patterns p = 3*rowclass + colclass (class 0: first row/column, 1: interior, 2: last), one small GEMM per object.
+ * out[t][y][x][out_channel_offset + o] = post(ELU(S[y][x][o] - csub[t][p(y,x)][o])). H, W >= 2; channels % 4 == 0. */
+int ossid_bcast_sub_epilogue(const float* S, const float* csub, int templates, int H, int W, int channels,
+                             const float* post_scale, const float* post_shift, float* out, int out_channel_stride,
+                             int out_channel_offset, void* stream);
+
 /* D12/D13  out[j][:] = src[idx[j]][:] for j < k, rows of row_floats (% 4 == 0) floats, with sigmoid applied on the way
  * when apply_sigmoid != 0: the per-detection segmentation maps gathered from the per-template ones
  * (network.py:575-579) + `torch.sigmoid(seg)` (models/dtoid/__init__.py:147) in one pass. idx: int64, each in

@@ -189,6 +189,34 @@ __global__ __launch_bounds__(256) void dw_xcorr_nhwc_kernel(const float4* __rest
     out[i] = acc;
 }
 
+// ---- conv(image - avg_t) without the convolution: conv is linear, so conv(x - a_t) = conv(x) - conv(a_t), the first term
+// is the SAME for every template (one batch-1 convolution per frame instead of one per template) and the second is the
+// response to a per-channel constant image: a per-template vector for each of the 9 border patterns (which taps fall
+// inside the frame), one tiny GEMM per object (`csub`). This kernel finishes `norm(F.elu(conv(image_feat - avg)))` of
+// network.py:346 for all templates: out[t][px][coff + o] = post(ELU(S[px][o] - csub[t][pattern(px)][o])), S with bias.
+__global__ __launch_bounds__(256) void bcast_sub_epilogue_kernel(const float4* __restrict__ S, const float4* __restrict__ csub,
+                                                                 int C4, int H, int W, size_t total,
+                                                                 const float4* __restrict__ sc, const float4* __restrict__ sh,
+                                                                 float* __restrict__ out, int out_cs, int out_coff) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int o4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int px = (int)(r % ((size_t)H * W)), t = (int)(r / ((size_t)H * W));
+    const int y = px / W, x = px - y * W;
+    const int pat = (y == 0 ? 0 : (y == H - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x == W - 1 ? 2 : 1));
+    const float4 s = S[(size_t)px * C4 + o4], c = csub[((size_t)t * 9 + pat) * C4 + o4];
+    float v[4] = {s.x - c.x, s.y - c.y, s.z - c.z, s.w - c.w};
+    const float4 a = sc ? sc[o4] : make_float4(1.f, 1.f, 1.f, 1.f), b = sh ? sh[o4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float u = v[k] > 0.0f ? v[k] : expm1f(v[k]);
+        v[k] = u * av[k] + bv[k];
+    }
+    *(float4*)(out + ((size_t)t * H * W + px) * out_cs + out_coff + 4 * o4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // ---- row gather (+ sigmoid): out[k][:] = f(src[idx[k]][:]) -- the per-detection segmentation maps picked out of the
 // per-template ones (network.py:575-579) with the sigmoid of dtoid/__init__.py:147 applied on the way, one pass instead of
 // a gather and an elementwise kernel over up to 500 x 480 x 640 floats
@@ -338,6 +366,22 @@ int ossid_nms(const float* boxes, int n, float iou_threshold, void* workspace, s
     } else {
         hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)words * 8, s, mask, n, words, keep, num_keep);
     }
+    return ossid_launch_status();
+}
+
+int ossid_bcast_sub_epilogue(const float* S, const float* csub, int templates, int H, int W, int channels,
+                             const float* post_scale, const float* post_shift, float* out, int out_channel_stride,
+                             int out_channel_offset, void* stream) {
+    if (templates < 0 || H < 2 || W < 2 || channels <= 0 || (channels % 4) || (out_channel_stride % 4) ||
+        (out_channel_offset % 4) || out_channel_stride < out_channel_offset + channels)
+        return OSSID_EINVAL;
+    if (templates == 0) return OSSID_OK;
+    if (!S || !csub || !out || (post_scale && !post_shift)) return OSSID_EINVAL;
+    const size_t total = (size_t)templates * H * W * (channels / 4);
+    if ((total + 255) / 256 > 0x7fffffffull) return OSSID_EINVAL;
+    hipLaunchKernelGGL(bcast_sub_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)S, (const float4*)csub, channels / 4, H, W, total, (const float4*)post_scale,
+                       (const float4*)post_shift, out, out_channel_stride, out_channel_offset);
     return ossid_launch_status();
 }
 

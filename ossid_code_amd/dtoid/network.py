@@ -227,6 +227,8 @@ class FusedHead:
         self.corr = corr
         self.dot = P(corr.corr_conv_dot, corr.norm_corr_dot, act=True)
         self.sub = P(corr.corr_conv_sub, corr.norm_corr_sub, act=True)
+        self.sub_raw = P(corr.corr_conv_sub)                  # conv + bias only: the template-independent half of `sub`
+        self._sub_wsum = None
         self.dot3 = P(corr.corr_conv_dot3x3, corr.norm_corr_dot3x3, act=True)
         self.cf = P(corr.cf, corr.nf, act=True)
         self.seg = [P(getattr(corr, "s%d" % i), getattr(corr, "ns%d" % i), act=True) for i in (1, 2, 3, 4, 5)]
@@ -236,8 +238,19 @@ class FusedHead:
         self.num_classes = cls.num_classes
 
     def refresh(self):
-        for pk in [self.dot, self.sub, self.dot3, self.cf, self.tail] + self.seg + self.cls + self.reg:
+        for pk in [self.dot, self.sub, self.sub_raw, self.dot3, self.cf, self.tail] + self.seg + self.cls + self.reg:
             pk.refresh()
+        self._sub_wsum = None
+
+    def sub_wsum(self):
+        """[640, 9*256]: for each border pattern p = 3*rowclass + colclass the weights of corr_conv_sub summed over the taps
+        that fall inside the frame (class 0: first row/column -> tap 0 is outside; 2: last -> tap 2 is outside)."""
+        if self._sub_wsum is None:
+            w = self.corr.corr_conv_sub.weight.detach().float()                  # [256, 640, 3, 3]
+            sel = ([1, 2], [0, 1, 2], [0, 1])
+            parts = [w[:, :, sel[rc]][:, :, :, sel[cc]].sum((2, 3)) for rc in range(3) for cc in range(3)]   # 9 x [256, 640]
+            self._sub_wsum = torch.stack(parts, 0).permute(2, 0, 1).reshape(w.shape[1], -1).contiguous()
+        return self._sub_wsum
 
     _TENSORS = {}
 
@@ -263,11 +276,12 @@ class FusedHead:
         t2 = corr._cab(corr.c2, corr.n2, corr._cab(corr.c1, corr.n1, template_feat)).contiguous()
         avg = F.avg_pool2d(template_feat, 7)
         a2 = avg.reshape(avg.shape[0], avg.shape[1]).float().contiguous()
-        return [t2, avg, a2, -a2]
+        csub = (a2 @ self.sub_wsum()).contiguous()            # [n_t, 9*256]: conv_sub's response to the constant image a_t
+        return [t2, avg, a2, csub]
 
     def correlation(self, image_feat, template_feat, side=None):
         corr = self.corr
-        t2, avg, a2, neg_a2 = self.template_side(template_feat) if side is None else side
+        t2, avg, a2, csub = self.template_side(template_feat) if side is None else side
         bcast = image_feat.shape[0] == 1 and image_feat.is_cuda and image_feat.shape[1] % 4 == 0
         dot3x3 = None if bcast else ops.dw_xcorr(image_feat, t2)
         if bcast:
@@ -282,7 +296,17 @@ class FusedHead:
             ctot = self.dot.cout + self.sub.cout + self.dot3.cout
             x = torch.empty((B, ctot, H, W), dtype=torch.float32, device=xin.device, memory_format=torch.channels_last)
             self.dot.run(xin, B, H, W, x, out_cs=ctot, out_coff=0, in_bs=0, pre=(a2, zeros))
-            self.sub.run(xin, B, H, W, x, out_cs=ctot, out_coff=self.dot.cout, in_bs=0, pre=(ones, neg_a2))
+            if H >= 2 and W >= 2:       # conv(image - avg_t) = conv(image) - conv(avg_t): ONE convolution per frame
+                S = torch.empty((1, self.sub.cout, H, W), dtype=torch.float32, device=xin.device,
+                                memory_format=torch.channels_last)
+                self.sub_raw.run(xin, 1, H, W, S)
+                with torch.cuda.device(xin.device):
+                    rc = ops._lib.fn("ossid_bcast_sub_epilogue")(
+                        S.data_ptr(), csub.data_ptr(), B, H, W, self.sub.cout, self.sub.scale.data_ptr(),
+                        self.sub.shift.data_ptr(), x.data_ptr(), ctot, self.dot.cout, ops._lib.stream())
+                ops._lib.check(rc, "ossid_bcast_sub_epilogue")
+            else:
+                self.sub.run(xin, B, H, W, x, out_cs=ctot, out_coff=self.dot.cout, in_bs=0, pre=(ones, -a2))
             d3 = ops.dw_xcorr_nhwc_bcast(xin, t2)             # born channels-last: no transposing copy
             self.dot3.run(d3, B, H, W, x, out_cs=ctot, out_coff=self.dot.cout + self.sub.cout)
         else:
