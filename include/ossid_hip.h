@@ -223,6 +223,17 @@ int ossid_bcast_sub_epilogue(const float* S, const float* csub, int templates, i
                              const float* post_scale, const float* post_shift, float* out, int out_channel_stride,
                              int out_channel_offset, void* stream);
 
+/* D6  `conv(image_feat * avg_t)` (network.py:345) with the channel contraction last, for MANY templates against one image:
+ * ossid_dot_expand builds G[c][y][x][o] = sum_taps w[o][c][tap] * x[y+dy][x+dx][c] (zero padding) from the channels-last
+ * image x [H][W][channels] and the weights re-laid as w_cto [channels][9][cout]; the caller then contracts
+ * z[t][(y,x,o)] = sum_c avg_t[c] * G[c][(y,x,o)] with a library GEMM and finishes with ossid_bias_elu_affine_slice:
+ * out[r][out_channel_offset + o] = post(ELU(z[r][o] + bias[o])), rows r = (template, pixel). cout % 4 == 0,
+ * 256 % (cout/4) == 0. G is channels * H * W * cout floats (0.74 GB for 640 x 29 x 39 x 256): caller-owned. */
+int ossid_dot_expand(const float* x, const float* w_cto, int channels, int cout, int H, int W, float* G, void* stream);
+int ossid_bias_elu_affine_slice(const float* z, long long rows, int channels, const float* bias, const float* post_scale,
+                                const float* post_shift, float* out, int out_channel_stride, int out_channel_offset,
+                                void* stream);
+
 /* D12/D13  out[j][:] = src[idx[j]][:] for j < k, rows of row_floats (% 4 == 0) floats, with sigmoid applied on the way
  * when apply_sigmoid != 0: the per-detection segmentation maps gathered from the per-template ones
  * (network.py:575-579) + `torch.sigmoid(seg)` (models/dtoid/__init__.py:147) in one pass. idx: int64, each in

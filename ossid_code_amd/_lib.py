@@ -68,6 +68,8 @@ _PROTOS = {
     "ossid_nms": (_i, [_vp, _i, _f, _vp, _sz, _vp, _vp, _vp]),
     "ossid_decode_clip_boxes": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     "ossid_gather_rows": (_i, [_vp, _i, C.c_longlong, _vp, _i, _i, _vp, _vp]),
+    "ossid_dot_expand": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ossid_bias_elu_affine_slice": (_i, [_vp, C.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ossid_bcast_sub_epilogue": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "ossid_amsgrad_step": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp]),
 }

@@ -217,6 +217,60 @@ __global__ __launch_bounds__(256) void bcast_sub_epilogue_kernel(const float4* _
     *(float4*)(out + ((size_t)t * H * W + px) * out_cs + out_coff + 4 * o4) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// ---- conv(image * avg_t) with the channel contraction LAST: out_t[px][o] = sum_c avg_t[c] * G[c][px][o],
+// G[c][px][o] = sum_taps W[o][c][tap] * x[px + tap][c] (zero outside the frame). G does not depend on the template, so for
+// many templates a 640-deep GEMM per template (library GEMM on G viewed as [C][HW*Cout]) replaces a 5 760-deep
+// convolution per template (network.py:345). This kernel builds G: one workgroup per (channel, 64-pixel run); a thread
+// keeps the 9 taps of its four output channels in registers and walks the pixels; 16-byte stores, 1 KB per pixel row.
+__global__ __launch_bounds__(256) void dot_expand_kernel(const float* __restrict__ x, const float4* __restrict__ wg,
+                                                         int C, int Cout4, int H, int W, float4* __restrict__ G) {
+    const int c = blockIdx.y, o4 = threadIdx.x % Cout4, pl = threadIdx.x / Cout4, np = 256 / Cout4;
+    const int HW = H * W;
+    float4 w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = wg[((size_t)c * 9 + t) * Cout4 + o4];
+    const int p0 = blockIdx.x * 64;
+    for (int p = p0 + pl; p < min(p0 + 64, HW); p += np) {
+        const int y = p / W, xx = p - y * W;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xq = xx + dx - 1;
+                if (xq < 0 || xq >= W) continue;
+                const float f = x[((size_t)yy * W + xq) * C + c];
+                const float4 ww = w[dy * 3 + dx];
+                acc.x = fmaf(ww.x, f, acc.x), acc.y = fmaf(ww.y, f, acc.y), acc.z = fmaf(ww.z, f, acc.z), acc.w = fmaf(ww.w, f, acc.w);
+            }
+        }
+        G[((size_t)c * HW + p) * Cout4 + o4] = acc;
+    }
+}
+
+// out[t][px][coff + o] = post(ELU(z[t][px][o] + bias[o])): the epilogue behind the GEMM above
+__global__ __launch_bounds__(256) void bias_elu_affine_slice_kernel(const float4* __restrict__ z, const float4* __restrict__ bias,
+                                                                    const float4* __restrict__ sc, const float4* __restrict__ sh,
+                                                                    int C4, size_t rows, float* __restrict__ out, int out_cs,
+                                                                    int out_coff) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * C4) return;
+    const int o4 = (int)(i % C4);
+    const size_t r = i / C4;
+    const float4 v4 = z[i], b = bias ? bias[o4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 a = sc ? sc[o4] : make_float4(1.f, 1.f, 1.f, 1.f), s = sh ? sh[o4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float v[4] = {v4.x + b.x, v4.y + b.y, v4.z + b.z, v4.w + b.w};
+    const float av[4] = {a.x, a.y, a.z, a.w}, sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float u = v[k] > 0.0f ? v[k] : expm1f(v[k]);
+        v[k] = u * av[k] + sv[k];
+    }
+    *(float4*)(out + r * out_cs + out_coff + 4 * o4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // ---- row gather (+ sigmoid): out[k][:] = f(src[idx[k]][:]) -- the per-detection segmentation maps picked out of the
 // per-template ones (network.py:575-579) with the sigmoid of dtoid/__init__.py:147 applied on the way, one pass instead of
 // a gather and an elementwise kernel over up to 500 x 480 x 640 floats
@@ -382,6 +436,31 @@ int ossid_bcast_sub_epilogue(const float* S, const float* csub, int templates, i
     hipLaunchKernelGGL(bcast_sub_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)S, (const float4*)csub, channels / 4, H, W, total, (const float4*)post_scale,
                        (const float4*)post_shift, out, out_channel_stride, out_channel_offset);
+    return ossid_launch_status();
+}
+
+int ossid_dot_expand(const float* x, const float* w_cto, int channels, int cout, int H, int W, float* G, void* stream) {
+    if (channels <= 0 || cout <= 0 || (cout % 4) || 256 % (cout / 4) || cout / 4 > 256 || H <= 0 || W <= 0 || channels > 65535)
+        return OSSID_EINVAL;
+    if (!x || !w_cto || !G) return OSSID_EINVAL;
+    hipLaunchKernelGGL(dot_expand_kernel, dim3((H * W + 63) / 64, channels), dim3(256), 0, (hipStream_t)stream, x,
+                       (const float4*)w_cto, channels, cout / 4, H, W, (float4*)G);
+    return ossid_launch_status();
+}
+
+int ossid_bias_elu_affine_slice(const float* z, long long rows, int channels, const float* bias, const float* post_scale,
+                                const float* post_shift, float* out, int out_channel_stride, int out_channel_offset,
+                                void* stream) {
+    if (rows < 0 || channels <= 0 || (channels % 4) || (out_channel_stride % 4) || (out_channel_offset % 4) ||
+        out_channel_stride < out_channel_offset + channels || (post_scale && !post_shift))
+        return OSSID_EINVAL;
+    if (rows == 0) return OSSID_OK;
+    if (!z || !out) return OSSID_EINVAL;
+    const size_t total = (size_t)rows * (channels / 4);
+    if ((total + 255) / 256 > 0x7fffffffull) return OSSID_EINVAL;
+    hipLaunchKernelGGL(bias_elu_affine_slice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)z, (const float4*)bias, (const float4*)post_scale, (const float4*)post_shift,
+                       channels / 4, (size_t)rows, out, out_channel_stride, out_channel_offset);
     return ossid_launch_status();
 }
 

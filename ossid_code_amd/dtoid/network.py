@@ -228,7 +228,8 @@ class FusedHead:
         self.dot = P(corr.corr_conv_dot, corr.norm_corr_dot, act=True)
         self.sub = P(corr.corr_conv_sub, corr.norm_corr_sub, act=True)
         self.sub_raw = P(corr.corr_conv_sub)                  # conv + bias only: the template-independent half of `sub`
-        self._sub_wsum = None
+        self._sub_wsum = self._dot_wcto = None
+        self._fill_derived()
         self.dot3 = P(corr.corr_conv_dot3x3, corr.norm_corr_dot3x3, act=True)
         self.cf = P(corr.cf, corr.nf, act=True)
         self.seg = [P(getattr(corr, "s%d" % i), getattr(corr, "ns%d" % i), act=True) for i in (1, 2, 3, 4, 5)]
@@ -240,16 +241,32 @@ class FusedHead:
     def refresh(self):
         for pk in [self.dot, self.sub, self.sub_raw, self.dot3, self.cf, self.tail] + self.seg + self.cls + self.reg:
             pk.refresh()
-        self._sub_wsum = None
+        self._fill_derived()
 
-    def sub_wsum(self):
-        """[640, 9*256]: for each border pattern p = 3*rowclass + colclass the weights of corr_conv_sub summed over the taps
-        that fall inside the frame (class 0: first row/column -> tap 0 is outside; 2: last -> tap 2 is outside)."""
-        if self._sub_wsum is None:
-            w = self.corr.corr_conv_sub.weight.detach().float()                  # [256, 640, 3, 3]
+    DOT_GEMM_MIN_TEMPLATES = 40     # from here on the channel-contraction-last form of `dot` wins (0.74 GB of G per frame)
+
+    def _fill_derived(self):
+        """Weight re-layouts the linearity tricks need, (re)written IN PLACE (a captured graph reads `_dot_wcto`):
+        _dot_wcto [c][tap][o]: corr_conv_dot for ossid_dot_expand;
+        _sub_wsum [640, 9*256]: for each border pattern p = 3*rowclass + colclass the weights of corr_conv_sub summed over the
+        taps that fall inside the frame (class 0: first row/column -> tap 0 is outside; 2: last -> tap 2 is outside)."""
+        with torch.no_grad():
+            w = self.corr.corr_conv_dot.weight.detach().float()                  # [256, 640, 3, 3]
+            wcto = w.permute(1, 2, 3, 0).reshape(w.shape[1], 9, w.shape[0])
+            w = self.corr.corr_conv_sub.weight.detach().float()
             sel = ([1, 2], [0, 1, 2], [0, 1])
             parts = [w[:, :, sel[rc]][:, :, :, sel[cc]].sum((2, 3)) for rc in range(3) for cc in range(3)]   # 9 x [256, 640]
-            self._sub_wsum = torch.stack(parts, 0).permute(2, 0, 1).reshape(w.shape[1], -1).contiguous()
+            wsum = torch.stack(parts, 0).permute(2, 0, 1).reshape(w.shape[1], -1)
+            if self._dot_wcto is None:
+                self._dot_wcto, self._sub_wsum = wcto.contiguous(), wsum.contiguous()
+            else:
+                self._dot_wcto.copy_(wcto)
+                self._sub_wsum.copy_(wsum)
+
+    def dot_wcto(self):
+        return self._dot_wcto
+
+    def sub_wsum(self):
         return self._sub_wsum
 
     _TENSORS = {}
@@ -295,7 +312,21 @@ class FusedHead:
             ones, zeros = self._const(a2)
             ctot = self.dot.cout + self.sub.cout + self.dot3.cout
             x = torch.empty((B, ctot, H, W), dtype=torch.float32, device=xin.device, memory_format=torch.channels_last)
-            self.dot.run(xin, B, H, W, x, out_cs=ctot, out_coff=0, in_bs=0, pre=(a2, zeros))
+            if B >= self.DOT_GEMM_MIN_TEMPLATES and self.dot.cout % 4 == 0 and 256 % (self.dot.cout // 4) == 0:
+                # conv(image * avg_t) = sum_c avg_t[c] * G[c]: G once per frame, then ONE [B x C] x [C x HW*Cout] GEMM
+                C = int(xin.shape[1])
+                G = torch.empty((C, H * W * self.dot.cout), dtype=torch.float32, device=xin.device)
+                with torch.cuda.device(xin.device):
+                    ops._lib.check(ops._lib.fn("ossid_dot_expand")(xin.data_ptr(), self.dot_wcto().data_ptr(), C,
+                                                                   self.dot.cout, H, W, G.data_ptr(), ops._lib.stream()),
+                                   "ossid_dot_expand")
+                    z = a2 @ G                                                   # [B, HW*Cout] = [t][px][o]
+                    ops._lib.check(ops._lib.fn("ossid_bias_elu_affine_slice")(
+                        z.data_ptr(), B * H * W, self.dot.cout, None if self.dot.bias is None else self.dot.bias.data_ptr(),
+                        self.dot.scale.data_ptr(), self.dot.shift.data_ptr(), x.data_ptr(), ctot, 0, ops._lib.stream()),
+                        "ossid_bias_elu_affine_slice")
+            else:
+                self.dot.run(xin, B, H, W, x, out_cs=ctot, out_coff=0, in_bs=0, pre=(a2, zeros))
             if H >= 2 and W >= 2:       # conv(image - avg_t) = conv(image) - conv(avg_t): ONE convolution per frame
                 S = torch.empty((1, self.sub.cout, H, W), dtype=torch.float32, device=xin.device,
                                 memory_format=torch.channels_last)

@@ -538,3 +538,20 @@ def test_fused_test_time_path_at_the_reference_default_480x480(hiplib):
         scale = float(b.abs().max().clamp(min=1e-6))
         assert float((a - b).abs().max()) / scale < 2e-4, name
         assert torch.equal(a, c), name
+
+
+@pytest.mark.gpu
+def test_dot_by_channel_contraction_last_matches_module_path(hiplib):
+    """conv(image * avg_t) as G (taps summed per channel, once per frame) + one GEMM over the channels, the form the fused
+    head switches to for many templates: against the nn.Module correlation on the dense outputs."""
+    torch.manual_seed(4)
+    net = dtoid.Network(img_size=(480, 640), heatmap_size=(29, 39)).cuda().eval()
+    feat = torch.randn(1, 640, 29, 39, device="cuda")
+    tmpl = torch.randn(6, 640, 7, 7, device="cuda")
+    with torch.no_grad():
+        x2r, heatr, segr = net.correlation_model(feat.expand(6, -1, -1, -1), tmpl, True)
+        fused = net._fused_head()
+        fused.DOT_GEMM_MIN_TEMPLATES = 1
+        x2, heat, seg = fused.correlation(feat, tmpl)
+    for name, a, b in (("x2", x2, x2r), ("heat", heat, heatr), ("seg", seg, segr)):
+        assert float((a - b).abs().max() / b.abs().max().clamp(min=1e-6)) < 1e-4, name
