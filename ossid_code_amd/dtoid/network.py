@@ -243,7 +243,8 @@ class FusedHead:
             pk.refresh()
         self._fill_derived()
 
-    DOT_GEMM_MIN_TEMPLATES = 40     # from here on the channel-contraction-last form of `dot` wins (0.74 GB of G per frame)
+    # from this many templates on the channel-contraction-last form of `dot` wins (0.74 GB of G per frame)
+    DOT_GEMM_MIN_TEMPLATES = int(os.environ.get("OSSID_DOT_GEMM_MIN", "16"))
 
     def _fill_derived(self):
         """Weight re-layouts the linearity tricks need, (re)written IN PLACE (a captured graph reads `_dot_wcto`):
