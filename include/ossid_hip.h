@@ -160,6 +160,11 @@ int ossid_dw_xcorr_bwd_k(const float* x, const float* dout, int planes, int H, i
  *        (F.interpolate(mode="nearest") in front of the conv, network.py:354-357).
  * in_channel_stride / out_channel_stride (0 = cin / cout) and out_channel_offset let a layer read the first cin channels of
  *        a wider resident buffer and append its output to it in place (DenseNet concatenation without torch.cat).
+ * taps 4: the four PHASES of a 3x3 / pad 1 convolution applied to a 2x nearest-neighbour up-sampled input (the decoder,
+ *        network.py:354-356): output pixel (2i+a, 2j+b) only sees source pixels (i+a-1, i+a) x (j+b-1, j+b), so each phase
+ *        is a 2x2 convolution of the SOURCE with row/column-merged weights -- 4/9 of the multiply-adds. height/width are
+ *        the SOURCE size, out is [B][2*height][2*width][..]; wpk = four ossid_conv_pack_weights(.., taps 4) sets, phase
+ *        2a+b, of the merged [cout][cin][2][2] kernels (rows: a=0 -> (w0, w1+w2), a=1 -> (w0+w1, w2); columns likewise).
  * cin % 16 == 0; cout, strides and offset % 4 == 0. wpk = ossid_conv_pack_weights(w [cout][cin][kh][kw]). */
 typedef struct ossid_conv_desc {
     const float* x;

@@ -52,16 +52,20 @@ struct ConvArgs {
 // Workgroup = 4 waves = WM (channel tiles) x WK (split of the reduction) x WN (pixel groups), each wave NT pixel tiles.
 // WK > 1 is for small problems (batch-1 backbone layers: a few dozen workgroups in all): the waves of a workgroup
 // share ONE output tile and each walks 1/WK of every channel chunk, the partial accumulators meet in LDS.
-// KCH = channels per LDS chunk (16, or 64 with split-K); NLD = float4 staged per thread per chunk; TAPS = 9 or 1.
+// KCH = channels per LDS chunk (16, or 64 with split-K); NLD = float4 staged per thread per chunk; TAPS = 9 or 1, or
+// 4 = one PHASE of a 3x3 convolution on a 2x nearest-neighbour up-sampled input: output pixel (2i+a, 2j+b) only ever sees
+// source pixels (i+a-1, i+a) x (j+b-1, j+b), so each of the four phases (a,b) is a 2x2 convolution of the SOURCE with
+// row/column-merged weights -- 4/9 of the multiply-adds of convolving the up-sampled image (network.py:354-356). Geometry
+// (H, W, pixel tiles, patch) is the source's; a block's group index carries the phase; outputs go to [2H][2W].
 template <int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
 __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     constexpr int WN = 4 / (WM * WK);
     constexpr int BPX = WN * NT * 32;
     constexpr int F4 = KCH / 4;                 // float4 per patch position
     constexpr int NKB = KCH / 8 / WK;           // 8-channel blocks of a chunk handled by one wave
-    constexpr int KY = TAPS == 9 ? 3 : 1;       // prefetch groups per channel block (3x3: one kernel row each)
-    constexpr int GQ = TAPS == 9 ? 3 : (NKB >= 2 ? 2 : 1);   // weight quads per prefetch group
-    constexpr int GPC = TAPS == 9 ? NKB * 3 : NKB / GQ;      // groups per chunk per wave
+    constexpr int KY = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1);   // prefetch groups per channel block (one kernel row each)
+    constexpr int GQ = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : (NKB >= 2 ? 2 : 1));   // weight quads per prefetch group
+    constexpr int GPC = TAPS == 9 ? NKB * 3 : (TAPS == 4 ? NKB * 2 : NKB / GQ);   // groups per chunk per wave
     static_assert(WM * WK * WN == 4 && KCH % (8 * WK) == 0 && 256 % F4 == 0, "bad tiling");
     extern __shared__ __attribute__((aligned(16))) float4 patch[];   // [2][buf_pos][F4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
@@ -92,6 +96,13 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         if (pt >= P) return;
         bx = pt % A.gx;
         b = pt / A.gx;
+    }
+    int ph_a = 0, ph_b = 0, phase = 0;              // TAPS == 4: the phase (a, b) rides on the group index
+    if (TAPS == 4) {
+        const int groups = A.gy >> 2;
+        phase = by / groups;
+        by -= phase * groups;
+        ph_a = phase >> 1, ph_b = phase & 1;
     }
     const int H = A.H, W = A.W, HW = H * W;
 
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         } else if (ROWSEG == 2) {
             const int row = wn * NT + t, yy = y_first + row, xx = x_first + c;
             pos0[t] = row * PW + c;
-            opx[t] = (yy < H && xx < W) ? (b * HW + yy * W + xx) : -1;
+            opx[t] = (yy < H && xx < W) ? (TAPS == 4 ? b * 4 * HW + (2 * yy + ph_a) * 2 * W + 2 * xx + ph_b : b * HW + yy * W + xx) : -1;
         } else if (ROWSEG) {
             const int xx = x_first + j;
             pos0[t] = j;
@@ -166,14 +177,14 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
             const int pxc = min(px, HW - 1);
             const int y = pxc / W, xx = pxc - y * W;
             pos0[t] = (y - y_first) * PW + xx;
-            opx[t] = (px < HW) ? (b * HW + px) : -1;
+            opx[t] = (px < HW) ? (TAPS == 4 ? b * 4 * HW + (2 * y + ph_a) * 2 * W + 2 * xx + ph_b : b * HW + px) : -1;
         }
     }
 
     const int co_tile = by * WM + wm;
     const bool active = co_tile < A.n_cotiles;
     const int nq = (A.Cin / 8) * TAPS;                          // weight quads per channel tile
-    const float4* W4 = A.wpk + (size_t)(active ? co_tile : 0) * nq * 64 + lane;
+    const float4* W4 = A.wpk + ((size_t)phase * A.n_cotiles + (active ? co_tile : 0)) * nq * 64 + lane;
 
     v16f acc[NT];
     {
@@ -225,6 +236,9 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         if (TAPS == 9) {
             const int ky = gi % 3, kbl = (gi / 3) % NKB, ch = gi / (3 * NKB);
             q = ((ch * (KCH / 8) + wk * NKB + kbl) * 9) + ky * 3 + i;
+        } else if (TAPS == 4) {
+            const int r = gi % 2, kbl = (gi / 2) % NKB, ch = gi / (2 * NKB);
+            q = ((ch * (KCH / 8) + wk * NKB + kbl) * 4) + r * 2 + i;
         } else {
             const int g = gi % GPC, ch = gi / GPC;
             q = ch * (KCH / 8) + wk * NKB + g * GQ + i;
@@ -261,8 +275,8 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
                 // (a workgroup's spare waves -- channel tiles past the last -- run the same MFMAs on tile 0's weights and
                 // store nothing: a per-wave branch here would put the accumulators through VGPR<->AGPR copies and a
                 // matrix-pipe drain around every group)
-                const int kb = wk * NKB + (TAPS == 9 ? g / 3 : g * GQ + i);       // 8-channel block inside the chunk
-                const int toff = TAPS == 9 ? (g % 3) * PW + i : 0;
+                const int kb = wk * NKB + (TAPS == 9 ? g / 3 : (TAPS == 4 ? g / 2 : g * GQ + i));   // 8-channel block inside the chunk
+                const int toff = TAPS == 9 ? (g % 3) * PW + i : (TAPS == 4 ? (ph_a + g % 2) * PW + ph_b + i : 0);
                 const float4 a = cur[i];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -392,7 +406,7 @@ int launch_conv(ConvArgs a, int B, hipStream_t s) {
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return OSSID_ELAUNCH;
-    a.gx = nblk, a.gy = (a.n_cotiles + WM - 1) / WM, a.gz = B;
+    a.gx = nblk, a.gy = (a.n_cotiles + WM - 1) / WM * (TAPS == 4 ? 4 : 1), a.gz = B;
     const long P = (long)a.gx * a.gz;
     long nwg;
     if (a.gy <= 8 && 8 % a.gy == 0)
@@ -413,7 +427,7 @@ size_t ossid_conv_packed_floats(int Cout, int Cin, int taps) {
 }
 
 int ossid_conv_pack_weights(const float* w, int Cout, int Cin, int taps, float* wpk, void* stream) {
-    if (!w || !wpk || Cout <= 0 || Cin <= 0 || Cin % 16 || (taps != 1 && taps != 9)) return OSSID_EINVAL;
+    if (!w || !wpk || Cout <= 0 || Cin <= 0 || Cin % 16 || (taps != 1 && taps != 9 && taps != 4)) return OSSID_EINVAL;
     const size_t total = ossid_conv_packed_floats(Cout, Cin, taps) / 4;
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                        Cout, Cin, taps, (float4*)wpk, total);
@@ -424,7 +438,7 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
     if (!d) return OSSID_EINVAL;
     const int B = d->batch, H = d->height, W = d->width, Cin = d->cin, Cout = d->cout;
     if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 16 || (Cout % 4) || B > 65535) return OSSID_EINVAL;
-    if (d->taps != 1 && d->taps != 9) return OSSID_EINVAL;
+    if (d->taps != 1 && d->taps != 9 && d->taps != 4) return OSSID_EINVAL;
     if (B == 0) return OSSID_OK;
     if (!d->x || !d->wpk || !d->out || (d->act != 0 && d->act != 1)) return OSSID_EINVAL;
     ConvArgs a;
@@ -458,6 +472,31 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
                                     : launch_conv<4, 1, 1, false, 1, 1, 16>(a, B, s);
         if (tiles >= 2) return launch_conv<2, 1, 2, false, 2, 1, 16>(a, B, s);
         return launch_conv<1, 1, 1, false, 2, 1, 16>(a, B, s);
+    }
+    if (d->taps == 4) {       // the four phases of a 3x3 conv on a 2x up-sampled input; H, W = SOURCE size, out = [B][2H][2W]
+        if (a.Hs != H || a.Ws != W || a.pre_scale) return OSSID_EINVAL;
+        const bool wide = W > 100;
+        const long per128 = wide ? (long)((H + 3) / 4) * ((W + 31) / 32) : ((long)H * W + 127) / 128;
+        if (tiles >= 4) {
+            if (wide) return launch_conv<4, 1, 2, 2, 8, 4, 16>(a, B, s);
+            const long groups = (tiles + 3) / 4 * 4;      // the phases multiply the workgroup count
+            int best = 2;
+            double best_cost = 1e30;
+            for (int nt = 1; nt <= 4; ++nt) {
+                const long nwg = (((long)H * W + nt * 32 - 1) / (nt * 32)) * B * groups;
+                const double cost = (double)((nwg + 511) / 512) * (nt + 0.25);
+                if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && nt > best)) best = nt, best_cost = cost;
+            }
+            switch (best) {
+                case 1: return launch_conv<4, 1, 1, 0, 8, 4, 16>(a, B, s);
+                case 2: return launch_conv<4, 1, 2, 0, 8, 4, 16>(a, B, s);
+                case 3: return launch_conv<4, 1, 3, 0, 8, 4, 16>(a, B, s);
+                default: return launch_conv<4, 1, 4, 0, 8, 4, 16>(a, B, s);
+            }
+        }
+        (void)per128;
+        if (tiles >= 2) return wide ? launch_conv<2, 1, 2, 2, 8, 4, 16>(a, B, s) : launch_conv<2, 1, 2, 0, 8, 4, 16>(a, B, s);
+        return wide ? launch_conv<1, 1, 2, 2, 8, 4, 16>(a, B, s) : launch_conv<1, 1, 1, 0, 8, 4, 16>(a, B, s);
     }
     const bool rowseg = W > 100;
     // workgroups of the variant the rules below would pick on a wide image (2-D tiles of 8 / 4 / NT rows x 32 columns)

@@ -1,6 +1,7 @@
 """Torch-facing wrappers of the DTOID device ops in libossid_hip.so (include/ossid_hip.h, "DTOID ops").
 Tensors only cross as raw pointers; autograd sees DwXcorr as one differentiable node."""
 import ctypes
+import os
 
 import torch
 
@@ -135,6 +136,9 @@ def _bn_affine(bn):
     return scale, (bn.bias.detach().float() - bn.running_mean.detach().float() * scale).contiguous()
 
 
+USE_PHASE_CONV = os.environ.get("OSSID_PHASE_CONV", "1") != "0"
+
+
 class PackedConv:
     """One nn.Conv2d (3x3 / stride 1 / padding 1, or 1x1) in the MFMA operand layout of csrc/conv.hip with its fused
     neighbours: `pre_bn` (+ReLU) = eval-mode BatchNorm in FRONT of the conv (DenseNet's BN-ReLU-Conv), `act` = ELU and
@@ -158,6 +162,12 @@ class PackedConv:
         self.pre_scale, self.pre_shift = mk(pre_bn)
         self.pre_relu = 1 if pre_relu else 0
         self._src = (conv, bn, pre_bn)
+        # 3x3 layers that may be called behind an exact 2x nearest up-sampling also keep the four PHASE weight sets
+        # (2x2 kernels with merged rows / columns, csrc/conv.hip TAPS = 4): 4/9 of the multiply-adds
+        self.wpk4 = None
+        if self.taps == 9 and pre_bn is None:
+            n4 = _lib.fn("ossid_conv_packed_floats")(self.cout, self.cin, 4)
+            self.wpk4 = torch.empty(4 * n4, dtype=torch.float32, device=w.device)
         self.refresh()
 
     def refresh(self):
@@ -168,6 +178,19 @@ class PackedConv:
         with torch.cuda.device(w.device):
             _lib.check(_lib.fn("ossid_conv_pack_weights")(w.data_ptr(), self.cout, self.cin, self.taps,
                                                           self.wpk.data_ptr(), _lib.stream()), "ossid_conv_pack_weights")
+        if self.wpk4 is not None:
+            n4 = self.wpk4.numel() // 4
+            rows = ((w[:, :, 0], w[:, :, 1] + w[:, :, 2]), (w[:, :, 0] + w[:, :, 1], w[:, :, 2]))       # phase a: [Cout,Cin,3] x2
+            for a in range(2):
+                for b in range(2):
+                    r0, r1 = rows[a]
+                    cols = (lambda r: (r[:, :, 0], r[:, :, 1] + r[:, :, 2])) if b == 0 else \
+                        (lambda r: (r[:, :, 0] + r[:, :, 1], r[:, :, 2]))
+                    w4 = torch.stack([torch.stack(cols(r0), -1), torch.stack(cols(r1), -1)], -2).contiguous()   # [Cout,Cin,2,2]
+                    with torch.cuda.device(w.device):
+                        _lib.check(_lib.fn("ossid_conv_pack_weights")(
+                            w4.data_ptr(), self.cout, self.cin, 4, self.wpk4[(a * 2 + b) * n4:].data_ptr(), _lib.stream()),
+                            "ossid_conv_pack_weights")
         if self.bias is not None:
             self.bias.copy_(conv.bias.detach())
         for mod, sc, sh in ((bn, self.scale, self.shift), (pre_bn, self.pre_scale, self.pre_shift)):
@@ -206,7 +229,25 @@ class PackedConv:
         x = x.float().contiguous(memory_format=torch.channels_last)
         out = torch.empty((B, self.cout, H, W), dtype=torch.float32, device=x.device,
                           memory_format=torch.channels_last)
+        if self.wpk4 is not None and USE_PHASE_CONV and (H, W) == (2 * Hs, 2 * Ws) and self.pre_scale is None:
+            if self.run_phases(x, B, Hs, Ws, out):
+                return out
         return self.run(x, B, H, W, out, src_hw=(Hs, Ws) if size is not None else (0, 0))
+
+    def run_phases(self, x_nhwc, B, Hs, Ws, out_nhwc):
+        """conv3x3(nearest_upsample_2x(x)) as four 2x2 phase convolutions of the source (one launch). False: not taken."""
+        d = _lib.ConvDesc()
+        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        d.x, d.wpk, d.bias, d.out = x_nhwc.data_ptr(), self.wpk4.data_ptr(), p(self.bias), out_nhwc.data_ptr()
+        d.post_scale, d.post_shift = p(self.scale), p(self.shift)
+        d.batch, d.height, d.width, d.cin, d.cout, d.taps, d.act = B, Hs, Ws, self.cin, self.cout, 4, self.act
+        d.in_batch_stride = -1
+        with torch.cuda.device(out_nhwc.device):
+            rc = _lib.fn("ossid_conv_nhwc_fwd")(C_byref(d), _lib.stream())
+        if rc == -22:
+            return False
+        _lib.check(rc, "ossid_conv_nhwc_fwd")
+        return True
 
 
 class SegTail:

@@ -272,10 +272,14 @@ def test_conv3x3_fused_nearest_upsample(hiplib, Hs, Ws, H, W, Cin, Cout):
     with torch.no_grad():
         up = torch.nn.functional.interpolate(x, size=(H, W), mode="nearest")
         want = ops.PackedConv3x3(conv)(up)                       # the same kernel on the materialised tensor
-        got = ops.PackedConv3x3(conv)(x, size=(H, W))
+        pk = ops.PackedConv3x3(conv)
+        xl = x.contiguous(memory_format=torch.channels_last)
+        got = pk.run(xl, 2, H, W, torch.empty_like(want), src_hw=(Hs, Ws))     # the 9-tap kernel with the fused index map
+        via_call = pk(x, size=(H, W))        # exact 2x: four 2x2 phase convolutions with merged weights (not bit-identical)
         ref = conv.double()(up.double())
     assert torch.equal(got, want)                                # bit-identical: only the staging index differs
     assert float((got.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert float((via_call.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
 def test_graphed_finetune_step_matches_eager(hiplib):
@@ -496,7 +500,7 @@ def test_c_abi_rejects_bad_arguments_without_launching(hiplib):
     d.x = d.wpk = d.out = p
     d.batch, d.height, d.width, d.cin, d.cout, d.taps, d.in_batch_stride = 1, 8, 8, 24, 32, 9, -1     # cin % 16 != 0
     assert _lib.fn("ossid_conv_nhwc_fwd")(C_byref(d), s) < 0
-    d.cin, d.taps = 32, 4                                                                               # 2x2 kernels: not built
+    d.cin, d.taps = 32, 5                                                                               # taps: 1, 9 or 4 (phases)
     assert _lib.fn("ossid_conv_nhwc_fwd")(C_byref(d), s) < 0
     d.taps, d.out = 9, None                                                                             # null output
     assert _lib.fn("ossid_conv_nhwc_fwd")(C_byref(d), s) < 0
@@ -555,3 +559,30 @@ def test_dot_by_channel_contraction_last_matches_module_path(hiplib):
         x2, heat, seg = fused.correlation(feat, tmpl)
     for name, a, b in (("x2", x2, x2r), ("heat", heat, heatr), ("seg", seg, segr)):
         assert float((a - b).abs().max() / b.abs().max().clamp(min=1e-6)) < 1e-4, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Cin,Cout,Hs,Ws", [(21, 256, 128, 29, 39), (3, 128, 64, 58, 78), (2, 64, 32, 116, 156),
+                                              (2, 32, 48, 7, 5), (1, 512, 512, 9, 11)])
+def test_phase_conv_equals_conv_of_2x_upsampled(hiplib, B, Cin, Cout, Hs, Ws):
+    """conv3x3(F.interpolate(x, scale 2, nearest)) computed as four 2x2 phase convolutions of the source with merged
+    weights (4/9 of the multiply-adds) vs torch on the up-sampled tensor, with the ELU + BatchNorm epilogue."""
+    import torch.nn.functional as F
+    torch.manual_seed(Cin + Cout + Hs)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1).cuda()
+    bn = torch.nn.BatchNorm2d(Cout).cuda().eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(B, Cin, Hs, Ws, device="cuda")
+    pk = ops.PackedConv3x3(conv, bn, act=True)
+    assert pk.wpk4 is not None
+    xl = x.contiguous(memory_format=torch.channels_last)
+    out = torch.empty((B, Cout, 2 * Hs, 2 * Ws), device="cuda").contiguous(memory_format=torch.channels_last)
+    assert pk.run_phases(xl, B, Hs, Ws, out), "the phase path did not take this shape"
+    with torch.no_grad():
+        want = bn(F.elu(conv(F.interpolate(x, scale_factor=2, mode="nearest"))))
+        full = pk.run(xl, B, 2 * Hs, 2 * Ws, torch.empty_like(out), src_hw=(Hs, Ws))      # the 9-tap fused-upsample path
+    scale = float(want.abs().max())
+    assert float((out - want).abs().max()) / scale < 2e-5
+    assert float((out - full).abs().max()) / scale < 2e-5
