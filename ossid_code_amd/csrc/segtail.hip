@@ -115,47 +115,34 @@ __global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A, c
         }
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // With an up-sampling ratio >= 2 the three input rows Y-1, Y, Y+1 of an output row come from at most TWO source rows, so
+    // the kernel rows that read the same source row are merged (their weights added): 2 x 3 taps instead of 3 x 3 --
+    // a third of the first conv's MFMAs gone. (Columns are not merged: the pattern would differ from lane to lane, and an
+    // MFMA's weight operand is shared by its 16 pixels.) Rows touching the frame border keep the full 3 x 3 form.
+    const bool can_merge = 2.0f * A.scale_h <= 1.0f;
 #pragma unroll 1
 #ifdef ST_ABL_NOMFMA
-    for (int t0 = wave_u; t0 < 0; t0 += 8) {
+    for (int t0 = 2 * wave_u; t0 < 0; t0 += 8) {
 #else
-    for (int t0 = wave_u; t0 < ST_MH * 2; t0 += 8) {
+    for (int t0 = 2 * wave_u; t0 < ST_MH * 2; t0 += 8) {    // the pair (t0, t0+1) = the two halves of ONE mid row
 #endif
-        int off[2][9];
+        const int my = t0 >> 1;
+        const int Y = y0 - 1 + my;                           // up-sampled row of this pair's mid pixels (wave-uniform)
+        int rofs[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = Y - 1 + dy;
+            rofs[dy] = (yy >= 0 && yy < H) ? (src_index(yy, A.scale_h, A.Hs) - sr0) * (ST_PC * ST_PSTRIDE) : -1;
+        }
         bool inside[2];
         int mpos[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int t = t0 + 4 * u;                        // wave-uniform
-            const int my = t >> 1, hx = t & 1;
-            const int Y = y0 - 1 + my;                       // up-sampled row of this tile's mid pixels
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const int yy = Y - 1 + dy;
-                const int rofs = (yy >= 0 && yy < H) ? (src_index(yy, A.scale_h, A.Hs) - sr0) * (ST_PC * ST_PSTRIDE) : -1;
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int cf = hx ? cofs[1][dx] : cofs[0][dx];
-                    off[u][dy * 3 + dx] = (rofs >= 0 && cf >= 0) ? rofs + cf : zero_off + 4 * g;
-                }
-            }
-            inside[u] = Y >= 0 && Y < H && (hx ? cin[1] : cin[0]);
-            mpos[u] = (my * ST_MW + hx * 16 + c) * ST_MSTRIDE + 4 * g;
+            inside[u] = Y >= 0 && Y < H && cin[u];
+            mpos[u] = (my * ST_MW + u * 16 + c) * ST_MSTRIDE + 4 * g;
         }
         v4f acc0 = {bias4[0], bias4[1], bias4[2], bias4[3]}, acc1 = acc0;
-        // the B quads of step s+1 are read from LDS while step s's eight MFMAs run (pinned: left alone the compiler
-        // issues each read right in front of its first use and every step waits out the LDS latency)
-        float4 p0 = *(const float4*)(patch + off[0][0]), p1 = *(const float4*)(patch + off[1][0]);
-#pragma unroll
-        for (int st = 0; st < 18; ++st) {
-            const int tn = (st + 1) >> 1, cbn = (st + 1) & 1;
-            float4 n0 = p0, n1 = p1;
-            if (st + 1 < 18) {
-                n0 = *(const float4*)(patch + off[0][tn] + 16 * cbn);
-                n1 = *(const float4*)(patch + off[1][tn] + 16 * cbn);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const float4 a = wq[st];
+        auto mfma8 = [&](const float4& a, const float4& p0, const float4& p1) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, p0.x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, p1.x, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, p0.y, acc0, 0, 0, 0);
@@ -164,8 +151,67 @@ __global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A, c
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, p1.z, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, p0.w, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, p1.w, acc1, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            p0 = n0, p1 = n1;
+        };
+        auto add4 = [](const float4& u, const float4& v) { return make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w); };
+        const bool interior = rofs[0] >= 0 && rofs[2] >= 0;
+        const bool va = rofs[1] == rofs[2], vb = rofs[0] == rofs[1];
+        if (can_merge && interior && (va || vb)) {
+            // variant A: rows 1,2 share a source row -> (w0 | w1+w2); variant B: rows 0,1 do -> (w0+w1 | w2)
+            const int r0 = rofs[0], r1 = va ? rofs[1] : rofs[2];
+            int off[2][6];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int cf = cofs[u][dx];
+                    off[u][dx] = cf >= 0 ? r0 + cf : zero_off + 4 * g;
+                    off[u][3 + dx] = cf >= 0 ? r1 + cf : zero_off + 4 * g;
+                }
+            float4 p0 = *(const float4*)(patch + off[0][0]), p1 = *(const float4*)(patch + off[1][0]);
+#pragma unroll
+            for (int st = 0; st < 12; ++st) {
+                const int tp = st >> 1, cb = st & 1, tn = (st + 1) >> 1, cbn = (st + 1) & 1;
+                float4 n0 = p0, n1 = p1;
+                if (st + 1 < 12) {
+                    n0 = *(const float4*)(patch + off[0][tn] + 16 * cbn);
+                    n1 = *(const float4*)(patch + off[1][tn] + 16 * cbn);
+                }
+                const int dx = tp % 3;
+                // merged weight quad of (row group tp / 3, column dx, channel block cb)
+                const float4 w0 = wq[(0 * 3 + dx) * 2 + cb], w1 = wq[(1 * 3 + dx) * 2 + cb], w2 = wq[(2 * 3 + dx) * 2 + cb];
+                const float4 a = tp < 3 ? (va ? w0 : add4(w0, w1)) : (va ? add4(w1, w2) : w2);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma8(a, p0, p1);
+                __builtin_amdgcn_sched_barrier(0);
+                p0 = n0, p1 = n1;
+            }
+        } else {
+            int off[2][9];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int cf = cofs[u][dx];
+                        off[u][dy * 3 + dx] = (rofs[dy] >= 0 && cf >= 0) ? rofs[dy] + cf : zero_off + 4 * g;
+                    }
+            // the B quads of step s+1 are read from LDS while step s's eight MFMAs run (pinned: left alone the compiler
+            // issues each read right in front of its first use and every step waits out the LDS latency)
+            float4 p0 = *(const float4*)(patch + off[0][0]), p1 = *(const float4*)(patch + off[1][0]);
+#pragma unroll
+            for (int st = 0; st < 18; ++st) {
+                const int tn = (st + 1) >> 1, cbn = (st + 1) & 1;
+                float4 n0 = p0, n1 = p1;
+                if (st + 1 < 18) {
+                    n0 = *(const float4*)(patch + off[0][tn] + 16 * cbn);
+                    n1 = *(const float4*)(patch + off[1][tn] + 16 * cbn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma8(wq[st], p0, p1);
+                __builtin_amdgcn_sched_barrier(0);
+                p0 = n0, p1 = n1;
+            }
         }
         // ELU -> BatchNorm; a mid pixel outside the image is the second conv's zero padding
 #pragma unroll
