@@ -170,8 +170,8 @@ def dtoid_leg(a, dev, dist, world):
                                      "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                                      "frac": (39.7e9 + 46.0e9 * nt) / t_fwd / 1e12 / PEAK_F32_MATRIX_TFLOPS,
                                      "note": "NOMINAL flops of the reference's forward (39.7 + 46.0 n_t GFLOP) over the "
-                                             "whole frame incl. top-k / NMS / host latency; the build executes ~7 % fewer "
-                                             "(conv(image - avg_t) by linearity); per-layer rates in "
+                                             "whole frame incl. top-k / NMS / host latency; the build executes ~17 % fewer in "
+                                             "the head (three reassociations, DESIGN.md 5); per-layer rates in "
                                              "profiles/r01_e_conv_layers.json"},
                         "cpu_baseline": cpu_fwd},
             "finetune": {"metric": "DTOID finetune samples/sec", "value": world * B / t_ft, "unit": "sample/s",
