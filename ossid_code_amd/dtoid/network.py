@@ -297,8 +297,11 @@ class FusedHead:
         csub = (a2 @ self.sub_wsum()).contiguous()            # [n_t, 9*256]: conv_sub's response to the constant image a_t
         return [t2, avg, a2, csub]
 
-    def correlation(self, image_feat, template_feat, side=None):
+    def correlation(self, image_feat, template_feat, side=None, frame=None):
+        """frame: a dict shared by the template chunks of ONE image (the template-independent tensors -- channels-last image,
+        G of the dot reassociation, S of the sub one -- are then computed once per frame, not once per chunk)."""
         corr = self.corr
+        frame = {} if frame is None else frame
         t2, avg, a2, csub = self.template_side(template_feat) if side is None else side
         bcast = image_feat.shape[0] == 1 and image_feat.is_cuda and image_feat.shape[1] % 4 == 0
         dot3x3 = None if bcast else ops.dw_xcorr(image_feat, t2)
@@ -309,18 +312,24 @@ class FusedHead:
             # in channel slices of one buffer (no torch.cat). Saves two 61 MB elementwise passes and a 73 MB copy per frame.
             B = int(template_feat.shape[0])
             H, W = int(image_feat.shape[2]), int(image_feat.shape[3])
-            xin = image_feat.float().contiguous(memory_format=torch.channels_last)
+            if "xin" not in frame:
+                frame["xin"] = image_feat.float().contiguous(memory_format=torch.channels_last)
+            xin = frame["xin"]
             ones, zeros = self._const(a2)
             ctot = self.dot.cout + self.sub.cout + self.dot3.cout
             x = torch.empty((B, ctot, H, W), dtype=torch.float32, device=xin.device, memory_format=torch.channels_last)
             if B >= self.DOT_GEMM_MIN_TEMPLATES and self.dot.cout % 4 == 0 and 256 % (self.dot.cout // 4) == 0:
                 # conv(image * avg_t) = sum_c avg_t[c] * G[c]: G once per frame, then ONE [B x C] x [C x HW*Cout] GEMM
                 C = int(xin.shape[1])
-                G = torch.empty((C, H * W * self.dot.cout), dtype=torch.float32, device=xin.device)
+                if "G" not in frame:
+                    G = torch.empty((C, H * W * self.dot.cout), dtype=torch.float32, device=xin.device)
+                    with torch.cuda.device(xin.device):
+                        ops._lib.check(ops._lib.fn("ossid_dot_expand")(xin.data_ptr(), self.dot_wcto().data_ptr(), C,
+                                                                       self.dot.cout, H, W, G.data_ptr(), ops._lib.stream()),
+                                       "ossid_dot_expand")
+                    frame["G"] = G
+                G = frame["G"]
                 with torch.cuda.device(xin.device):
-                    ops._lib.check(ops._lib.fn("ossid_dot_expand")(xin.data_ptr(), self.dot_wcto().data_ptr(), C,
-                                                                   self.dot.cout, H, W, G.data_ptr(), ops._lib.stream()),
-                                   "ossid_dot_expand")
                     z = a2 @ G                                                   # [B, HW*Cout] = [t][px][o]
                     ops._lib.check(ops._lib.fn("ossid_bias_elu_affine_slice")(
                         z.data_ptr(), B * H * W, self.dot.cout, None if self.dot.bias is None else self.dot.bias.data_ptr(),
@@ -329,9 +338,11 @@ class FusedHead:
             else:
                 self.dot.run(xin, B, H, W, x, out_cs=ctot, out_coff=0, in_bs=0, pre=(a2, zeros))
             if H >= 2 and W >= 2:       # conv(image - avg_t) = conv(image) - conv(avg_t): ONE convolution per frame
-                S = torch.empty((1, self.sub.cout, H, W), dtype=torch.float32, device=xin.device,
-                                memory_format=torch.channels_last)
-                self.sub_raw.run(xin, 1, H, W, S)
+                if "S" not in frame:
+                    frame["S"] = torch.empty((1, self.sub.cout, H, W), dtype=torch.float32, device=xin.device,
+                                             memory_format=torch.channels_last)
+                    self.sub_raw.run(xin, 1, H, W, frame["S"])
+                S = frame["S"]
                 with torch.cuda.device(xin.device):
                     rc = ops._lib.fn("ossid_bcast_sub_epilogue")(
                         S.data_ptr(), csub.data_ptr(), B, H, W, self.sub.cout, self.sub.scale.data_ptr(),
@@ -519,9 +530,10 @@ class Network(nn.Module):
             features = self.image_feature_extractor(image, template_global)
         fused = self._fused_head() if (self.use_fused_head and features.is_cuda and not self.training) else None
         cls_out, reg_out, seg_out, heat_out = [], [], [], []
+        frame = {}
         for ci, chunk in enumerate(template_features):
             if fused is not None:
-                xc, heat, seg = fused.correlation(features, chunk, None if sides is None else sides[ci])
+                xc, heat, seg = fused.correlation(features, chunk, None if sides is None else sides[ci], frame)
                 cls_out.append(fused.classification(xc))
                 reg_out.append(fused.regression(xc))
             else:
