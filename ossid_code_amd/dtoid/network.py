@@ -577,23 +577,26 @@ class Network(nn.Module):
         graph, s_img, s_tf, s_g, outs, _, s_sides, last = entry
         s_img.copy_(image)
         s_g.copy_(template_global)
-        src_key = (tuple((c.data_ptr(), c._version) for c in template_features), self.__dict__.get("_plan_epoch", 0))
-        if src_key != last:
+        # identity of the template tensors (held by reference below, so their addresses cannot be recycled for other data
+        # while an entry is cached) + their version counters + the weight epoch
+        srcs = list(template_features)
+        src_key = (tuple((id(c), c._version) for c in srcs), self.__dict__.get("_plan_epoch", 0))
+        if last is None or last[0] != src_key:
             for dst, src in zip(s_tf, template_features):
                 dst.copy_(src)
             if s_sides is not None:
                 # per object (= per set of template tensors) the template-only tensors are computed once and kept: a loop
                 # over the objects of a scene only pays the small copies into the graph's static buffers
                 sc = self.__dict__.setdefault("_side_cache", {})
-                sides = sc.get(src_key)
-                if sides is None:
+                hit = sc.get(src_key)
+                if hit is None:
                     if len(sc) >= 64:
                         sc.clear()
-                    sides = sc[src_key] = [[t.clone() for t in fused.template_side(c)] for c in template_features]
-                for bufs, vals in zip(s_sides, sides):
+                    hit = sc[src_key] = (srcs, [[t.clone() for t in fused.template_side(c)] for c in srcs])
+                for bufs, vals in zip(s_sides, hit[1]):
                     for dst, src in zip(bufs, vals):
                         dst.copy_(src)
-            entry[7] = src_key
+            entry[7] = (src_key, srcs)
         graph.replay()
         return outs
 

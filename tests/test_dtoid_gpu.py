@@ -586,3 +586,29 @@ def test_phase_conv_equals_conv_of_2x_upsampled(hiplib, B, Cin, Cout, Hs, Ws):
     scale = float(want.abs().max())
     assert float((out - want).abs().max()) / scale < 2e-5
     assert float((out - full).abs().max()) / scale < 2e-5
+
+
+@pytest.mark.gpu
+def test_template_side_cache_is_not_fooled_by_recycled_addresses(hiplib):
+    """Template features of one object are freed and another object's features land at the same device address (the caching
+    allocator recycles it): the cached template-only tensors of the first object must not be used for the second."""
+    torch.manual_seed(11)
+    net = dtoid.Network(img_size=(480, 640), heatmap_size=(29, 39)).cuda().eval()
+    with torch.no_grad():
+        for conv in (net.classification.output, net.regression.output, net.correlation_model.seg_final):
+            conv.weight.normal_(0, 0.05)
+        img = torch.rand(1, 3, 480, 640, device="cuda")
+        g = net.compute_template_global(torch.rand(1, 4, 124, 124, device="cuda"))
+        loc = [net.compute_template_local(torch.rand(3, 4, 124, 124, device="cuda"))]
+        ptr = loc[0].data_ptr()
+        first = [t.clone() for t in net._graphed_dense(img, loc, g)[:4]]
+        del loc
+        loc = [net.compute_template_local(torch.rand(3, 4, 124, 124, device="cuda") * 0.5)]
+        recycled = loc[0].data_ptr() == ptr
+        got = net._graphed_dense(img, loc, g)
+        net.use_graph = False
+        want = net._dense_all_templates(img, loc, g)
+    for a, b in zip(got[:4], want[:4]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+    assert not torch.allclose(got[0], first[0])
+    print("address recycled:", recycled)
