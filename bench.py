@@ -183,11 +183,40 @@ def dtoid_leg(a, dev, dist, world):
                          "tflops": world * B * 258e9 / t_ft / 1e12}}
 
 
+def resolve_world(a, environ=None, spawn=None):
+    """How many ranks ACTUALLY run, and what to do when --gpus disagrees (pure host logic, tests/test_bench_contract.py).
+    Every reported number (value, n_gpus, the parallelism string) is computed from the returned world size, never
+    from --gpus. Returns (world, rank, local_rank), or calls `spawn(n)` -- which must not return -- when `--gpus N > 1`
+    was given to a bare `python bench.py` (no torchrun environment): the N ranks are then launched as children through
+    torch.distributed.run BEFORE this process touches the GPU. A torchrun world that differs from --gpus is an error."""
+    environ = os.environ if environ is None else environ
+    launched = "WORLD_SIZE" in environ and "RANK" in environ
+    world = int(environ.get("WORLD_SIZE", "1"))
+    if not launched and a.gpus > 1:
+        (spawn or spawn_ranks)(a.gpus)
+        raise SystemExit("bench.py: spawn_ranks returned")
+    if a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but %d rank(s) were launched (WORLD_SIZE); refusing to report a "
+                         "throughput for GPUs that did no work" % (a.gpus, world))
+    return world, int(environ.get("RANK", "0")), int(environ.get("LOCAL_RANK", "0"))
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU, RCCL) as a child job and leave with
+    its exit code. Nothing here has initialised the GPU yet (torch.cuda.device_count() does not)."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible" % (n, have))
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
 def main():
     a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local = resolve_world(a)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -215,7 +244,7 @@ def main():
     model = synth.random_pn2_state(zephyr.PointNet2SSG(8, Args(), num_class=1), 0).eval()
 
     base, base_scores = None, None
-    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
         base, base_scores = cpu_baseline(d, model, a.cpu_sample)
 
     model = model.to(dev)
@@ -296,15 +325,15 @@ def main():
         achieved = STAGE_FLOPS[dom] * N_HYP / (dom_ms * 1e-3) / 1e12
         feat_bytes = N_HYP * N_PTS * (32 + 8) + IMG_H * IMG_W * 16 + N_PTS * 48 + N_HYP * 64
         return {
-            "metric": "hypotheses scored/sec", "value": a.gpus * a.steps * N_HYP / elapsed, "unit": "hyp/s",
-            "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "metric": "hypotheses scored/sec", "value": world * a.steps * N_HYP / elapsed, "unit": "hyp/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "zephyr_score: %d hypotheses x %d model points, %dx%d RGB-D frame, "
                                    "HSVD_diff_uv_norm features (D=8) + PointNet2SSG (SA 512/0.2/64 [8,64,64,128], "
                                    "SA 128/0.4/64 [131,128,128,256], SA all [259,256,512,1024], FC 512-256-1); "
                                    "BASELINE.json configs[1]" % (N_HYP, N_PTS, IMG_W, IMG_H),
                        "frames_per_step_per_gpu": 1, "frames_in_flight_per_gpu": len(streams),
-                       "parallelism": "frames sharded, %d rank(s)" % a.gpus, "top1": top1},
+                       "parallelism": "frames sharded, %d rank(s)" % world, "top1": top1},
             "roofline": {"bound": "mfma", "kernel": dom + "_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
                          "traffic": traffic, "avg_launch_ms": dom_ms,
@@ -324,8 +353,10 @@ def main():
         import threading
 
         def on_timeout():   # a thread, not a signal: the main thread may be blocked inside a collective
+            # the headline line is already measured: print it with the error note, then leave NON-ZERO on every rank --
+            # a hung collective or GPU must not read as a successful run (no retry, no restart in-process)
             emit({"error": "DTOID leg timed out after %d s" % a.dtoid_timeout})
-            os._exit(0)
+            os._exit(3)
         watchdog = threading.Timer(a.dtoid_timeout, on_timeout)
         watchdog.daemon = True
         watchdog.start()

@@ -12,6 +12,32 @@ static inline int ossid_launch_status() {
     return e == hipSuccess ? OSSID_OK : OSSID_ELAUNCH;
 }
 
+// Kernels that declare more dynamic LDS than the default limit need hipFuncAttributeMaxDynamicSharedMemorySize. It is a
+// property of the FUNCTION, not of a launch: raise it to the hardware maximum ONCE per (function, device), the first
+// time the function is launched (always a warm-up pass, never inside a stream capture), instead of before every launch.
+// Round 1 set it per launch -- also from inside torch.cuda.graph captures, where a rocprofv3-traced run segfaulted in the
+// launch path ("capture under the profiler").
+struct OssidLdsAttr {
+    int done[16];
+};
+static inline int ossid_ensure_dyn_lds(const void* fn, size_t bytes, OssidLdsAttr& st) {
+    if (bytes <= 48 * 1024) return OSSID_OK;
+    if (bytes > 160 * 1024) return OSSID_EINVAL;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return OSSID_ELAUNCH;
+    dev &= 15;
+    if (__atomic_load_n(&st.done[dev], __ATOMIC_ACQUIRE)) return OSSID_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return OSSID_ELAUNCH;
+    __atomic_store_n(&st.done[dev], 1, __ATOMIC_RELEASE);
+    return OSSID_OK;
+}
+#define OSSID_ENSURE_LDS(kern, bytes)                                             \
+    do {                                                                          \
+        static OssidLdsAttr ossid_lds_attr_;                                      \
+        const int rc_ = ossid_ensure_dyn_lds((const void*)(kern), (bytes), ossid_lds_attr_); \
+        if (rc_ != OSSID_OK) return rc_;                                          \
+    } while (0)
+
 // 64-lane wave reductions (xor butterfly; every lane ends with the result)
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll

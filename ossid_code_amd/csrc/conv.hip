@@ -403,9 +403,7 @@ int launch_conv(ConvArgs a, int B, hipStream_t s) {
     const size_t red = WK > 1 ? (size_t)WK * (WM * WN) * NT * 16 * 64 * 4 : 0;
     if (red > lds) lds = red;
     auto kern = conv_nhwc_kernel<WM, WK, NT, ROWSEG, NLD, TAPS, KCH>;
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return OSSID_ELAUNCH;
+    OSSID_ENSURE_LDS(kern, lds);
     a.gx = nblk, a.gy = (a.n_cotiles + WM - 1) / WM * (TAPS == 4 ? 4 : 1), a.gz = B;
     const long P = (long)a.gx * a.gz;
     long nwg;

@@ -413,9 +413,7 @@ int ossid_nms(const float* boxes, int n, float iou_threshold, void* workspace, s
                        mask, words);
     if (words <= 16) {
         const int lds = n * words * 8;
-        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)nms_scan_small_kernel,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return OSSID_ELAUNCH;
+        OSSID_ENSURE_LDS(nms_scan_small_kernel, (size_t)lds);
         hipLaunchKernelGGL(nms_scan_small_kernel, dim3(1), dim3(256), lds, s, mask, n, words, keep, num_keep);
     } else {
         hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)words * 8, s, mask, n, words, keep, num_keep);

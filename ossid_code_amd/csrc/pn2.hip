@@ -996,10 +996,7 @@ int launch_fps(const float* xyz, int stride, int B, int n, int npoint, int* idx,
     // larger sets: points and running distances in LDS
     size_t lds = (size_t)n * 20;
     if (lds > 160 * 1024 - 1024) return OSSID_EINVAL;
-    if (lds > 48 * 1024)
-        if (hipFuncSetAttribute((const void*)fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return OSSID_ELAUNCH;
+    OSSID_ENSURE_LDS(fps_kernel, lds);
     hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(256), lds, s, xyz, stride, n, npoint, idx, new_xyz);
     return ossid_launch_status();
 }
@@ -1008,10 +1005,7 @@ int launch_ball(const float* xyz, int stride, int B, int n, const float* new_xyz
                 hipStream_t s) {
     size_t lds = (size_t)n * 16;
     if (lds > 160 * 1024 - 1024) return OSSID_EINVAL;
-    if (lds > 48 * 1024)
-        if (hipFuncSetAttribute((const void*)ball_query_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return OSSID_ELAUNCH;
+    OSSID_ENSURE_LDS(ball_query_kernel, lds);
     const float r2 = radius * radius;
     hipLaunchKernelGGL(ball_query_kernel, dim3(B, (npoint + BQ_CPB - 1) / BQ_CPB), dim3(BQ_THREADS), lds, s, xyz, stride,
                        n, new_xyz, npoint, r2, idx);
@@ -1098,9 +1092,7 @@ int ossid_pn2_score(const float* point_x, int B, int M, const ossid_pn2_weights*
     {
         const int total = B * np1;
         const int grid = (total + 4 * SA1_CPW - 1) / (4 * SA1_CPW);
-        if (hipFuncSetAttribute((const void*)sa1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SA1_LDS_FLOATS * 4) != hipSuccess)
-            return OSSID_ELAUNCH;
+        OSSID_ENSURE_LDS(sa1_kernel, (size_t)SA1_LDS_FLOATS * 4);
         hipLaunchKernelGGL(sa1_kernel, dim3(grid), dim3(256), SA1_LDS_FLOATS * 4, s, point_x, M, ws.ball1, ws.xyz1, np1, total, W(0),
                            Bv(0), W(1), Bv(1), W(2), Bv(2), ws.feat1);
         if ((rc = ossid_launch_status())) return rc;
@@ -1121,9 +1113,7 @@ int ossid_pn2_score(const float* point_x, int B, int M, const ossid_pn2_weights*
         const int total = B * np2;
         const int per_wg = (SA2_THREADS / 64) * SA2_CPW;
         const int grid = (total + per_wg - 1) / per_wg;
-        if (hipFuncSetAttribute((const void*)sa2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SA2_LDS_FLOATS * 4) != hipSuccess)
-            return OSSID_ELAUNCH;
+        OSSID_ENSURE_LDS(sa2_kernel, (size_t)SA2_LDS_FLOATS * 4);
         hipLaunchKernelGGL(sa2_kernel, dim3(grid), dim3(SA2_THREADS), SA2_LDS_FLOATS * 4, s, ws.p2, ws.xyz1, np1, ws.ball2, ws.xyz2, np2,
                            total, blob + w->wxyz2_off, W(4), Bv(4), W(5), Bv(5), ws.feat2);
         if ((rc = ossid_launch_status())) return rc;

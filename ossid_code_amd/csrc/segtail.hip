@@ -300,8 +300,7 @@ int ossid_seg_tail_fwd(const float* x, int batch, int src_height, int src_width,
     if (need_r > ST_PR || need_c > ST_PC) return OSSID_EINVAL;
     a.tiles_x = (width + ST_TW - 1) / ST_TW, a.tiles_y = (height + ST_TH - 1) / ST_TH;
     const int lds = ST_LDS_FLOATS * 4;
-    if (hipFuncSetAttribute((const void*)seg_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        return OSSID_ELAUNCH;
+    OSSID_ENSURE_LDS(seg_tail_kernel, (size_t)lds);
     hipLaunchKernelGGL(seg_tail_kernel, dim3(a.tiles_x * a.tiles_y, batch), dim3(256), lds, (hipStream_t)stream, a, w2);
     return ossid_launch_status();
 }

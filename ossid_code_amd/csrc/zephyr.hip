@@ -450,9 +450,7 @@ extern "C" int ossid_pose_errors(const double* transforms, const double* transfo
     if (symmetric) {
         const size_t lds = (size_t)M * 24;
         if (lds > 150 * 1024) return OSSID_EINVAL;
-        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)pose_error_kernel<true>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return OSSID_ELAUNCH;
+        OSSID_ENSURE_LDS(pose_error_kernel<true>, lds);
         hipLaunchKernelGGL(pose_error_kernel<true>, dim3(N), dim3(256), lds, (hipStream_t)stream, transforms, transform_gt,
                            points, M, err);
     } else {

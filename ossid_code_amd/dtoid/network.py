@@ -270,20 +270,33 @@ class FusedHead:
     def sub_wsum(self):
         return self._sub_wsum
 
-    _TENSORS = {}
-
     @staticmethod
     def version_key(*mods):
         """(storage identity, value versions): a change of the first means the parameters were re-homed (rebuild, and
         drop captured graphs: they read the old addresses), of the second only that values changed (refresh in place).
-        Runs once per frame, so the walk over the module tree (~1 ms for DenseNet-121: it was 8 % of a frame) is done
-        once per module set and only the tensors' pointers and version counters are read afterwards."""
-        ent = FusedHead._TENSORS.get(tuple(id(m) for m in mods))
-        if ent is None or any(r() is not m for r, m in zip(ent[0], mods)):
-            import weakref
+        Runs once per frame, so the walk over the module tree (~1 ms for DenseNet-121: it was 8 % of a frame) is not
+        repeated: the tensor list is kept ON the first module (it dies with it -- no global table holding parameter
+        storage alive) and only pointers and version counters are read per call. The list is re-derived when a
+        Parameter OBJECT was replaced (load_state_dict(assign=True), module surgery): the cheap check is the count and
+        identity of the modules' direct `_parameters` / `_buffers` values."""
+        owner = mods[0]
+        ent = owner.__dict__.get("_ossid_version_tensors")
+        sig = tuple(id(m) for m in mods)
+        if ent is not None and ent[0] == sig:
+            # a replaced Parameter shows up as a different object in its module's dict
+            if any(d[k] is not t for d, k, t in ent[3]):
+                ent = None
+        else:
+            ent = None
+        if ent is None:
             params = [t for m in mods for t in m.parameters()]
-            ent = ([weakref.ref(m) for m in mods], params, params + [t for m in mods for t in m.buffers()])
-            FusedHead._TENSORS[tuple(id(m) for m in mods)] = ent
+            homes = []
+            for m in mods:
+                for sub in m.modules():
+                    homes += [(sub._parameters, k, t) for k, t in sub._parameters.items() if t is not None]
+                    homes += [(sub._buffers, k, t) for k, t in sub._buffers.items() if t is not None]
+            ent = (sig, params, params + [t for m in mods for t in m.buffers()], homes)
+            owner.__dict__["_ossid_version_tensors"] = ent
         return (tuple(t.data_ptr() for t in ent[1]), tuple(t._version for t in ent[2]))
 
     def template_side(self, template_feat):
@@ -447,8 +460,15 @@ class FusedBackbone:
 class Network(nn.Module):
     use_fused_backbone = True  # test-time DenseNet blocks on csrc/conv.hip; False = the nn.Module path (MIOpen)
     use_fused_head = True     # test-time head on csrc/conv.hip; False = the nn.Module path (MIOpen convolutions)
-    # replay the dense part of forward_all_templates from a captured hipGraph (OSSID_NO_GRAPH=1: eager, for profilers)
-    use_graph = os.environ.get("OSSID_NO_GRAPH", "0") != "1"
+    # Replay the dense part of forward_all_templates from a captured hipGraph. OSSID_NO_GRAPH=1 forces eager; eager is
+    # also chosen automatically when the process runs under a rocprofiler-sdk tool (rocprofv3 preloads
+    # librocprofiler-sdk-tool.so and sets ROCP_TOOL_LIBRARIES): with its launch interception active a kernel launch
+    # into a CAPTURING stream segfaulted on the host in round 1 ("capture under the profiler"), and
+    # kernel-trace rows of graph-replayed kernels would carry no per-launch correlation anyway.
+    under_profiler = ("rocprofiler" in os.environ.get("LD_PRELOAD", "") or
+                      bool(os.environ.get("ROCP_TOOL_LIBRARIES")) or bool(os.environ.get("ROCPROFILER_LIBRARY_CTOR")))
+    use_graph = os.environ.get("OSSID_NO_GRAPH", "0") != "1" and (
+        not under_profiler or os.environ.get("OSSID_GRAPH_UNDER_PROFILER", "0") == "1")
 
     def __init__(self, img_size=(480, 480), heatmap_size=(29, 29), template_size=124):
         super().__init__()

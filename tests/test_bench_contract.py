@@ -49,3 +49,47 @@ def test_bench_defaults_are_one_gpu_and_minutes():
     assert re.search(r'"--gpus", type=int, default=1', src)
     steps = int(re.search(r'"--steps", type=int, default=(\d+)', src).group(1))
     assert 1 <= steps <= 100
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_reported_world_is_the_launched_world_never_the_gpus_flag():
+    """`--gpus 8` on one process must not print 8x the throughput of one GPU."""
+    import pytest
+    bench = _bench_module()
+
+    class A:
+        gpus = 1
+
+    # plain single process
+    assert bench.resolve_world(A, environ={}) == (1, 0, 0)
+    # torchrun world that agrees with --gpus
+    A.gpus = 4
+    assert bench.resolve_world(A, environ={"WORLD_SIZE": "4", "RANK": "2", "LOCAL_RANK": "2"}) == (4, 2, 2)
+    # torchrun world that disagrees: refuse (non-zero exit), both directions
+    A.gpus = 8
+    with pytest.raises(SystemExit) as e:
+        bench.resolve_world(A, environ={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert e.value.code not in (0, None)
+    A.gpus = 1
+    with pytest.raises(SystemExit):
+        bench.resolve_world(A, environ={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    # bare `python bench.py --gpus 8`: the ranks are spawned (before any GPU call), this process never measures
+    A.gpus = 8
+    spawned = []
+
+    def fake_spawn(n):
+        spawned.append(n)
+        raise SystemExit(0)
+    with pytest.raises(SystemExit):
+        bench.resolve_world(A, environ={}, spawn=fake_spawn)
+    assert spawned == [8]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "a.gpus *" not in src and '"n_gpus": a.gpus' not in src           # numbers come from `world`
+    assert "os._exit(0)" not in src                                           # the watchdog leaves non-zero
