@@ -139,7 +139,7 @@ def dtoid_leg(a, dev, dist, world):
         del mc
     flat = finetune.FlatParams(m)
     opt = finetune.FusedAMSGrad(flat, lr=1e-4, weight_decay=1e-6)
-    sync = finetune.GradSync(flat) if dist is not None else None
+    sync = finetune.GradSync(flat, model=m) if dist is not None else None
     if sync is not None:
         sync.broadcast_params(0)
     mask = torch.zeros(B, 1, 480, 640)

@@ -126,17 +126,116 @@ class FusedAMSGrad:
 
 
 class GradSync:
-    """Averages the flat gradient buffer over the ranks of a process group: a few large asynchronous all-reduces
-    (RCCL when the backend is "nccl"; gloo in the CPU tests), one wait."""
+    """Keeps data-parallel replicas of the detector identical (one process per GPU; RCCL when the backend is "nccl",
+    gloo in the CPU tests). Three duties, the contract being Lightning DDP's (reference train.py:93-102, whose default
+    `broadcast_buffers=True` also replicates BatchNorm running statistics):
 
-    def __init__(self, flat, process_group=None, bucket_mb=32):
+      gradients   mean over ranks of the flat gradient buffer, in a few large buckets. With `overlap=True` (default) the
+                  all-reduce of a bucket is issued from autograd hooks as soon as the last gradient of the bucket has
+                  been produced, so the exchange of the head's 90 MB runs under the backbone's backward pass; buckets are
+                  always launched in the same (descending) order on every rank. `sync()` is the non-overlapped form
+                  (used behind a hipGraph replay, which runs no hooks).
+      parameters  broadcast once from rank 0 (`broadcast_params`), as DDP's constructor does.
+      buffers     `sync_buffers()`: every floating-point / integer buffer of the model (BatchNorm running_mean /
+                  running_var / num_batches_tracked) is broadcast from rank 0 in ONE coalesced message per dtype. Each
+                  rank normalises with the statistics of its own slice of the batch (per-rank statistics, as DDP without
+                  SyncBN) but every rank LEAVES a finetune step holding rank 0's running statistics -- what DDP hands to
+                  all ranks at the start of the next forward. Without this the eval-mode detectors drift apart and the
+                  speculative stream (stream.run_speculative) would commit frames scored by different detectors."""
+
+    def __init__(self, flat, process_group=None, bucket_mb=32, model=None, overlap=True):
         import torch.distributed as dist
-        self.dist, self.flat, self.group = dist, flat, process_group
+        self.dist, self.flat, self.group, self.model = dist, flat, process_group, model
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         n = flat.n_used
         per = max(1, int(bucket_mb * (1 << 20) // 4))
         self.bounds = [(s, min(n, s + per)) for s in range(0, n, per)]
+        self.overlap = overlap
+        self._hooks, self._works, self._armed = [], [], False
+        # bucket k = the parameters whose flat range STARTS inside bounds[k] (a tensor straddling a boundary belongs to
+        # the bucket it starts in; the bucket's all-reduce range is stretched to cover it)
+        self._buckets = []
+        if self.world > 1 or overlap:
+            used = [(name, p) + flat.offsets[name] for name, p in flat.entries if flat.offsets[name][0] < n]
+            k = 0
+            cur = {"params": [], "lo": 0, "hi": 0}
+            for name, p, off, cnt in used:
+                while k + 1 < len(self.bounds) and off >= self.bounds[k][1]:
+                    if cur["params"]:
+                        self._buckets.append(cur)
+                    k += 1
+                    cur = {"params": [], "lo": off, "hi": off}
+                if not cur["params"]:
+                    cur["lo"] = off
+                cur["params"].append((p, off, cnt))
+                cur["hi"] = off + cnt
+            if cur["params"]:
+                self._buckets.append(cur)
+            for b in self._buckets:
+                b["views"] = [flat.grad[off:off + cnt].view_as(p) for p, off, cnt in b["params"]]
 
+    # ---- overlapped gradient exchange ---------------------------------------------------------------------------------
+    def begin(self):
+        """Arm the hooks for ONE backward pass (call after flat.detach_grads(), before loss.backward())."""
+        if not self._hooks:
+            for bi, b in enumerate(self._buckets):
+                for p, _, _ in b["params"]:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        for b in self._buckets:
+            b["pending"], b["flushed"] = len(b["params"]), False
+        self._next = len(self._buckets) - 1          # buckets go out last-to-first: backward produces them in that order
+        self._works, self._armed = [], True
+
+    def _make_hook(self, bi):
+        def hook(param):
+            if not self._armed:
+                return
+            b = self._buckets[bi]
+            b["pending"] -= 1
+            if b["pending"] == 0:
+                self._launch_ready()
+        return hook
+
+    def _launch_ready(self):
+        # fixed launch order (descending bucket index) on every rank, whatever order autograd finished them in
+        while self._next >= 0 and self._buckets[self._next]["pending"] == 0:
+            self._flush(self._buckets[self._next])
+            self._next -= 1
+
+    def _flush(self, b):
+        dst, src = [], []
+        for (p, off, cnt), v in zip(b["params"], b["views"]):
+            if p.grad is None:
+                v.zero_()                         # no gradient this step: contributes zero, like gather_grads
+            elif p.grad.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for (p, _, _), v in zip(b["params"], b["views"]):
+            p.grad = v
+        b["flushed"] = True
+        if self.world > 1:
+            g = self.flat.grad[b["lo"]:b["hi"]]
+            g.mul_(1.0 / self.world)
+            if g.is_cuda and self.dist.get_backend(self.group) != "nccl":
+                torch.cuda.synchronize(g.device)          # see sync(): host-staged gloo on a shared device
+            self._works.append(self.dist.all_reduce(g, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """After loss.backward(): flush what the hooks could not (parameters that got no gradient), wait for all
+        buckets. On return flat.grad holds the mean over ranks and every p.grad is its view of the flat buffer."""
+        self._armed = False
+        for b in self._buckets:
+            b["pending"] = 0
+        self._launch_ready()
+        for w in self._works:
+            w.wait()
+        if self._works and self.flat.grad.is_cuda and self.dist.get_backend(self.group) != "nccl":
+            torch.cuda.synchronize(self.flat.grad.device)
+        self._works = []
+
+    # ---- non-overlapped form ------------------------------------------------------------------------------------------
     def sync(self):
         if self.world == 1:
             return
@@ -157,9 +256,26 @@ class GradSync:
             torch.cuda.synchronize(g.device)
 
     def broadcast_params(self, src=0):
-        """Make every replica start from rank `src`'s weights (DDP's constructor does the same)."""
+        """Make every replica start from rank `src`'s weights AND buffers (DDP's constructor does the same)."""
         if self.world > 1:
             self.dist.broadcast(self.flat.param, src=src, group=self.group)
+            self.sync_buffers(src)
+
+    def sync_buffers(self, src=0, model=None):
+        """Broadcast every buffer of the model from rank `src`, coalesced per dtype (BatchNorm statistics of the whole
+        detector: ~0.4 MB of floats + ~240 int64 counters -> two messages)."""
+        model = self.model if model is None else model
+        if self.world == 1 or model is None:
+            return
+        by_dtype = {}
+        for b in model.buffers():
+            by_dtype.setdefault(b.dtype, []).append(b)
+        for dt in sorted(by_dtype, key=str):
+            bufs = by_dtype[dt]
+            flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+            self.dist.broadcast(flat, src=src, group=self.group)
+            torch._foreach_copy_([b.detach() for b in bufs],
+                                 [c.view_as(b) for c, b in zip(flat.split([b.numel() for b in bufs]), bufs)])
 
 
 class GraphedForwardBackward:
@@ -203,14 +319,18 @@ class GraphedForwardBackward:
 
 def finetune_step(model, batch, optimizer, sync=None, graphed=None):
     """One finetune iteration on a batch already on the device; returns the detached loss. `graphed`: a
-    GraphedForwardBackward built for this batch shape (optional)."""
+    GraphedForwardBackward built for this batch shape (optional). With `sync` (data parallel): gradient mean over ranks
+    (overlapped with backward in the eager form), then the step, then rank 0's BatchNorm buffers to every rank."""
     if graphed is not None:
         loss = graphed(batch)
         if sync is not None:
             sync.sync()
         optimizer.step()
-        return loss
-    return _finetune_step_eager(model, batch, optimizer, sync)
+    else:
+        loss = _finetune_step_eager(model, batch, optimizer, sync)
+    if sync is not None:
+        sync.sync_buffers(model=model if sync.model is None else None)
+    return loss
 
 
 def _finetune_step_eager(model, batch, optimizer, sync=None):
@@ -218,15 +338,22 @@ def _finetune_step_eager(model, batch, optimizer, sync=None):
     out = model(batch)
     loss = out["loss"]
     flat = getattr(optimizer, "flat", None)
-    if flat is not None:               # FusedAMSGrad over FlatParams: gradients gathered by one multi-tensor copy
+    if flat is None and sync is not None:
+        flat = sync.flat               # a torch optimizer over FlatParams views: same gather protocol
+    if flat is not None:               # gradients gathered into the flat buffer by multi-tensor copies
         flat.detach_grads()
-        loss.backward()
-        flat.gather_grads()
+        if sync is not None and sync.overlap:
+            sync.begin()               # per-bucket gather + all-reduce from autograd hooks, under the backward pass
+            loss.backward()
+            sync.finish()
+        else:
+            loss.backward()
+            flat.gather_grads()
+            if sync is not None:
+                sync.sync()
     else:
         optimizer.zero_grad()
         loss.backward()
-    if sync is not None:
-        sync.sync()
     optimizer.step()
     return loss.detach()
 

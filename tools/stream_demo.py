@@ -39,7 +39,7 @@ def main():
     det = dtoid.DtoidNet(dtoid.DtoidConfig()).to(dev).eval()
     flat = finetune.FlatParams(det)
     opt = finetune.FusedAMSGrad(flat, lr=1e-4, weight_decay=1e-6)
-    sync = finetune.GradSync(flat) if dist is not None else None
+    sync = finetune.GradSync(flat, model=det) if dist is not None else None
     if sync is not None:
         sync.broadcast_params(0)
     class Args:
@@ -94,6 +94,8 @@ def main():
                     torch.cuda.synchronize()
                     t4 = time.perf_counter()
                     opt.step()
+                    if sync is not None:
+                        sync.sync_buffers()
                     torch.cuda.synchronize()
                     note("step B=%d: fwd %.2f s, bwd %.2f s, sync %.2f s, opt %.3f s" %
                          (len(mine), t2 - t1, t3 - t2, t4 - t3, time.perf_counter() - t4))
