@@ -630,17 +630,25 @@ class Network(nn.Module):
             else:
                 cls_all, reg_all, seg_all, heat_all, fmap = self._dense_all_templates(image, template_features,
                                                                                       template_features_global[0])
+            return self.postprocess(cls_all, reg_all, seg_all, heat_all, fmap, (image.shape[2], image.shape[3]), topk,
+                                    seg_sigmoid)
+
+    def postprocess(self, cls_all, reg_all, seg_all, heat_all, fmap, img_hw, topk=1, seg_sigmoid=False):
+        """Dense head outputs of ONE image (cls [n_t,A,2], reg [n_t,A,4], seg [n_t,1,H,W], heat [n_t,1,hh,hw]) -> the
+        reference's detection list (network.py:543-581: decode + clip, top-1000 object scores over all templates, NMS 0.5,
+        first `topk`, per-detection segmentation / heat map of the template that fired). Everything stays on the device."""
+        with torch.no_grad():
             n_t, A = reg_all.shape[0], reg_all.shape[1]
             anchors = self.anchors([list(fmap)], device=reg_all.device)
-            boxes = ops.decode_clip_boxes(anchors, reg_all, image.shape[3], image.shape[2]).view(-1, 4)
+            boxes = ops.decode_clip_boxes(anchors, reg_all, img_hw[1], img_hw[0]).view(-1, 4)
             k = min(1000, n_t * A)
-            max_score, max_id = torch.topk(cls_all.reshape(-1, 2)[:, 1], k)      # class 1 = object
+            max_score, max_id = ops.topk_scores(cls_all.reshape(-1, 2)[:, 1], k)  # class 1 = object
             anchors_pred = boxes[max_id]
             obj_indices = (max_id // A).to(torch.float32)[:, None]                # which local template fired
             keep = ops.nms(anchors_pred, max_score, 0.5, sorted_desc=True)[:topk]   # topk returns them sorted
             max_score, anchors_pred, obj_indices = max_score[keep], anchors_pred[keep], obj_indices[keep]
             tid = obj_indices.reshape(-1).long()
-            if image.is_cuda:    # seg_sigmoid (additive argument): the sigmoid DtoidNet applies afterwards, folded into the gather
+            if seg_all.is_cuda:  # seg_sigmoid (additive argument): the sigmoid DtoidNet applies afterwards, folded into the gather
                 seg = ops.gather_rows(seg_all[:, 0], tid, sigmoid=seg_sigmoid)
             else:
                 seg = torch.sigmoid(seg_all[:, 0][tid]) if seg_sigmoid else seg_all[:, 0][tid]

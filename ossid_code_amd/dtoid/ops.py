@@ -98,6 +98,13 @@ def nms(boxes, scores, iou_threshold, sorted_desc=False):
     return kept if order is None else order[kept]
 
 
+def topk_scores(scores, k):
+    """(values, indices) of the k largest entries of a 1-D score vector, in decreasing order (network.py:555,
+    `torch.topk(classifications, 1000, dim=1)` on the object column). Ties between equal scores resolve to the lower
+    index."""
+    return torch.topk(scores, k)
+
+
 def gather_rows(src, idx, sigmoid=False):
     """src [R, ...] float32, idx [k] int64 -> src[idx] (optionally through a sigmoid), one pass over the data."""
     _lib.require_cuda(src, idx)
