@@ -53,6 +53,7 @@ def parse():
                         "frame with the MFMA-bound MLP kernels of another (+3.6 %% measured) but then the per-kernel "
                         "HIP-event durations include the other frame's kernels, so the roofline leg needs 1 (default)")
     p.add_argument("--dtoid-templates", type=int, default=21)
+    p.add_argument("--dtoid-images", type=int, default=32, help="images per batch of the configs[2] leg")
     p.add_argument("--dtoid-timeout", type=int, default=420, help="watchdog (s) for the secondary DTOID leg")
     p.add_argument("--dtoid-batch", type=int, default=8, help="finetune batch per GPU (cfg-4: 64 over 8 GPUs)")
     return p.parse_args()
@@ -82,6 +83,25 @@ def cpu_baseline(d, model, sample):
     return {"value": sample / (t2 - t0), "unit": "hyp/s", "cores": int(cores), "kind": "port",
             "sample": "%d of the %d hypotheses of the same frame (x %d points): blur+featurize %.2f s, PointNet2SSG "
                       "%.2f s; C/OpenMP oracle, AVX2 fmaf chains" % (sample, N_HYP, N_PTS, t1 - t0, t2 - t1)}, scores
+
+
+def dtoid_flops(nt, hw=(29, 39), img=(480, 640)):
+    """(nominal, executed) f32 flops (2 x MAC) of one test-time frame with nt templates. Nominal = the reference's forward
+    (39.7 G backbone + 45.96 G per (image, template) pair). Executed = what this build's kernels do after
+    the exact reassociations of DESIGN.md 5: conv(image - avg_t) once per frame instead of per template; conv(image *
+    avg_t) as G once per frame + a [nt x 640] GEMM from 16 templates on; the three decoder convs behind a 2x nearest
+    up-sampling as four 2x2 phase convs (4/9); the decoder tail's first conv with merged kernel rows (2/3)."""
+    px = hw[0] * hw[1]
+    conv640 = 2.0 * px * 256 * 640 * 9                      # one 640->256 3x3 conv at 29x39: 3.336 G
+    nominal = 39.7e9 + 45.96e9 * nt
+    dec = 3 * 2.0 * (2 * hw[0]) * (2 * hw[1]) * 128 * 256 * 9          # s2, s3, s4: equal cost, 2.668 G each
+    s5 = 2.0 * img[0] * img[1] * 16 * 32 * 9
+    per_t = 45.96e9 - conv640 - dec * (5.0 / 9.0) - s5 / 3.0
+    per_frame = 39.7e9 + conv640
+    if nt >= 16:
+        per_t -= conv640 - 2.0 * 640 * px * 256
+        per_frame += conv640
+    return nominal, per_frame + per_t * nt
 
 
 def dtoid_leg(a, dev, dist, world):
@@ -119,6 +139,23 @@ def dtoid_leg(a, dev, dist, world):
             "limg": torch.rand(1, nt, 3, 124, 124, generator=g).to(dev),
             "lmask": (torch.rand(1, nt, 1, 124, 124, generator=g) > 0.5).float().to(dev)}
     t_fwd = timed(lambda: m.forwardTestTime(test), 3, 10)
+    # BASELINE configs[2] as stated: batch = 32 images x 21 templates. (i) forward_all_templates semantics per image
+    # through the additive batched API (backbone once on the batch, head graph per image); (ii) Network.forward on 32
+    # (image, template) pairs
+    B32 = a.dtoid_images
+    test32 = dict(test, img=torch.rand(B32, 3, 480, 640, generator=g).to(dev))
+    t_b32 = timed(lambda: m.forwardTestTimeBatch(test32), 1, 3)
+    pairs = [torch.rand(B32, 3, 480, 640, generator=g), torch.rand(B32, 3, 124, 124, generator=g),
+             (torch.rand(B32, 1, 124, 124, generator=g) > 0.5).float(), torch.rand(B32, 3, 124, 124, generator=g),
+             (torch.rand(B32, 1, 124, 124, generator=g) > 0.5).float()]
+    pairs = [dtoid.normalizeImageRange(p.to(dev)) if p.shape[1] == 3 else p.to(dev) for p in pairs]
+
+    def run_pairs():
+        with torch.no_grad():
+            m.model(*pairs)
+    t_pairs = timed(run_pairs, 1, 3)
+    del test32, pairs
+    torch.cuda.empty_cache()
     cpu_fwd = None
     if dist is None and not a.no_cpu_baseline:
         # the same network through torch's CPU kernels (the nn.Module path of this build = the reference's structure),
@@ -162,18 +199,35 @@ def dtoid_leg(a, dev, dist, world):
         t_ft_hip = timed(lambda: finetune.finetune_step(m, batch, opt, sync), 2, 4)
     finally:
         dops.set_train_conv_impl("miopen")
+    nominal, executed = dtoid_flops(nt)
+    note = ("nominal = the reference's forward (39.7 + 45.96 n_t GFLOP) over the whole call incl. top-k / NMS / host "
+            "latency; executed = what the build's kernels do after the exact reassociations (DESIGN.md 5, "
+            "bench.dtoid_flops); per-layer rates in profiles/")
+
+    def roof(flops_nom, flops_exec, t):
+        return {"bound": "mfma", "achieved": flops_nom / t / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops_nom / t / 1e12 / PEAK_F32_MATRIX_TFLOPS, "achieved_executed": flops_exec / t / 1e12,
+                "frac_executed": flops_exec / t / 1e12 / PEAK_F32_MATRIX_TFLOPS, "note": note}
+    pair_flops = (39.7e9 + 45.96e9 + 0.36e9) * B32          # + the two template encoders per pair
+    # per-pair images: only the decoder reassociations apply (phase convs 4/9, tail rows 2/3)
+    pair_saved = B32 * (3 * 2.0 * 58 * 78 * 128 * 256 * 9 * (5.0 / 9.0) + 2.0 * 480 * 640 * 16 * 32 * 9 / 3.0)
     return {"forward": {"metric": "DTOID imgs/sec", "value": world / t_fwd, "unit": "img/s", "ms_per_image": 1e3 * t_fwd,
                         "config": "forward_all_templates, 1 image x %d local templates per rank, 480x640, topk 500, f32; "
                                   "hand-written MFMA conv head + hipGraph" % nt,
-                        "tflops": world * (39.7e9 + 46.0e9 * nt) / t_fwd / 1e12,
-                        "roofline": {"bound": "mfma", "achieved": (39.7e9 + 46.0e9 * nt) / t_fwd / 1e12,
-                                     "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                                     "frac": (39.7e9 + 46.0e9 * nt) / t_fwd / 1e12 / PEAK_F32_MATRIX_TFLOPS,
-                                     "note": "NOMINAL flops of the reference's forward (39.7 + 46.0 n_t GFLOP) over the "
-                                             "whole frame incl. top-k / NMS / host latency; the build executes ~17 % fewer in "
-                                             "the head (three reassociations, DESIGN.md 5); per-layer rates in "
-                                             "profiles/r01_e_conv_layers.json"},
+                        "tflops": world * nominal / t_fwd / 1e12,
+                        "roofline": roof(nominal, executed, t_fwd),
                         "cpu_baseline": cpu_fwd},
+            "forward_batch": {"metric": "DTOID imgs/sec", "value": world * B32 / t_b32, "unit": "img/s",
+                              "ms_per_batch": 1e3 * t_b32, "ms_per_image": 1e3 * t_b32 / B32,
+                              "config": "BASELINE configs[2]: batch=%d images 640x480 x %d templates per rank "
+                                        "(forwardTestTimeBatch: forward_all_templates semantics per image, backbone "
+                                        "batched, head graph per image), topk 500, f32" % (B32, nt),
+                              "roofline": roof(B32 * nominal, B32 * executed, t_b32)},
+            "forward_pairs": {"metric": "DTOID (image, template) pairs/sec", "value": world * B32 / t_pairs,
+                              "unit": "pair/s", "ms_per_batch": 1e3 * t_pairs,
+                              "config": "Network.forward on %d (image, template) pairs per rank, eval, f32 (template "
+                                        "encoders + backbone + head, dense outputs)" % B32,
+                              "roofline": roof(pair_flops, pair_flops - pair_saved, t_pairs)},
             "finetune": {"metric": "DTOID finetune samples/sec", "value": world * B / t_ft, "unit": "sample/s",
                          "ms_per_step": 1e3 * t_ft, "ms_per_step_eager": 1e3 * t_ft_eager,
                          "ms_per_step_head_convs_hand_written": 1e3 * t_ft_hip, "global_batch": world * B,

@@ -140,6 +140,22 @@ class DtoidNet(nn.Module):
             out["seg_IoU_50"] = (iou > 0.5).float()
         return out
 
+    def forwardTestTimeBatch(self, input):
+        """ADDITIVE API (BASELINE configs[2] "batch=32 ... with 21 templates"): forwardTestTime for a
+        batch of images `img [B,3,H,W]` that all look for the SAME object (`limg [1,n_t,3,h,w]`, `lmask`, `obj_id` as in
+        forwardTestTime). The reference asserts B = 1 (models/dtoid/__init__.py:64) and would be called B times; here the
+        image backbone runs once on the whole batch. Returns a list of B dicts with forwardTestTime's keys."""
+        image = normalizeImageRange(input["img"])
+        obj_id = int(input["obj_id"][0])
+        local, glob = self._template_features(input, obj_id, image.device)
+        res = self.model.forward_all_templates_batch(image, local, glob, topk=self.TOP_K, seg_sigmoid=True)
+        outs = []
+        for scores, boxes, tids, seg, heat in res:
+            outs.append({"pred_bbox": boxes, "pred_scores": scores, "pred_template_ids": tids[:, 0],
+                         "segmentation": seg.unsqueeze(1), "heat_map": heat.unsqueeze(1), "final_bbox": [boxes],
+                         "final_score": [scores]})
+        return outs
+
     def forward(self, input):
         image, template, template_mask = input["img"], input["limg"], input["lmask"]
         global_template, global_template_mask = input["gimg"], input["gmask"]

@@ -433,6 +433,8 @@ class FusedBackbone:
     def __call__(self, image, template_feat):
         ife = self.ife
         x0 = ife.backdense_0(image)
+        if template_feat.shape[0] == 1 and x0.shape[0] > 1:        # a batch of images of ONE object (batched test time)
+            template_feat = template_feat.expand(x0.shape[0], -1, -1, -1)
         x = x0 + ops.dw_xcorr(x0, template_feat)
         for m in self.stem:
             x = m(x)
@@ -534,20 +536,31 @@ class Network(nn.Module):
         """(B,3,H,W), (B,3,h,w), (B,1,h,w), (B,3,h,w), (B,1,h,w) ->
         classifications [B,A,2], regression [B,A,4], anchors [1,A,4], heat_map [B,1,hh,hw], segmentation [B,1,H,W]"""
         g = self.template_feature_extractor_global(torch.cat([global_template, global_template_mask], dim=1))
-        features = self.image_feature_extractor(image, g)
         local = self.template_feature_extractor(torch.cat([template, template_mask], dim=1))
+        if image.is_cuda and not self.training and not torch.is_grad_enabled() and self.use_fused_head:
+            # inference on (image, template) PAIRS (BASELINE configs[2] (ii)): backbone and head on csrc/conv.hip
+            features = self._features(image, g)
+            fused = self._fused_head()
+            xcors, heat_map, segmentation = fused.correlation(features, local)
+            anchors = self.anchors([[xcors.size(2), xcors.size(3)]], device=xcors.device)
+            return fused.classification(xcors), fused.regression(xcors), anchors, heat_map, segmentation
+        features = self.image_feature_extractor(image, g)
         xcors, heat_map, segmentation = self.correlation_model(features, local)
         anchors = self.anchors([[xcors.size(2), xcors.size(3)]], device=xcors.device)
         classifications, _ = self.classification(xcors)
         return classifications, self.regression(xcors), anchors, heat_map, segmentation
 
-    def _dense_all_templates(self, image, template_features, template_global, sides=None):
-        """Backbone once + head per template chunk -> dense (cls [n_t,A,2], reg [n_t,A,4], seg [n_t,1,H,W],
-        heat [n_t,1,hh,hw], feature-map shape). No host syncs, no data-dependent shapes: capturable in a hipGraph."""
+    def _features(self, image, template_global):
+        """D4: image feature map [B,640,h,w] (test time: DenseNet blocks on csrc/conv.hip)."""
         if self.use_fused_backbone and image.is_cuda and not self.training:
-            features = self._fused_backbone()(image, template_global)
-        else:
-            features = self.image_feature_extractor(image, template_global)
+            return self._fused_backbone()(image, template_global)
+        if template_global.shape[0] == 1 and image.shape[0] > 1:
+            template_global = template_global.expand(image.shape[0], -1, -1, -1)
+        return self.image_feature_extractor(image, template_global)
+
+    def _dense_head(self, features, template_features, sides=None):
+        """Head of ONE image (features [1,640,h,w]) per template chunk -> dense (cls [n_t,A,2], reg [n_t,A,4],
+        seg [n_t,1,H,W], heat [n_t,1,hh,hw], feature-map shape)."""
         fused = self._fused_head() if (self.use_fused_head and features.is_cuda and not self.training) else None
         cls_out, reg_out, seg_out, heat_out = [], [], [], []
         frame = {}
@@ -565,38 +578,46 @@ class Network(nn.Module):
         cat = lambda parts: parts[0] if len(parts) == 1 else torch.cat(parts, 0)   # noqa: E731  (one chunk: no copy)
         return (cat(cls_out), cat(reg_out), cat(seg_out), cat(heat_out), (xc.size(2), xc.size(3)))
 
-    def _graphed_dense(self, image, template_features, template_global):
+    def _dense_all_templates(self, image, template_features, template_global, sides=None):
+        """Backbone once + head per template chunk. No host syncs, no data-dependent shapes: capturable in a hipGraph."""
+        return self._dense_head(self._features(image, template_global), template_features, sides)
+
+    def _graphed_dense(self, image, template_features, template_global, head_only=False):
         """The dense part replayed from a captured hipGraph (the B=1 backbone alone is ~500 launches and otherwise
-        host-bound). One graph per (image shape, chunk sizes, packed-head identity); inputs are copied into the
-        graph's static buffers, outputs are read from them."""
+        host-bound). One graph per (input shape, chunk sizes, packed-head identity); inputs are copied into the
+        graph's static buffers, outputs are read from them. head_only: `image` is already the feature map [1,640,h,w]
+        (the batched test-time path runs the backbone once for the whole batch and replays this graph per image)."""
         fused = self._fused_head() if self.use_fused_head else None
-        fused_bb = self._fused_backbone() if self.use_fused_backbone else None
+        fused_bb = self._fused_backbone() if (self.use_fused_backbone and not head_only) else None
         key = (tuple(image.shape), tuple(int(c.shape[0]) for c in template_features), id(fused), id(fused_bb),
-               str(image.device))
+               str(image.device), bool(head_only))
         cache = self.__dict__.setdefault("_graph_cache", {})
         entry = cache.get(key)
         if entry is None:
             if len(cache) >= 4:
                 cache.clear()
             s_img, s_tf = image.clone(), [c.clone() for c in template_features]
-            s_g = template_global.clone()
+            s_g = None if head_only else template_global.clone()
             side = torch.cuda.Stream(device=image.device)
             side.wait_stream(torch.cuda.current_stream())
             # the template-only part of the correlation lives OUTSIDE the graph, in static buffers refreshed only when the
             # templates or the weights change (below)
             s_sides = [fused.template_side(c) for c in s_tf] if fused is not None else None
+            run = (lambda: self._dense_head(s_img, s_tf, s_sides)) if head_only else \
+                (lambda: self._dense_all_templates(s_img, s_tf, s_g, s_sides))
             with torch.cuda.stream(side):           # warm-up off the capture: MIOpen picks its kernels here
                 for _ in range(2):
-                    self._dense_all_templates(s_img, s_tf, s_g, s_sides)
+                    run()
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                outs = self._dense_all_templates(s_img, s_tf, s_g, s_sides)
+                outs = run()
             entry = [graph, s_img, s_tf, s_g, outs, (fused, fused_bb), s_sides, None]
             cache[key] = entry
         graph, s_img, s_tf, s_g, outs, _, s_sides, last = entry
         s_img.copy_(image)
-        s_g.copy_(template_global)
+        if s_g is not None:
+            s_g.copy_(template_global)
         # identity of the template tensors (held by reference below, so their addresses cannot be recycled for other data
         # while an entry is cached) + their version counters + the weight epoch
         srcs = list(template_features)
@@ -619,6 +640,25 @@ class Network(nn.Module):
             entry[7] = (src_key, srcs)
         graph.replay()
         return outs
+
+    def forward_all_templates_batch(self, images, template_features, template_features_global, topk=1, seg_sigmoid=False):
+        """ADDITIVE API (the reference handles one image per call, models/dtoid/__init__.py:64): `forward_all_templates`
+        semantics for a batch of images [B,3,H,W] of ONE object (BASELINE configs[2]: 32 images x 21 templates). The
+        image backbone runs once on the whole batch (at batch 1 its 120 dependent launches are latency-bound; batched
+        they are not), the head graph is replayed per image on that image's feature map, post-processing per image.
+        Returns a list of B result lists, each exactly what forward_all_templates(images[i:i+1], ...) returns."""
+        with torch.no_grad():
+            feats = self._features(images, template_features_global[0])
+            out = []
+            hw = (images.shape[2], images.shape[3])
+            for i in range(images.shape[0]):
+                f = feats[i:i + 1]
+                if self.use_graph and f.is_cuda and not self.training:
+                    dense = self._graphed_dense(f, template_features, None, head_only=True)
+                else:
+                    dense = self._dense_head(f, template_features)
+                out.append(self.postprocess(*dense, hw, topk, seg_sigmoid))
+            return out
 
     def forward_all_templates(self, image, template_features, template_features_global, topk=1, seg_sigmoid=False):
         """image [1,3,H,W]; template_features: list of [n_i,640,7,7] chunks; template_features_global: [[1,64,3,3]]

@@ -612,3 +612,67 @@ def test_template_side_cache_is_not_fooled_by_recycled_addresses(hiplib):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
     assert not torch.allclose(got[0], first[0])
     print("address recycled:", recycled)
+
+
+@pytest.mark.gpu
+def test_batched_test_time_api_equals_per_image_calls(hiplib):
+    """BASELINE configs[2] shape, reduced: forwardTestTimeBatch on B images x n_t templates gives, image by image, what
+    forwardTestTime gives (the batched backbone reorders no sums per image: same kernels, same tiles -> tight tolerance;
+    the dense head outputs are compared, post-NMS lists of a random-weight network are ill-conditioned)."""
+    cfg = dtoid.DtoidConfig()
+    torch.manual_seed(11)
+    m = dtoid.DtoidNet(cfg).cuda().eval()
+    with torch.no_grad():
+        for conv in (m.model.classification.output, m.model.regression.output, m.model.correlation_model.seg_final,
+                     m.model.correlation_model.corr_conv_heatmap):
+            conv.weight.normal_(0, 0.05)
+    g = torch.Generator().manual_seed(3)
+    B, nt = 3, 5
+    imgs = torch.rand(B, 3, 480, 640, generator=g).cuda()
+    test = {"obj_id": torch.tensor([1]), "limg": torch.rand(1, nt, 3, 124, 124, generator=g).cuda(),
+            "lmask": (torch.rand(1, nt, 1, 124, 124, generator=g) > 0.5).float().cuda()}
+    outs = m.forwardTestTimeBatch(dict(test, img=imgs))
+    assert len(outs) == B
+    local, glob = m._template_features(test, 1, imgs.device)
+    net = m.model
+    with torch.no_grad():
+        feats = net._features(dtoid.normalizeImageRange(imgs), glob[0])
+        for i in range(B):
+            one = net._features(dtoid.normalizeImageRange(imgs[i:i + 1]), glob[0])
+            assert float((feats[i:i + 1] - one).abs().max()) <= 2e-4 * float(one.abs().max())
+            single = m.forwardTestTime(dict(test, img=imgs[i:i + 1]))
+            k = outs[i]["pred_scores"].shape[0]
+            assert outs[i]["segmentation"].shape == (k, 1, 480, 640) and outs[i]["pred_bbox"].shape == (k, 4)
+            assert abs(float(outs[i]["pred_scores"][0]) - float(single["pred_scores"][0])) < 1e-4
+            assert set(outs[i]) == set(single)
+            # dense outputs of the head-only graph on the batched features vs the single-image graph
+            a = [t.clone() for t in net._graphed_dense(feats[i:i + 1], local, None, head_only=True)[:4]]
+            b = net._graphed_dense(dtoid.normalizeImageRange(imgs[i:i + 1]), local, glob[0])[:4]
+            for x, y in zip(a, b):
+                assert float((x - y).abs().max()) <= 2e-4 * float(y.abs().max().clamp(min=1e-6))
+
+
+@pytest.mark.gpu
+def test_network_forward_on_pairs_eval_runs_on_the_fused_kernels_and_matches_the_module_path(hiplib):
+    """configs[2] (ii): Network.forward on (image, template) pairs in eval / no_grad mode goes through FusedBackbone +
+    FusedHead (per-pair images: no broadcast) and agrees with the nn.Module path."""
+    torch.manual_seed(12)
+    net = dtoid.Network(img_size=(480, 640), heatmap_size=(29, 39)).cuda().eval()
+    with torch.no_grad():
+        for conv in (net.classification.output, net.regression.output, net.correlation_model.seg_final,
+                     net.correlation_model.corr_conv_heatmap):
+            conv.weight.normal_(0, 0.05)
+    g = torch.Generator().manual_seed(4)
+    B = 3
+    args = [torch.rand(B, 3, 480, 640, generator=g), torch.rand(B, 3, 124, 124, generator=g),
+            (torch.rand(B, 1, 124, 124, generator=g) > 0.5).float(), torch.rand(B, 3, 124, 124, generator=g),
+            (torch.rand(B, 1, 124, 124, generator=g) > 0.5).float()]
+    args = [a.cuda() for a in args]
+    with torch.no_grad():
+        got = net(*args)
+        net.use_fused_head = net.use_fused_backbone = False
+        want = net(*args)
+        net.use_fused_head = net.use_fused_backbone = True
+    assert got[0].shape == (B, 27144, 2) and got[1].shape == (B, 27144, 4) and got[4].shape == (B, 1, 480, 640)
+    for name, a, b in zip(("cls", "reg", "anchors", "heat", "seg"), got, want):
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max().clamp(min=1e-6)), name
