@@ -212,6 +212,88 @@ int ossid_conv3x3_wgrad(const float* x, const float* dy, int B, int H, int W, in
                         int dy_channel_stride, void* workspace, size_t workspace_bytes, float* dw, int accumulate,
                         void* stream);
 
+/* D16  weight gradient of a 3x3 / pad 1 or 1x1 convolution whose INPUT carried a fused prologue in the forward pass
+ * (training-mode BatchNorm folded to a per-channel affine, + ReLU: DenseNet's BN-ReLU-Conv, models/dtoid/network.py:164-184;
+ * the head's `norm(F.elu(conv(x)))` feeding the next conv, :330-357):
+ *   dw[co][ci][tap] (+)= sum_{b,y,x} dy[b][y][x][co] * P(x)[b][y+dy][x+dx][ci],  P(v) = relu?(v * pre_scale[ci] + pre_shift[ci])
+ * on real pixels, zero outside the image (pre_scale NULL = identity). x [B][H][W][in_channel_stride], dy
+ * [B][H][W][dy_channel_stride] channels-last (0 = cin / cout); dw in torch layout [cout][cin][kh][kw]. Operands are staged
+ * through LDS and fed to v_mfma_f32_32x32x2_f32 with the pixels on K; split-K slabs in `workspace`
+ * (ossid_conv_wgrad_workspace_bytes), summed in a fixed order -- bit-reproducible, no float atomics. cin, cout % 4 == 0. */
+typedef struct ossid_wgrad_desc {
+    const float* x;
+    const float* dy;
+    const float* pre_scale;
+    const float* pre_shift;
+    float* dw;
+    void* workspace;
+    size_t workspace_bytes;
+    int32_t batch, height, width, cin, cout, taps, pre_relu, accumulate;
+    int32_t in_channel_stride, dy_channel_stride;
+    int32_t src_height, src_width;   /* > 0 (3x3 only): x is [B][src_h][src_w][..], nearest-neighbour up-sampled to
+                                        [height][width] on the fly, as in the forward (ossid_conv_desc) */
+} ossid_wgrad_desc;
+size_t ossid_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps);
+int ossid_conv_wgrad(const ossid_wgrad_desc* desc_host, void* stream);
+
+/* D16  packed weights of the DATA gradient: dx = conv(dy, W') with W'[ci][co][tap] = w[co][ci][taps-1-tap] (transposed,
+ * rotated by 180 degrees), in the layout ossid_conv_nhwc_fwd reads for a [cout' = Cin][cin' = Cout] layer -- the data
+ * gradient itself is that forward kernel on dy. Cout % 16 == 0; wpk has ossid_conv_packed_floats(Cin, Cout, taps) floats. */
+int ossid_conv_pack_weights_dgrad(const float* w, int Cout, int Cin, int taps, float* wpk, void* stream);
+
+/* D16  one generic channels-last pass of the training step (rows = B*H*W pixels, `channels` % 4 == 0):
+ *     m   = 1 (mask_mode 0) | [mask_scale[c] * x + mask_shift[c] > 0] (1: ReLU behind a folded BatchNorm)
+ *           | (x > 0 ? 1 : x + 1) (2: ELU'(v) written in terms of x = ELU(v))
+ *     r   = (alpha[c] * g + beta[c] * x + kappa[c]) * m              (NULL alpha/beta/kappa = 1 / 0 / 0)
+ *     out = r, or out + r when accumulate != 0                        (out NULL: sums only)
+ *     sums[0][c], sums[1][c] = sum over rows of (g*m, g*m*x) (sum_mode 1) or (r, r*x) (sum_mode 2); 0 = none
+ * Instances: BatchNorm batch statistics (g = x, sum_mode 1: sum x, sum x^2); backward of ELU + BatchNorm statistics
+ * (alpha 1, beta/kappa from ossid_bn_fold_bwd, mask 2, sum_mode 2 -> the bias gradient); backward of a folded
+ * BatchNorm+ReLU prologue (g = d out of the data gradient, mask 1, alpha = scale, sum_mode 1 -> d shift, d scale);
+ * DenseNet's concatenation gradient (accumulate into the block's gradient buffer). Column sums go through per-block
+ * partials [ossid_chan_op_partials(rows, channels)][2][channels] floats and are combined in a fixed order in double. */
+typedef struct ossid_chan_op_desc {
+    const float* g;
+    const float* x;
+    float* out;
+    const float* alpha;
+    const float* beta;
+    const float* kappa;
+    const float* mask_scale;
+    const float* mask_shift;
+    float* partials;
+    float* sums;
+    int64_t n_rows;
+    int32_t channels, g_stride, x_stride, out_stride, mask_mode, accumulate, sum_mode;
+    int32_t sums_row_stride;         /* floats between sums[0][.] and sums[1][.] (0 = channels): lets a layer write the
+                                        statistics of its channel slice into a block-wide [2][C_total] table */
+} ossid_chan_op_desc;
+int ossid_chan_op_partials(long long n_rows, int channels);
+int ossid_chan_op(const ossid_chan_op_desc* desc_host, void* stream);
+
+/* D16  training-mode BatchNorm2d (nn.BatchNorm2d in train(), online_learning.py:656) folded into the per-channel affine
+ * the NEXT convolution applies while staging its input: from sums = (sum x, sum x^2) over n rows,
+ *   (sums[c], sums[sums_row_stride + c]; 0 = C) mean, biased var -> scale = gamma * rstd, shift = beta - mean * scale; running statistics updated in place with
+ *   `momentum` (unbiased variance), as torch does. Backward: (d scale, d shift) -> d gamma, d beta and the coefficients of
+ *   the statistics' own gradient  dx += coef_x[c] * x + coef_1[c]  (= d mean / n + 2 (x - mean) d var / n), which the
+ *   producer's ossid_chan_op pass applies (accumulate != 0: += onto coef_x / coef_1, several consumers of one tensor). */
+int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, int C, double n, const float* gamma, const float* beta, float eps, float momentum,
+                      float* running_mean, float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out,
+                      void* stream);
+int ossid_bn_fold_bwd(const float* dscale, const float* dshift, const float* gamma, const float* mean, const float* rstd,
+                      int C, double n, float* dgamma, float* dbeta, float* coef_x, float* coef_1, int accumulate,
+                      void* stream);
+
+/* D4  nn.AvgPool2d(2, stride) of the DenseNet transitions (stride 2; the third one stride 1, network.py:165),
+ * channels-last. backward != 0: x is d out [B][Ho][Wo][C] and out receives d in [B][H][W][C]. */
+int ossid_avgpool2_nhwc(const float* x, int B, int H, int W, int C, int stride, float* out, int backward, void* stream);
+
+/* D6  gradient of F.interpolate(mode="nearest") [Hs][Ws] -> [H][W] (network.py:354-357), channels-last: every source
+ * pixel sums the destination pixels that read it, rows row_start[sy] .. row_start[sy+1]-1 (int32 [Hs+1], device),
+ * columns likewise -- tables built by the caller with the forward's index formula. */
+int ossid_upsample_nearest_bwd_nhwc(const float* dup, int B, int Hs, int Ws, int H, int W, int C, const int32_t* row_start,
+                                    const int32_t* col_start, float* dsrc, void* stream);
+
 /* D12  torchvision.ops.nms(boxes, scores, iou_threshold)      network.py:563, models/dtoid/utils.py:33
  * boxes [n][4] (x1,y1,x2,y2) ALREADY sorted by descending score (network.py:555 feeds it the top-k order);
  * keep [n] receives the indices of the survivors in that order, *num_keep their count. n <= 16384. */

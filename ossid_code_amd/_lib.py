@@ -28,6 +28,21 @@ class ConvDesc(C.Structure):
                                          "out_channel_offset", "pre_batch_stride")] + [("in_batch_stride", C.c_int64)]
 
 
+class WgradDesc(C.Structure):
+    """struct ossid_wgrad_desc (include/ossid_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("x", "dy", "pre_scale", "pre_shift", "dw", "workspace")] + [("workspace_bytes", _sz)] + \
+               [(n, C.c_int32) for n in ("batch", "height", "width", "cin", "cout", "taps", "pre_relu", "accumulate",
+                                         "in_channel_stride", "dy_channel_stride", "src_height", "src_width")]
+
+
+class ChanOpDesc(C.Structure):
+    """struct ossid_chan_op_desc (include/ossid_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("g", "x", "out", "alpha", "beta", "kappa", "mask_scale", "mask_shift", "partials",
+                                   "sums")] + [("n_rows", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("channels", "g_stride", "x_stride", "out_stride", "mask_mode", "accumulate",
+                                         "sum_mode", "sums_row_stride")]
+
+
 _PROTOS = {
     "ossid_abi_version": (_i, [C.c_char_p, _i]),
     "ossid_zephyr_prep_frame_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -64,6 +79,15 @@ _PROTOS = {
     "ossid_conv3x3_wgrad_splits": (_i, [_i, _i, _i, _i, _i]),
     "ossid_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ossid_conv3x3_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),
+    "ossid_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "ossid_conv_wgrad": (_i, [_vp, _vp]),
+    "ossid_conv_pack_weights_dgrad": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "ossid_chan_op_partials": (_i, [C.c_longlong, _i]),
+    "ossid_chan_op": (_i, [_vp, _vp]),
+    "ossid_bn_fold_fwd": (_i, [_vp, _i, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ossid_bn_fold_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ossid_avgpool2_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "ossid_upsample_nearest_bwd_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ossid_nms_workspace_bytes": (_sz, [_i]),
     "ossid_nms": (_i, [_vp, _i, _f, _vp, _sz, _vp, _vp, _vp]),
     "ossid_decode_clip_boxes": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),

@@ -1,0 +1,664 @@
+// Kernels of the DTOID finetune step (scripts/online_learning.py:650-679: model.train(); loss.backward(); optimizer.step())
+// that are not a forward convolution: everything here works on channels-last activations [rows = B*H*W][channels].
+//
+//   chan_op_kernel      one generic pass  out (+)= (alpha[c]*g + beta[c]*x + kappa[c]) * mask(x)  with optional per-channel
+//                       column sums -- BatchNorm batch statistics, BatchNorm / ReLU / ELU backward, the dense block's
+//                       gradient accumulation: all are instances (see include/ossid_hip.h, ossid_chan_op)
+//   bn_fold_*           training-mode BatchNorm folded to a per-channel (scale, shift) that the NEXT convolution applies
+//                       while staging its input (csrc/conv.hip prologue) + its backward
+//   avgpool2_*          DenseNet transitions (network.py:165: the third one with stride 1)
+//   upsample_bwd        gradient of F.interpolate(mode="nearest") (network.py:354-357): window sums
+//   wgrad_kernel        weight gradient of the 3x3 / 1x1 convolutions on the f32 matrix cores, operands staged through
+//                       LDS, the input's BatchNorm(+ReLU) prologue re-applied on the fly, deterministic split-K
+//   pack_dgrad_kernel   conv weights -> MFMA layout of the TRANSPOSED, 180-degree-rotated kernel: the data gradient is
+//                       ossid_conv_nhwc_fwd on dy with these
+#include "common.h"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ v16f mfma(float a, float b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// =====================================================================================================================
+// generic per-channel elementwise pass with column sums
+struct ChanOpArgs {
+    const float *g, *x;
+    float* out;
+    const float *alpha, *beta, *kappa, *ms, *mt;
+    long long n_rows;
+    int C, g_cs, x_cs, out_cs, mask_mode, accumulate, sum_mode, rows_per_block;
+    float* partials;      // [gridDim.y][2][C]
+};
+
+
+template <int QX>
+__global__ __launch_bounds__(256) void chan_op_kernel(const ChanOpArgs A) {
+    constexpr int RY = 256 / QX;
+    __shared__ float red[RY][QX][8];
+    const int tx = threadIdx.x % QX, ty = threadIdx.x / QX;
+    const int q = blockIdx.x * QX + tx;
+    const bool valid = q * 4 < A.C;
+    const int c0 = q * 4;
+    auto ld4 = [&](const float* p, float dflt) {
+        return (p && valid) ? *(const float4*)(p + c0) : make_float4(dflt, dflt, dflt, dflt);
+    };
+    const float4 al = ld4(A.alpha, 1.f), be = ld4(A.beta, 0.f), ka = ld4(A.kappa, 0.f), ms = ld4(A.ms, 1.f),
+                 mt = ld4(A.mt, 0.f);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const long long r0 = (long long)blockIdx.y * A.rows_per_block;
+    const long long r1 = r0 + A.rows_per_block < A.n_rows ? r0 + A.rows_per_block : A.n_rows;
+    if (valid) {
+        for (long long r = r0 + ty; r < r1; r += RY) {
+            const float4 gv = *(const float4*)(A.g + r * A.g_cs + c0);
+            const float4 xv = A.x ? *(const float4*)(A.x + r * A.x_cs + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float g[4] = {gv.x, gv.y, gv.z, gv.w}, x[4] = {xv.x, xv.y, xv.z, xv.w};
+            const float a4[4] = {al.x, al.y, al.z, al.w}, b4[4] = {be.x, be.y, be.z, be.w}, k4[4] = {ka.x, ka.y, ka.z, ka.w};
+            const float ms4[4] = {ms.x, ms.y, ms.z, ms.w}, mt4[4] = {mt.x, mt.y, mt.z, mt.w};
+            float res[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float m = 1.0f;
+                if (A.mask_mode == 1) m = (ms4[i] * x[i] + mt4[i] > 0.0f) ? 1.0f : 0.0f;
+                else if (A.mask_mode == 2) m = x[i] > 0.0f ? 1.0f : x[i] + 1.0f;
+                const float gm = g[i] * m;
+                res[i] = (a4[i] * g[i] + b4[i] * x[i] + k4[i]) * m;
+                if (A.sum_mode == 1) s1[i] += gm, s2[i] += gm * x[i];
+                else if (A.sum_mode == 2) s1[i] += res[i], s2[i] += res[i] * x[i];
+            }
+            if (A.out) {
+                float* o = A.out + r * A.out_cs + c0;
+                if (A.accumulate) {
+                    const float4 ov = *(const float4*)o;
+                    res[0] += ov.x, res[1] += ov.y, res[2] += ov.z, res[3] += ov.w;
+                }
+                *(float4*)o = make_float4(res[0], res[1], res[2], res[3]);
+            }
+        }
+    }
+    if (A.sum_mode == 0) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[ty][tx][i] = s1[i], red[ty][tx][4 + i] = s2[i];
+    __syncthreads();
+    if (ty == 0 && valid) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = red[0][tx][i];
+        for (int y = 1; y < RY; ++y)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] += red[y][tx][i];
+        float* p = A.partials + (size_t)blockIdx.y * 2 * A.C + c0;
+        *(float4*)p = make_float4(t[0], t[1], t[2], t[3]);
+        *(float4*)(p + A.C) = make_float4(t[4], t[5], t[6], t[7]);
+    }
+}
+
+// sums[s][c] = sum over the P row-chunk partials, in a fixed order, accumulated in double
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int P, int C,
+                                                              float* __restrict__ sums, int row_stride) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * C) return;
+    double s = 0.0;
+    for (int p = 0; p < P; ++p) s += (double)partials[(size_t)p * 2 * C + i];
+    sums[i < C ? i : row_stride + (i - C)] = (float)s;
+}
+
+// =====================================================================================================================
+// training-mode BatchNorm as a folded affine. sums = (sum x, sum x^2) over n rows.
+__global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restrict__ sums, int sums_row_stride, int C, double n,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ scale,
+                                                          float* __restrict__ shift, float* __restrict__ mean_out,
+                                                          float* __restrict__ rstd_out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double mean = (double)sums[c] / n;
+    double var = (double)sums[sums_row_stride + c] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+    const float s = (float)((double)g * rstd);
+    scale[c] = s;
+    shift[c] = (float)((double)b - mean * (double)s);
+    mean_out[c] = (float)mean;
+    rstd_out[c] = (float)rstd;
+    if (running_mean) {   // torch: running = (1 - momentum) * running + momentum * batch (unbiased variance)
+        const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+    }
+}
+
+// (d scale, d shift) -> d gamma, d beta and the two per-channel coefficients of the statistics' own gradient:
+//   dx += cb[c] * x + ck[c]     (= d mean / n + 2 (x - mean) d var / n)
+__global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, int C, double n,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          float* __restrict__ cb, float* __restrict__ ck, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double g = gamma ? (double)gamma[c] : 1.0, mu = (double)mean[c], r = (double)rstd[c];
+    const double dt = (double)dshift[c], ds = (double)dscale[c] - dt * mu;     // shift = beta - mean * scale
+    const double s = g * r;
+    const double dmean = -dt * s, dvar = -0.5 * ds * g * r * r * r;
+    if (dgamma) dgamma[c] = (float)(ds * r);
+    if (dbeta) dbeta[c] = (float)dt;
+    const double b = 2.0 * dvar / n, k = dmean / n - 2.0 * mu * dvar / n;
+    if (accumulate) {
+        cb[c] += (float)b;
+        ck[c] += (float)k;
+    } else {
+        cb[c] = (float)b;
+        ck[c] = (float)k;
+    }
+}
+
+// =====================================================================================================================
+// 2x2 average pooling, stride 1 or 2, channels-last
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float4* __restrict__ x, int H, int W, int C4, int stride,
+                                                           int Ho, int Wo, size_t total, float4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C4);
+    size_t r = i / C4;
+    const int xo = (int)(r % Wo);
+    r /= Wo;
+    const int yo = (int)(r % Ho), b = (int)(r / Ho);
+    const float4* p = x + (((size_t)b * H + (size_t)yo * stride) * W + (size_t)xo * stride) * C4 + c;
+    const float4 a = p[0], bb = p[C4], cc = p[(size_t)W * C4], d = p[(size_t)W * C4 + C4];
+    out[i] = make_float4(0.25f * ((a.x + bb.x) + (cc.x + d.x)), 0.25f * ((a.y + bb.y) + (cc.y + d.y)),
+                         0.25f * ((a.z + bb.z) + (cc.z + d.z)), 0.25f * ((a.w + bb.w) + (cc.w + d.w)));
+}
+
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float4* __restrict__ dout, int H, int W, int C4, int stride,
+                                                           int Ho, int Wo, size_t total, float4* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C4);
+    size_t r = i / C4;
+    const int X = (int)(r % W);
+    r /= W;
+    const int Y = (int)(r % H), b = (int)(r / H);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        const int yy = Y - dy;
+        if (yy < 0 || yy % stride) continue;
+        const int yo = yy / stride;
+        if (yo >= Ho) continue;
+#pragma unroll
+        for (int dxx = 0; dxx < 2; ++dxx) {
+            const int xx = X - dxx;
+            if (xx < 0 || xx % stride) continue;
+            const int xo = xx / stride;
+            if (xo >= Wo) continue;
+            const float4 v = dout[(((size_t)b * Ho + yo) * Wo + xo) * C4 + c];
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+    }
+    dx[i] = make_float4(0.25f * s.x, 0.25f * s.y, 0.25f * s.z, 0.25f * s.w);
+}
+
+// gradient of nearest-neighbour up-sampling [Hs][Ws] -> [H][W]: source pixel (sy, sx) sums the destination pixels that
+// read it: rows row_start[sy] .. row_start[sy+1]-1, columns col_start[sx] .. col_start[sx+1]-1 (tables built by the caller
+// with the forward's own index formula)
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float4* __restrict__ dup, int Hs, int Ws, int H, int W, int C4,
+                                                           const int* __restrict__ row_start, const int* __restrict__ col_start,
+                                                           size_t total, float4* __restrict__ dsrc) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C4);
+    size_t r = i / C4;
+    const int sx = (int)(r % Ws);
+    r /= Ws;
+    const int sy = (int)(r % Hs), b = (int)(r / Hs);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int y = row_start[sy]; y < row_start[sy + 1]; ++y)
+        for (int x = col_start[sx]; x < col_start[sx + 1]; ++x) {
+            const float4 v = dup[(((size_t)b * H + y) * W + x) * C4 + c];
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+    dsrc[i] = s;
+}
+
+// =====================================================================================================================
+// weights for the data gradient: the convolution dx = conv(dy, W') with W'[ci][co][tap] = W[co][ci][taps-1-tap]
+// (transposed, rotated by 180 degrees), packed exactly as pack_conv_kernel packs a [Cout' = Cin][Cin' = Cout] layer
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict__ w, int Cout, int Cin, int taps,
+                                                         float4* __restrict__ wpk, size_t total) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int lane = i & 63;
+    size_t r = i >> 6;
+    const int tap = r % taps;
+    r /= taps;
+    const int kb = r % (Cout / 8);                  // blocks of 8 "input" channels of the transposed layer = co
+    const int mt = r / (Cout / 8);                  // tiles of 32 "output" channels = ci
+    const int ci = mt * 32 + (lane & 31), co = kb * 8 + 4 * (lane >> 5);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (ci < Cin) ? w[((size_t)(co + e) * Cin + ci) * taps + (taps - 1 - tap)] : 0.0f;
+    wpk[i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// =====================================================================================================================
+// weight gradient: dW[co][ci][tap] = sum_px dY[px][co] * P(X)[px + tap][ci],  P = the forward's input prologue
+// (per-channel affine (+ReLU) on real pixels, zero outside the image). GEMM with the PIXELS on K:
+// v_mfma_f32_32x32x2_f32, A = dY (rows = output channels, k = two consecutive pixels, one per lane half), B = P(X)
+// shifted by the tap (columns = input channels). A workgroup owns a (WM*TM*32) x (WN*TN*32) tile of (co, ci) for one
+// kernel row and a share of the row-chunks (split-K); a chunk = KT consecutive pixels
+// of one image row, staged through double-buffered LDS with 16-byte global loads ([px][channel]: an operand read is one
+// conflict-free ds_read_b32 per lane), next chunk's loads in flight under the current chunk's MFMAs. Partial results go
+// to slabs [split][tap][co][ci], summed in a fixed order by wgrad_reduce2_kernel: bit-reproducible, no float atomics.
+struct WgradArgs {
+    const float *x, *dy, *pre_scale, *pre_shift;
+    float* slabs;
+    int B, H, W, Cin, Cout, in_cs, dy_cs, pre_relu, KT, chunks_per_row, nsplit, co_blocks, ci_blocks, ntiles;
+    int Hs, Ws;             // x is [B][Hs][Ws][..], nearest-neighbour up-sampled to [H][W] on the fly (Hs == H: plain)
+    float scale_h, scale_w;
+    long long n_chunks;     // B * H * chunks_per_row
+};
+
+template <int TAPS, int KYB, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
+    constexpr int CO_T = WM * TM * 32, CI_T = WN * TN * 32;
+    constexpr int KX = TAPS == 9 ? 3 : 1;
+    constexpr int NT = TM * TN * KX * KYB;                   // accumulator tiles per wave
+    constexpr int HALO = TAPS == 9 ? 2 : 0;
+    constexpr int KTMAX = 48;
+    constexpr int DY4 = CO_T / 4, X4 = CI_T / 4;              // float4 per staged pixel
+    constexpr int NLD_DY = (KTMAX * DY4 + 255) / 256, NLD_X = (KYB * (KTMAX + HALO) * X4 + 255) / 256;
+    static_assert(WM * WN == 4 && 256 % DY4 == 0 && 256 % X4 == 0, "bad tiling");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int KT = A.KT;
+    const int dy_buf = KT * CO_T, x_buf = KYB * (KT + HALO) * CI_T;      // floats per buffer
+    float* dyl = lds;                                // [2][KT][CO_T]
+    float* xl = lds + 2 * dy_buf;                    // [2][KYB][KT + HALO][CI_T]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int wm = wave % WM, wn = wave / WM;
+
+    // ---- which tile / split: XCD x takes splits x, x+8, ...; consecutive workgroups of an XCD walk the tiles of ONE
+    // split, i.e. re-read the same dY / X rows from that XCD's L2 (placement only -- any mapping computes the same sums)
+    const int L = blockIdx.x;
+    const int j = L >> 3;
+    const int split = (L & 7) + 8 * (j / A.ntiles);
+    int tile = j % A.ntiles;
+    if (split >= A.nsplit) return;
+    int ky0 = 0;
+    if (TAPS == 9 && KYB == 1) {
+        ky0 = tile % 3;
+        tile /= 3;
+    }
+    const int cib = tile % A.ci_blocks, cob = tile / A.ci_blocks;
+    const int co0 = cob * CO_T, ci0 = cib * CI_T;
+
+    v16f acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // staging maps (fixed per thread): dY element e -> (pixel, co quad); X element e -> (ky row, position, ci quad)
+    const int dyq = tid % DY4, xq = tid % X4;
+    const bool dyq_ok = co0 + 4 * dyq < A.Cout, xq_ok = ci0 + 4 * xq < A.Cin;
+    float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (A.pre_scale && xq_ok) {
+        ps = *(const float4*)(A.pre_scale + ci0 + 4 * xq);
+        pt = *(const float4*)(A.pre_shift + ci0 + 4 * xq);
+    }
+    float4 sdy[NLD_DY], sx[NLD_X];
+
+    const int H = A.H, W = A.W;
+    auto chunk_geom = [&](long long ch, int& b, int& y, int& x0) {
+        const int cr = (int)(ch % A.chunks_per_row);
+        const long long row = ch / A.chunks_per_row;
+        y = (int)(row % H);
+        b = (int)(row / H);
+        x0 = cr * KT;
+    };
+    auto stage_load = [&](long long ch) {
+        int b, y, x0;
+        chunk_geom(ch, b, y, x0);
+        const float* dyr = A.dy + ((size_t)(b * H + y) * W) * A.dy_cs + co0 + 4 * dyq;
+#pragma unroll
+        for (int e = 0; e < NLD_DY; ++e) {
+            const int p = (tid + e * 256) / DY4;               // pixel within the chunk
+            const bool ok = p < KT && x0 + p < W && dyq_ok;
+            sdy[e] = ok ? *(const float4*)(dyr + (size_t)(x0 + p) * A.dy_cs) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < NLD_X; ++e) {
+            const int idx = (tid + e * 256) / X4;              // (ky row, position)
+            const int kr = idx / (KT + HALO), p = idx - kr * (KT + HALO);
+            const int yy = y + (TAPS == 9 ? ky0 + kr - 1 : 0), xx = x0 + p - (TAPS == 9 ? 1 : 0);
+            const bool ok = kr < KYB && yy >= 0 && yy < H && xx >= 0 && xx < W && xq_ok;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                // same index formula as the forward's fused up-sampling (csrc/conv.hip stage map)
+                const int sy = (A.Hs == H) ? yy : min((int)floorf((float)yy * A.scale_h), A.Hs - 1);
+                const int sxx = (A.Ws == W) ? xx : min((int)floorf((float)xx * A.scale_w), A.Ws - 1);
+                v = *(const float4*)(A.x + ((size_t)(b * A.Hs + sy) * A.Ws + sxx) * A.in_cs + ci0 + 4 * xq);
+                if (A.pre_scale) {
+                    v.x = v.x * ps.x + pt.x, v.y = v.y * ps.y + pt.y, v.z = v.z * ps.z + pt.z, v.w = v.w * ps.w + pt.w;
+                    if (A.pre_relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                }
+            }
+            sx[e] = v;
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < NLD_DY; ++e) {
+            const int idx = tid + e * 256;
+            if (idx < KT * DY4) *(float4*)(dyl + (size_t)buf * dy_buf + (size_t)idx * 4) = sdy[e];
+        }
+#pragma unroll
+        for (int e = 0; e < NLD_X; ++e) {
+            const int idx = tid + e * 256;
+            if (idx < KYB * (KT + HALO) * X4) *(float4*)(xl + (size_t)buf * x_buf + (size_t)idx * 4) = sx[e];
+        }
+    };
+
+    long long ch = split;
+    if (ch < A.n_chunks) {
+        stage_load(ch);
+        stage_write(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    const int ksteps = KT / 2;
+#pragma unroll 1
+    for (; ch < A.n_chunks; ch += A.nsplit) {
+        const long long nxt = ch + A.nsplit;
+        if (nxt < A.n_chunks) stage_load(nxt);
+        const float* da = dyl + (size_t)buf * dy_buf + (size_t)h * CO_T + wm * TM * 32 + c;
+        const float* xb = xl + (size_t)buf * x_buf + (size_t)h * CI_T + wn * TN * 32 + c;
+        float a[2][TM], bv[2][KYB][TN][KX];
+        auto fetch = [&](int k, float(&aa)[TM], float(&bb)[KYB][TN][KX]) {
+#pragma unroll
+            for (int m = 0; m < TM; ++m) aa[m] = da[(size_t)(2 * k) * CO_T + 32 * m];
+#pragma unroll
+            for (int kr = 0; kr < KYB; ++kr)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int kx = 0; kx < KX; ++kx)
+                        bb[kr][n][kx] = xb[((size_t)kr * (KT + HALO) + 2 * k + kx) * CI_T + 32 * n];
+        };
+        auto run = [&](const float(&aa)[TM], const float(&bb)[KYB][TN][KX]) {
+#pragma unroll
+            for (int kr = 0; kr < KYB; ++kr)
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+#pragma unroll
+                        for (int kx = 0; kx < KX; ++kx) {
+                            const int t = ((kr * TM + m) * TN + n) * KX + kx;
+                            acc[t] = mfma(aa[m], bb[kr][n][kx], acc[t]);
+                        }
+        };
+        // operands of k-step k+1 are read from LDS while the MFMAs of step k run (KT is even; two steps per trip)
+        fetch(0, a[0], bv[0]);
+#pragma unroll 1
+        for (int k = 0; k < ksteps; k += 2) {
+            if (k + 1 < ksteps) fetch(k + 1, a[1], bv[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            run(a[0], bv[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < ksteps) {
+                if (k + 2 < ksteps) fetch(k + 2, a[0], bv[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                run(a[1], bv[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (nxt < A.n_chunks) stage_write(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- slab [split][tap][Cout][Cin]: rows of an accumulator tile = output channels (registers), columns = input
+    // channels (lanes): 128-byte rows
+    float* slab = A.slabs + (size_t)split * TAPS * A.Cout * A.Cin;
+#pragma unroll
+    for (int kr = 0; kr < KYB; ++kr)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                const int ci = ci0 + (wn * TN + n) * 32 + c;
+                if (ci >= A.Cin) continue;
+#pragma unroll
+                for (int kx = 0; kx < KX; ++kx) {
+                    const int t = ((kr * TM + m) * TN + n) * KX + kx;
+                    const int tap = TAPS == 9 ? (ky0 + kr) * 3 + kx : 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = co0 + (wm * TM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (co < A.Cout) slab[((size_t)tap * A.Cout + co) * A.Cin + ci] = acc[t][r];
+                    }
+                }
+            }
+}
+
+// dw[co][ci][tap] (+)= sum over splits of slabs[split][tap][co][ci]
+__global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restrict__ slabs, int nsplit, int taps, int Cout,
+                                                            int Cin, float* __restrict__ dw, int accumulate) {
+    const size_t n = (size_t)taps * Cout * Cin;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // index in [tap][co][ci] order: coalesced reads
+    if (i >= n) return;
+    const int ci = (int)(i % Cin);
+    const size_t r = i / Cin;
+    const int co = (int)(r % Cout), tap = (int)(r / Cout);
+    float s = 0.0f;
+    for (int k = 0; k < nsplit; ++k) s += slabs[(size_t)k * n + i];
+    float* o = dw + ((size_t)co * Cin + ci) * taps + tap;
+    *o = accumulate ? *o + s : s;
+}
+
+struct WgradPlan {
+    int variant;     // 0: <9,1,2,1,2,2> 128 co x 64 ci   1: <9,1,1,2,2,2> 64 x 128   2: <9,1,1,1,1,4> 32 x 128
+                     // 3: <1,1,2,2,2,2> 128 x 128 (1x1)  4: <1,1,1,2,2,2> 64 x 128 (1x1)
+    int co_t, ci_t, KT, chunks_per_row, nsplit, co_blocks, ci_blocks, ntiles, B, H, W;
+    long long n_chunks;
+    size_t lds;
+};
+
+bool wgrad_plan(int B, int H, int W, int Cin, int Cout, int taps, WgradPlan& p) {
+    if ((long long)B * H * W > 0x3fffffffLL) return false;
+    if (taps == 9) {
+        if (Cout <= 32) p.variant = 2, p.co_t = 32, p.ci_t = 128;
+        else if (Cout <= 64 || Cout == 96) p.variant = 1, p.co_t = 64, p.ci_t = 128;
+        else p.variant = 0, p.co_t = 128, p.ci_t = 64;
+        p.B = B, p.H = H, p.W = W;
+        const int ktmax = 48;
+        p.chunks_per_row = (W + ktmax - 1) / ktmax;
+        p.KT = ((W + p.chunks_per_row - 1) / p.chunks_per_row + 1) & ~1;
+    } else if (taps == 1) {
+        if (Cout <= 64) p.variant = 4, p.co_t = 64, p.ci_t = 128;
+        else p.variant = 3, p.co_t = 128, p.ci_t = 128;
+        p.B = 1, p.H = 1, p.W = B * H * W;          // no halo: the whole tensor is one long pixel row
+        p.KT = 32;
+        p.chunks_per_row = (p.W + p.KT - 1) / p.KT;
+    } else {
+        return false;
+    }
+    p.n_chunks = (long long)p.B * p.H * p.chunks_per_row;
+    p.co_blocks = (Cout + p.co_t - 1) / p.co_t;
+    p.ci_blocks = (Cin + p.ci_t - 1) / p.ci_t;
+    p.ntiles = p.co_blocks * p.ci_blocks * (taps == 9 ? 3 : 1);
+    // two to three workgroups per CU in all, in multiples of 8 splits (one per XCD); every split costs a slab
+    long want = (640 + p.ntiles - 1) / p.ntiles;
+    want = (want + 7) / 8 * 8;
+    if (want < 8) want = 8;
+    while (want > 8 && want > p.n_chunks) want -= 8;
+    p.nsplit = (int)want;
+    const int halo = taps == 9 ? 2 : 0;
+    p.lds = (size_t)2 * (p.KT * p.co_t + (p.KT + halo) * p.ci_t) * sizeof(float);
+    return true;
+}
+
+template <int TAPS, int KYB, int TM, int TN, int WM, int WN>
+int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t s) {
+    auto kern = wgrad_kernel<TAPS, KYB, TM, TN, WM, WN>;
+    OSSID_ENSURE_LDS(kern, p.lds);
+    const long nwg = 8L * ((long)(p.nsplit + 7) / 8) * p.ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), p.lds, s, a);
+    return ossid_launch_status();
+}
+
+template <int QX>
+int launch_chan_op(const ChanOpArgs& a, int P, hipStream_t s) {
+    const int C4 = (a.C + 3) / 4;
+    hipLaunchKernelGGL(chan_op_kernel<QX>, dim3((C4 + QX - 1) / QX, P), dim3(256), 0, s, a);
+    return ossid_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int ossid_chan_op_partials(long long n_rows, int C) {
+    const int C4 = (C + 3) / 4;
+    const int QX = C4 <= 8 ? 8 : C4 <= 16 ? 16 : C4 <= 32 ? 32 : 64;
+    const int gx = (C4 + QX - 1) / QX, RY = 256 / QX;
+    long P = (2048 + gx - 1) / gx;
+    const long maxP = (long)((n_rows + 4 * RY - 1) / (4 * RY));          // at least 4 rows per thread
+    if (P > maxP) P = maxP;
+    if (P < 1) P = 1;
+    return (int)P;
+}
+
+int ossid_chan_op(const ossid_chan_op_desc* d, void* stream) {
+    if (!d) return OSSID_EINVAL;
+    if (d->n_rows < 0 || d->channels <= 0 || d->channels % 4) return OSSID_EINVAL;
+    if (d->n_rows == 0) return OSSID_OK;
+    if (!d->g || (d->mask_mode != 0 && !d->x) || d->mask_mode < 0 || d->mask_mode > 2 || d->sum_mode < 0 || d->sum_mode > 2)
+        return OSSID_EINVAL;
+    if (d->sum_mode != 0 && (!d->partials || !d->sums)) return OSSID_EINVAL;
+    if (!d->out && d->sum_mode == 0) return OSSID_EINVAL;
+    ChanOpArgs a;
+    a.g = d->g, a.x = d->x, a.out = d->out, a.alpha = d->alpha, a.beta = d->beta, a.kappa = d->kappa;
+    a.ms = d->mask_scale, a.mt = d->mask_shift, a.n_rows = d->n_rows, a.C = d->channels;
+    a.g_cs = d->g_stride > 0 ? d->g_stride : d->channels;
+    a.x_cs = d->x_stride > 0 ? d->x_stride : d->channels;
+    a.out_cs = d->out_stride > 0 ? d->out_stride : d->channels;
+    if ((a.g_cs % 4) || (a.x_cs % 4) || (a.out_cs % 4)) return OSSID_EINVAL;
+    a.mask_mode = d->mask_mode, a.accumulate = d->accumulate, a.sum_mode = d->sum_mode;
+    a.partials = d->partials;
+    const int P = ossid_chan_op_partials(d->n_rows, d->channels);
+    a.rows_per_block = (int)((d->n_rows + P - 1) / P);
+    const int C4 = d->channels / 4;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (C4 <= 8) rc = launch_chan_op<8>(a, P, s);
+    else if (C4 <= 16) rc = launch_chan_op<16>(a, P, s);
+    else if (C4 <= 32) rc = launch_chan_op<32>(a, P, s);
+    else rc = launch_chan_op<64>(a, P, s);
+    if (rc != OSSID_OK || d->sum_mode == 0) return rc;
+    const int C2 = 2 * d->channels;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C2 + 255) / 256), dim3(256), 0, s, (const float*)d->partials, P,
+                       d->channels, d->sums, d->sums_row_stride > 0 ? d->sums_row_stride : d->channels);
+    return ossid_launch_status();
+}
+
+int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, int C, double n, const float* gamma, const float* beta, float eps, float momentum,
+                      float* running_mean, float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out,
+                      void* stream) {
+    if (!sums || C <= 0 || n <= 0 || !scale || !shift || !mean_out || !rstd_out || (!running_mean != !running_var))
+        return OSSID_EINVAL;
+    hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums,
+                       sums_row_stride > 0 ? sums_row_stride : C, C, n, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean_out, rstd_out);
+    return ossid_launch_status();
+}
+
+int ossid_bn_fold_bwd(const float* dscale, const float* dshift, const float* gamma, const float* mean, const float* rstd,
+                      int C, double n, float* dgamma, float* dbeta, float* coef_x, float* coef_1, int accumulate,
+                      void* stream) {
+    if (!dscale || !dshift || !mean || !rstd || C <= 0 || n <= 0 || !coef_x || !coef_1) return OSSID_EINVAL;
+    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dscale, dshift, gamma,
+                       mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate);
+    return ossid_launch_status();
+}
+
+int ossid_avgpool2_nhwc(const float* x, int B, int H, int W, int C, int stride, float* out, int backward, void* stream) {
+    if (!x || !out || B <= 0 || H < 2 || W < 2 || C <= 0 || C % 4 || (stride != 1 && stride != 2)) return OSSID_EINVAL;
+    const int Ho = (H - 2) / stride + 1, Wo = (W - 2) / stride + 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (!backward) {
+        const size_t total = (size_t)B * Ho * Wo * (C / 4);
+        hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4*)x, H, W,
+                           C / 4, stride, Ho, Wo, total, (float4*)out);
+    } else {      // x = d out [B][Ho][Wo][C], out = d in [B][H][W][C]
+        const size_t total = (size_t)B * H * W * (C / 4);
+        hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4*)x, H, W,
+                           C / 4, stride, Ho, Wo, total, (float4*)out);
+    }
+    return ossid_launch_status();
+}
+
+int ossid_upsample_nearest_bwd_nhwc(const float* dup, int B, int Hs, int Ws, int H, int W, int C, const int32_t* row_start,
+                                    const int32_t* col_start, float* dsrc, void* stream) {
+    if (!dup || !dsrc || !row_start || !col_start || B <= 0 || Hs <= 0 || Ws <= 0 || H < Hs || W < Ws || C <= 0 || C % 4)
+        return OSSID_EINVAL;
+    const size_t total = (size_t)B * Hs * Ws * (C / 4);
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dup, Hs, Ws, H, W, C / 4, row_start, col_start, total, (float4*)dsrc);
+    return ossid_launch_status();
+}
+
+int ossid_conv_pack_weights_dgrad(const float* w, int Cout, int Cin, int taps, float* wpk, void* stream) {
+    if (!w || !wpk || Cout <= 0 || Cin <= 0 || Cout % 16 || (taps != 1 && taps != 9)) return OSSID_EINVAL;
+    const size_t total = ossid_conv_packed_floats(Cin, Cout, taps) / 4;        // a [Cout' = Cin][Cin' = Cout] layer
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout,
+                       Cin, taps, (float4*)wpk, total);
+    return ossid_launch_status();
+}
+
+size_t ossid_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps) {
+    WgradPlan p;
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !wgrad_plan(B, H, W, Cin, Cout, taps, p)) return 0;
+    return (size_t)p.nsplit * taps * Cout * Cin * sizeof(float);
+}
+
+int ossid_conv_wgrad(const ossid_wgrad_desc* d, void* stream) {
+    if (!d) return OSSID_EINVAL;
+    const int B = d->batch, H = d->height, W = d->width, Cin = d->cin, Cout = d->cout, taps = d->taps;
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 4) || (Cout % 4)) return OSSID_EINVAL;
+    if (!d->x || !d->dy || !d->dw || !d->workspace || (d->pre_scale && !d->pre_shift)) return OSSID_EINVAL;
+    WgradPlan p;
+    if (!wgrad_plan(B, H, W, Cin, Cout, taps, p)) return OSSID_EINVAL;
+    if (d->workspace_bytes < (size_t)p.nsplit * taps * Cout * Cin * sizeof(float)) return OSSID_EINVAL;
+    WgradArgs a;
+    a.x = d->x, a.dy = d->dy, a.pre_scale = d->pre_scale, a.pre_shift = d->pre_shift, a.slabs = (float*)d->workspace;
+    a.B = p.B, a.H = p.H, a.W = p.W, a.Cin = Cin, a.Cout = Cout;
+    a.in_cs = d->in_channel_stride > 0 ? d->in_channel_stride : Cin;
+    a.dy_cs = d->dy_channel_stride > 0 ? d->dy_channel_stride : Cout;
+    if ((a.in_cs % 4) || (a.dy_cs % 4) || a.in_cs < Cin || a.dy_cs < Cout) return OSSID_EINVAL;
+    a.Hs = d->src_height > 0 ? d->src_height : p.H, a.Ws = d->src_width > 0 ? d->src_width : p.W;
+    if ((a.Hs != p.H || a.Ws != p.W) && (taps != 9 || a.Hs > H || a.Ws > W)) return OSSID_EINVAL;
+    a.scale_h = (float)a.Hs / (float)p.H, a.scale_w = (float)a.Ws / (float)p.W;
+    a.pre_relu = d->pre_relu, a.KT = p.KT, a.chunks_per_row = p.chunks_per_row, a.nsplit = p.nsplit;
+    a.co_blocks = p.co_blocks, a.ci_blocks = p.ci_blocks, a.ntiles = p.ntiles, a.n_chunks = p.n_chunks;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    switch (p.variant) {
+        case 0: rc = launch_wgrad<9, 1, 2, 1, 2, 2>(a, p, s); break;
+        case 1: rc = launch_wgrad<9, 1, 1, 2, 2, 2>(a, p, s); break;
+        case 2: rc = launch_wgrad<9, 1, 1, 1, 1, 4>(a, p, s); break;
+        case 3: rc = launch_wgrad<1, 1, 2, 2, 2, 2>(a, p, s); break;
+        default: rc = launch_wgrad<1, 1, 1, 2, 2, 2>(a, p, s); break;
+    }
+    if (rc != OSSID_OK) return rc;
+    const size_t n = (size_t)taps * Cout * Cin;
+    hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)d->workspace,
+                       p.nsplit, taps, Cout, Cin, d->dw, d->accumulate);
+    return ossid_launch_status();
+}
+
+}  // extern "C"

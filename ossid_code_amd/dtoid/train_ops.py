@@ -1,0 +1,474 @@
+"""Training-mode (finetune) execution of the DTOID convolutions on the hand-written kernels, channels-last end to end.
+
+Reference step being reproduced: scripts/online_learning.py:650-679 (`model.train(); out = model(batch);
+out['loss'].backward(); optimizer.step()`) over models/dtoid/network.py:439-471. What is MI355X-specific:
+
+  * every 3x3 / 1x1 convolution runs forward, data gradient and weight gradient on the f32 matrix cores
+    (csrc/conv.hip, csrc/train.hip), exact f32, on [B][H][W][C] tensors -- no NCHW<->NHWC transposes;
+  * training-mode BatchNorm never materialises its output: batch statistics are column sums of the producer's output
+    (`ossid_chan_op`), folded with gamma / beta into a per-channel (scale, shift) (`ossid_bn_fold_fwd`) that the NEXT
+    convolution applies -- with the ReLU -- while it stages its input. In a dense block the statistics of a feature
+    channel are computed ONCE, when the channel is produced, and shared by every later layer (they all normalise the
+    same values): O(L) reductions instead of DenseNet's O(L^2);
+  * backward passes are the same few kernels: ELU' / ReLU masks, the BatchNorm-statistics gradient and the bias /
+    scale / shift reductions are all instances of one generic pass (`ossid_chan_op`); a dense block keeps ONE gradient
+    buffer and every layer accumulates into its channel prefix in place.
+
+autograd sees a handful of coarse Functions (FusedConv, BNFold, ColStats, AvgPool2, DenseBlockTrain); tensors are
+logical NCHW in torch.channels_last memory format, so torch ops (losses, the few layers left on MIOpen) interoperate.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+_byref = ctypes.byref
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def nhwc(x):
+    return x.float().contiguous(memory_format=torch.channels_last)
+
+
+def empty_nhwc(B, C, H, W, device):
+    return torch.empty((B, C, H, W), dtype=torch.float32, device=device, memory_format=torch.channels_last)
+
+
+def flat(t, offset=0):
+    """1-D alias of a channels-last tensor's memory ([B][H][W][C] order), from element `offset` on: how a channel
+    slice of a wider buffer is handed to the raw ops (pointer to its first element + the buffer's channel stride)."""
+    v = t.permute(0, 2, 3, 1).reshape(-1)
+    assert v.data_ptr() == t.data_ptr(), "expected a dense channels-last tensor"
+    return v[offset:]
+
+
+# ---- per-(device, stream) scratch: column-sum partials, split-K slabs -------------------------------------------------
+_SCRATCH = {}
+
+
+def _scratch(name, nbytes, device):
+    key = (name, str(device), torch.cuda.current_stream(device).cuda_stream)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = t
+    return t
+
+
+# ---- raw ops (no autograd) --------------------------------------------------------------------------------------------
+def chan_op(g, n_rows, C, x=None, out=None, g_cs=0, x_cs=0, out_cs=0, alpha=None, beta=None, kappa=None, mask_mode=0,
+            mask_scale=None, mask_shift=None, accumulate=False, sum_mode=0, sums=None, sums_row_stride=0):
+    """include/ossid_hip.h ossid_chan_op on raw channels-last buffers (tensors only provide pointers; a tensor that is a
+    channel slice of a wider buffer is passed as its first-element pointer + the buffer's channel count as stride).
+    Returns `sums` ([2, C] float32, allocated when sum_mode != 0 and none was given)."""
+    d = _lib.ChanOpDesc()
+    dev = g.device
+    d.g, d.x, d.out = g.data_ptr(), _p(x), _p(out)
+    d.alpha, d.beta, d.kappa, d.mask_scale, d.mask_shift = _p(alpha), _p(beta), _p(kappa), _p(mask_scale), _p(mask_shift)
+    d.n_rows, d.channels, d.g_stride, d.x_stride, d.out_stride = int(n_rows), int(C), int(g_cs), int(x_cs), int(out_cs)
+    d.mask_mode, d.accumulate, d.sum_mode, d.sums_row_stride = int(mask_mode), 1 if accumulate else 0, int(sum_mode), int(sums_row_stride)
+    if sum_mode:
+        if sums is None:
+            sums = torch.empty((2, C), dtype=torch.float32, device=dev)
+        P = _lib.fn("ossid_chan_op_partials")(int(n_rows), int(C))
+        d.partials = _scratch("chan", P * 2 * C * 4, dev).data_ptr()
+        d.sums = sums.data_ptr()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.fn("ossid_chan_op")(_byref(d), _lib.stream()), "ossid_chan_op")
+    return sums
+
+
+class _Packed:
+    """Per-weight-tensor device buffers for the MFMA operand layouts (forward and data-gradient), re-filled every step
+    IN PLACE (the step is captured in a hipGraph: addresses must not change)."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, w, kind):
+        key = (w.data_ptr(), tuple(w.shape), kind)
+        ent = cls._cache.get(key)
+        if ent is None:
+            cout, cin = int(w.shape[0]), int(w.shape[1])
+            taps = int(w.shape[2] * w.shape[3])
+            n = _lib.fn("ossid_conv_packed_floats")(cout, cin, taps) if kind == "fwd" else \
+                _lib.fn("ossid_conv_packed_floats")(cin, cout, taps)
+            if len(cls._cache) > 4096:
+                cls._cache.clear()
+            ent = cls._cache[key] = torch.empty(n, dtype=torch.float32, device=w.device)
+        return ent
+
+
+def _pack(w, kind):
+    w = w.detach()
+    assert w.is_contiguous() and w.dtype == torch.float32
+    cout, cin, taps = int(w.shape[0]), int(w.shape[1]), int(w.shape[2] * w.shape[3])
+    buf = _Packed.get(w, kind)
+    name = "ossid_conv_pack_weights" if kind == "fwd" else "ossid_conv_pack_weights_dgrad"
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.fn(name)(w.data_ptr(), cout, cin, taps, buf.data_ptr(), _lib.stream()), name)
+    return buf
+
+
+def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_relu=False, act=0, in_cs=0, out_cs=0,
+             out_coff=0, src_hw=(0, 0)):
+    d = _lib.ConvDesc()
+    d.x, d.wpk, d.bias, d.out = x.data_ptr(), wpk.data_ptr(), _p(bias), out.data_ptr()
+    if pre is not None:
+        d.pre_scale, d.pre_shift = pre[0].data_ptr(), pre[1].data_ptr()
+    d.in_batch_stride, d.pre_batch_stride = -1, 0
+    d.batch, d.height, d.width, d.cin, d.cout, d.taps = B, H, W, cin, cout, taps
+    d.act, d.pre_relu = int(act), 1 if pre_relu else 0
+    d.src_height, d.src_width = int(src_hw[0]), int(src_hw[1])
+    d.in_channel_stride, d.out_channel_stride, d.out_channel_offset = int(in_cs), int(out_cs), int(out_coff)
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.fn("ossid_conv_nhwc_fwd")(_byref(d), _lib.stream()), "ossid_conv_nhwc_fwd")
+    return out
+
+
+def wgrad_raw(x, dy, B, H, W, cin, cout, taps, dw, pre=None, pre_relu=False, in_cs=0, dy_cs=0, src_hw=(0, 0),
+              accumulate=False):
+    d = _lib.WgradDesc()
+    dev = dw.device
+    nbytes = _lib.fn("ossid_conv_wgrad_workspace_bytes")(B, H, W, cin, cout, taps)
+    ws = _scratch("wgrad", nbytes, dev)
+    d.x, d.dy, d.dw, d.workspace, d.workspace_bytes = x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes
+    if pre is not None:
+        d.pre_scale, d.pre_shift = pre[0].data_ptr(), pre[1].data_ptr()
+    d.batch, d.height, d.width, d.cin, d.cout, d.taps = B, H, W, cin, cout, taps
+    d.pre_relu, d.accumulate = 1 if pre_relu else 0, 1 if accumulate else 0
+    d.in_channel_stride, d.dy_channel_stride = int(in_cs), int(dy_cs)
+    d.src_height, d.src_width = int(src_hw[0]), int(src_hw[1])
+    with torch.cuda.device(dev):
+        _lib.check(_lib.fn("ossid_conv_wgrad")(_byref(d), _lib.stream()), "ossid_conv_wgrad")
+    return dw
+
+
+def bn_fold_fwd(sums, C, n, gamma, beta, eps, momentum, running_mean, running_var, sums_row_stride=0):
+    dev = sums.device
+    out = torch.empty((4, C), dtype=torch.float32, device=dev)          # scale, shift, mean, rstd
+    with torch.cuda.device(dev):
+        rc = _lib.fn("ossid_bn_fold_fwd")(sums.data_ptr(), int(sums_row_stride), C, float(n), _p(gamma), _p(beta), float(eps),
+                                          float(momentum), _p(running_mean), _p(running_var), out[0].data_ptr(),
+                                          out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _lib.stream())
+    _lib.check(rc, "ossid_bn_fold_fwd")
+    return out
+
+
+def bn_fold_bwd(dscale, dshift, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate=False):
+    with torch.cuda.device(coef_x.device):
+        rc = _lib.fn("ossid_bn_fold_bwd")(dscale.data_ptr(), dshift.data_ptr(), _p(gamma), mean.data_ptr(), rstd.data_ptr(),
+                                          C, float(n), _p(dgamma), _p(dbeta), coef_x.data_ptr(), coef_1.data_ptr(),
+                                          1 if accumulate else 0, _lib.stream())
+    _lib.check(rc, "ossid_bn_fold_bwd")
+
+
+def _mom(bn):
+    return 0.1 if bn.momentum is None else bn.momentum
+
+
+_UP_TABLES = {}
+
+
+def _upsample_tables(Hs, Ws, H, W, device):
+    """row_start / col_start of ossid_upsample_nearest_bwd_nhwc, from the forward's index formula
+    (min(floor(dst * (float)in / (float)out), in - 1) in float32, csrc/conv.hip)."""
+    key = (Hs, Ws, H, W, str(device))
+    if key not in _UP_TABLES:
+        def table(n_src, n_dst):
+            scale = torch.tensor(n_src, dtype=torch.float32) / torch.tensor(n_dst, dtype=torch.float32)
+            src = torch.clamp(torch.floor(torch.arange(n_dst, dtype=torch.float32) * scale).to(torch.int64), max=n_src - 1)
+            start = torch.searchsorted(src, torch.arange(n_src + 1, dtype=torch.int64))
+            return start.to(torch.int32).to(device)
+        _UP_TABLES[key] = (table(Hs, H), table(Ws, W))
+    return _UP_TABLES[key]
+
+
+def upsample_bwd(dup, B, Hs, Ws, H, W, C):
+    rs, cs = _upsample_tables(Hs, Ws, H, W, dup.device)
+    out = empty_nhwc(B, C, Hs, Ws, dup.device)
+    with torch.cuda.device(dup.device):
+        rc = _lib.fn("ossid_upsample_nearest_bwd_nhwc")(dup.data_ptr(), B, Hs, Ws, H, W, C, rs.data_ptr(), cs.data_ptr(),
+                                                        out.data_ptr(), _lib.stream())
+    _lib.check(rc, "ossid_upsample_nearest_bwd_nhwc")
+    return out
+
+
+# ---- autograd Functions -----------------------------------------------------------------------------------------------
+class ColStats(torch.autograd.Function):
+    """x [B,C,H,W] channels-last -> sums [2,C] = (sum x, sum x^2) over B*H*W. The gradient arriving on `sums` is, by the
+    private convention shared with BNFold, g[0] = d/d(sum x), g[1] = 2 * d/d(sum x^2), so dx = g[0][c] + g[1][c] * x."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(x)
+        B, C, H, W = x.shape
+        ctx.save_for_backward(x)
+        return chan_op(x, B * H * W, C, x=x, sum_mode=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        ones_zero = torch.zeros(C, dtype=torch.float32, device=x.device)
+        chan_op(x, B * H * W, C, x=x, out=dx, alpha=ones_zero, beta=g[1], kappa=g[0])
+        return dx
+
+
+class BNFold(torch.autograd.Function):
+    """Training-mode BatchNorm2d as a per-channel (scale, shift): forward(sums, gamma, beta) with the module's running
+    buffers updated in place (momentum, unbiased variance) exactly as nn.BatchNorm2d.train() does. Returns
+    stacked [2, C] = (scale, shift)."""
+
+    @staticmethod
+    def forward(ctx, sums, gamma, beta, n, bn):
+        C = int(sums.shape[1])
+        out = bn_fold_fwd(sums, C, n, gamma, beta, bn.eps, _mom(bn),
+                          bn.running_mean if bn.track_running_stats else None,
+                          bn.running_var if bn.track_running_stats else None)
+        ctx.save_for_backward(gamma, out)
+        ctx.n = n
+        return out[:2]
+
+    @staticmethod
+    def backward(ctx, g):
+        gamma, out = ctx.saved_tensors
+        C = int(out.shape[1])
+        g = g.contiguous()
+        res = torch.empty((4, C), dtype=torch.float32, device=out.device)      # dgamma, dbeta, coef_x, coef_1
+        bn_fold_bwd(g[0], g[1], gamma, out[2], out[3], C, ctx.n, res[0], res[1], res[2], res[3])
+        dsums = torch.stack([res[3], res[2]])      # ColStats convention: [d/d sum x, 2 d/d sum x^2]
+        return dsums, res[0], res[1], None, None
+
+
+def bn_fold(sums, n, bn):
+    """(scale, shift) of a training-mode nn.BatchNorm2d given the column sums of its input."""
+    st = BNFold.apply(sums, bn.weight, bn.bias, n, bn)
+    return st[0], st[1]
+
+
+class FusedConv(torch.autograd.Function):
+    """u = ELU?( conv( relu?( x * pre_scale + pre_shift ) [nearest-up-sampled to `size`], w ) + bias ), optionally with
+    the column sums of u as a second output (for the BatchNorm that follows). 3x3 / pad 1 / stride 1 or 1x1.
+    Backward: one generic pass for ELU' + the statistics' gradient + the bias gradient, the weight gradient on the
+    prologue'd input, the data gradient as the forward kernel on the rotated weights, an up-sampling window sum, one
+    generic pass for the prologue's mask / scale and the (d scale, d shift) sums."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, pre_scale, pre_shift, pre_relu, act_elu, size, want_stats):
+        x = nhwc(x)
+        B, Cin, Hs, Ws = x.shape
+        Cout, taps = int(w.shape[0]), int(w.shape[2] * w.shape[3])
+        H, W = (Hs, Ws) if size is None else (int(size[0]), int(size[1]))
+        pre = None if pre_scale is None else (pre_scale.contiguous(), pre_shift.contiguous())
+        u = empty_nhwc(B, Cout, H, W, x.device)
+        conv_raw(x, _pack(w, "fwd"), B, H, W, Cin, Cout, taps, u, bias=None if bias is None else bias.detach(), pre=pre,
+                 pre_relu=pre_relu, act=1 if act_elu else 0, src_hw=(Hs, Ws) if size is not None else (0, 0))
+        sums = chan_op(u, B * H * W, Cout, x=u, sum_mode=1) if want_stats else None
+        ctx.save_for_backward(x, w, u if (act_elu or want_stats) else None, None if pre is None else pre[0],
+                              None if pre is None else pre[1])
+        ctx.cfg = (pre_relu, act_elu, (H, W), want_stats, bias is not None)
+        if want_stats:
+            return u, sums
+        return u
+
+    @staticmethod
+    def backward(ctx, du, dsums=None):
+        x, w, u, ps, pt = ctx.saved_tensors
+        pre_relu, act_elu, (H, W), want_stats, has_bias = ctx.cfg
+        B, Cin, Hs, Ws = x.shape
+        Cout, taps = int(w.shape[0]), int(w.shape[2] * w.shape[3])
+        dev = x.device
+        N = B * H * W
+        du = nhwc(du)
+        need = ctx.needs_input_grad
+        # 1. through ELU and the statistics: dv = (du + dsums[1] * u + dsums[0]) * ELU'(u); column sums = bias gradient
+        db = None
+        use_stats = want_stats and dsums is not None
+        if act_elu or use_stats or (has_bias and need[2]):
+            dv = torch.empty_like(du) if (act_elu or use_stats) else None
+            sums = chan_op(du, N, Cout, x=u if (act_elu or use_stats) else None, out=dv,
+                           beta=dsums[1].contiguous() if use_stats else None,
+                           kappa=dsums[0].contiguous() if use_stats else None, mask_mode=2 if act_elu else 0,
+                           sum_mode=2 if (has_bias and need[2]) else 0)
+            if dv is None:
+                dv = du
+            if sums is not None:
+                db = sums[0].clone()
+        else:
+            dv = du
+        pre = None if ps is None else (ps, pt)
+        # 2. weight gradient on the (prologue'd, up-sampled) input
+        dw = None
+        if need[1]:
+            dw = torch.empty_like(w)
+            wgrad_raw(x, dv, B, H, W, Cin, Cout, taps, dw, pre=pre, pre_relu=pre_relu,
+                      src_hw=(Hs, Ws) if (H, W) != (Hs, Ws) else (0, 0))
+        # 3. data gradient
+        dx = dps = dpt = None
+        if need[0] or (pre is not None and (need[3] or need[4])):
+            dxu = empty_nhwc(B, Cin, H, W, dev)
+            conv_raw(dv, _pack(w, "dgrad"), B, H, W, Cout, Cin, taps, dxu)
+            if (H, W) != (Hs, Ws):
+                dxu = upsample_bwd(dxu, B, Hs, Ws, H, W, Cin)
+            if pre is not None:
+                dx = torch.empty_like(x)
+                sums = chan_op(dxu, B * Hs * Ws, Cin, x=x, out=dx, alpha=ps, mask_mode=1 if pre_relu else 0, mask_scale=ps,
+                               mask_shift=pt, sum_mode=1)
+                dpt, dps = sums[0], sums[1]
+            else:
+                dx = dxu
+        return dx, dw, db, dps, dpt, None, None, None, None
+
+
+def fused_conv(x, conv, pre=None, pre_relu=False, act_elu=False, size=None, want_stats=False):
+    """Apply an nn.Conv2d (3x3 / pad 1 or 1x1, stride 1) through FusedConv. pre = (scale, shift) or None."""
+    ps, pt = (None, None) if pre is None else pre
+    return FusedConv.apply(x, conv.weight, conv.bias, ps, pt, bool(pre_relu), bool(act_elu), size, bool(want_stats))
+
+
+class AvgPool2(torch.autograd.Function):
+    """nn.AvgPool2d(2, stride) on a channels-last tensor."""
+
+    @staticmethod
+    def forward(ctx, x, stride):
+        x = nhwc(x)
+        B, C, H, W = x.shape
+        Ho, Wo = (H - 2) // stride + 1, (W - 2) // stride + 1
+        out = empty_nhwc(B, C, Ho, Wo, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.fn("ossid_avgpool2_nhwc")(x.data_ptr(), B, H, W, C, stride, out.data_ptr(), 0, _lib.stream()),
+                       "ossid_avgpool2_nhwc")
+        ctx.cfg = (B, C, H, W, stride)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W, stride = ctx.cfg
+        g = nhwc(g)
+        dx = empty_nhwc(B, C, H, W, g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.fn("ossid_avgpool2_nhwc")(g.data_ptr(), B, H, W, C, stride, dx.data_ptr(), 1, _lib.stream()),
+                       "ossid_avgpool2_nhwc")
+        return dx, None
+
+
+class DenseBlockTrain(torch.autograd.Function):
+    """A DenseNet block in training mode (models/dtoid/network.py:164-184 builds torchvision's densenet121; each layer is
+    BN-ReLU-Conv1x1(128) - BN-ReLU-Conv3x3(32) on the concatenation of everything before it).
+
+    Forward: ONE resident [B][H][W][C_total] buffer; a [2][C_total] table of column sums filled once per produced channel;
+    per layer two folded BatchNorms and two convolutions with the fold applied in their input staging; the layer's 32
+    channels are appended in place. Backward: ONE gradient buffer; per layer (last to first): finish the layer's own
+    channel slice (statistics term), weight + data gradient of the 3x3, ReLU/BatchNorm backward on the 128-channel
+    bottleneck (two generic passes), weight + data gradient of the 1x1, and one generic pass that masks, scales and
+    ACCUMULATES the input gradient onto the channel prefix while summing (d shift, d scale)."""
+
+    @staticmethod
+    def forward(ctx, x, block, *params):
+        x = nhwc(x)
+        B, C0, H, W = x.shape
+        L, growth = block.nlayers, block.growth
+        Ct = C0 + L * growth
+        dev = x.device
+        N = B * H * W
+        buf = empty_nhwc(B, Ct, H, W, dev)
+        buf[:, :C0] = x
+        table = torch.empty((2, Ct), dtype=torch.float32, device=dev)
+        chan_op(buf, N, C0, x=buf, g_cs=Ct, x_cs=Ct, sum_mode=1, sums=table, sums_row_stride=Ct)
+        layers = list(block.values())
+        saved = []
+        c = C0
+        for li, layer in enumerate(layers):
+            g1, b1, w1, g2, b2, w2 = params[6 * li:6 * li + 6]
+            f1 = bn_fold_fwd(table, c, N, g1, b1, layer.norm1.eps, _mom(layer.norm1), layer.norm1.running_mean,
+                             layer.norm1.running_var, sums_row_stride=Ct)
+            mid = int(w1.shape[0])
+            y1 = empty_nhwc(B, mid, H, W, dev)
+            conv_raw(buf, _pack(w1, "fwd"), B, H, W, c, mid, 1, y1, pre=(f1[0], f1[1]), pre_relu=True, in_cs=Ct)
+            s2 = chan_op(y1, N, mid, x=y1, sum_mode=1)
+            f2 = bn_fold_fwd(s2, mid, N, g2, b2, layer.norm2.eps, _mom(layer.norm2), layer.norm2.running_mean,
+                             layer.norm2.running_var)
+            conv_raw(y1, _pack(w2, "fwd"), B, H, W, mid, growth, 9, buf, pre=(f2[0], f2[1]), pre_relu=True, out_cs=Ct,
+                     out_coff=c)
+            new = flat(buf, c)                                      # pointer to channel c of pixel 0
+            chan_op(new, N, growth, x=new, g_cs=Ct, x_cs=Ct, sum_mode=1, sums=table.view(-1)[c:], sums_row_stride=Ct)
+            saved.append((f1, y1, f2))
+            c += growth
+        ctx.block, ctx.saved, ctx.buf, ctx.params, ctx.C0 = block, saved, buf, params, C0
+        return buf
+
+    @staticmethod
+    def backward(ctx, gbuf):
+        block, saved, buf, params, C0 = ctx.block, ctx.saved, ctx.buf, ctx.params, ctx.C0
+        B, Ct, H, W = buf.shape
+        dev = buf.device
+        N = B * H * W
+        L, growth = block.nlayers, block.growth
+        G = gbuf.float().clone(memory_format=torch.channels_last)          # ours to accumulate into
+        coef = torch.zeros((2, Ct), dtype=torch.float32, device=dev)          # [coef_x, coef_1] of the statistics' gradient
+        grads = [None] * len(params)
+        mid = int(params[2].shape[0])
+        db = empty_nhwc(B, mid, H, W, dev)
+        da = empty_nhwc(B, Ct, H, W, dev)          # data gradient of the 1x1: c_l <= Ct channels, written densely [N][c_l]
+        c = C0 + L * growth
+        for li in range(L - 1, -1, -1):
+            c -= growth
+            g1, b1, w1, g2, b2, w2 = params[6 * li:6 * li + 6]
+            f1, y1, f2 = saved[li]
+            # the layer's own 32 channels: every later consumer has added its share; add the statistics term
+            gs, xs = flat(G, c), flat(buf, c)
+            chan_op(gs, N, growth, x=xs, out=gs, g_cs=Ct, x_cs=Ct, out_cs=Ct, beta=coef[0, c:c + growth],
+                    kappa=coef[1, c:c + growth])
+            # 3x3: weight gradient on relu(bn2(y1)), data gradient to the bottleneck
+            dw2 = torch.empty_like(w2)
+            wgrad_raw(y1, gs, B, H, W, mid, growth, 9, dw2, pre=(f2[0], f2[1]), pre_relu=True, dy_cs=Ct)
+            # (the data gradient reads the strided slice: in_cs = Ct)
+            conv_raw(gs, _pack(w2, "dgrad"), B, H, W, growth, mid, 9, db, in_cs=Ct)
+            s = chan_op(db, N, mid, x=y1, out=db, alpha=f2[0], mask_mode=1, mask_scale=f2[0], mask_shift=f2[1], sum_mode=1)
+            r2 = torch.empty((4, mid), dtype=torch.float32, device=dev)
+            bn_fold_bwd(s[1], s[0], g2, f2[2], f2[3], mid, N, r2[0], r2[1], r2[2], r2[3])
+            chan_op(db, N, mid, x=y1, out=db, beta=r2[2], kappa=r2[3])          # dz = scale*db*mask + coef_x*y1 + coef_1
+            # 1x1: weight gradient on relu(bn1(buf[:, :c])), data gradient to the c input channels
+            dw1 = torch.empty_like(w1)
+            wgrad_raw(buf, db, B, H, W, c, mid, 1, dw1, pre=(f1[0], f1[1]), pre_relu=True, in_cs=Ct)
+            conv_raw(db, _pack(w1, "dgrad"), B, H, W, mid, c, 1, da)
+            s = chan_op(da, N, c, x=buf, out=G, x_cs=Ct, out_cs=Ct, alpha=f1[0], mask_mode=1, mask_scale=f1[0],
+                        mask_shift=f1[1], accumulate=True, sum_mode=1)
+            r1 = torch.empty((2, c), dtype=torch.float32, device=dev)
+            bn_fold_bwd(s[1], s[0], g1, f1[2], f1[3], c, N, r1[0], r1[1], coef[0], coef[1], accumulate=True)
+            grads[6 * li:6 * li + 6] = [r1[0], r1[1], dw1, r2[0], r2[1], dw2]
+        # the block's input channels
+        chan_op(G, N, C0, x=buf, out=G, g_cs=Ct, x_cs=Ct, out_cs=Ct, beta=coef[0, :C0], kappa=coef[1, :C0])
+        dx = G[:, :C0].contiguous(memory_format=torch.channels_last)
+        ctx.saved = ctx.buf = None
+        return (dx, None) + tuple(grads)
+
+
+def dense_block_train(x, block):
+    params = []
+    for layer in block.values():
+        params += [layer.norm1.weight, layer.norm1.bias, layer.conv1.weight, layer.norm2.weight, layer.norm2.bias,
+                   layer.conv2.weight]
+    return DenseBlockTrain.apply(x, block, *params)
+
+
+def bn_relu_conv(x, bn, conv, relu=True, act_elu=False, want_stats=False):
+    """Training-mode BatchNorm (+ReLU) in front of a convolution, folded into its input staging."""
+    B, C, H, W = x.shape
+    scale, shift = bn_fold(ColStats.apply(x), B * H * W, bn)
+    return fused_conv(x, conv, pre=(scale, shift), pre_relu=relu, act_elu=act_elu, want_stats=want_stats)
+
+
+def bump_batches_tracked(module):
+    """num_batches_tracked += 1 for every BatchNorm of `module` in ONE multi-tensor launch (the folded BatchNorms above
+    update running_mean / running_var in their own kernel but not the counter)."""
+    ts = [m.num_batches_tracked for m in module.modules()
+          if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None]
+    if ts:
+        torch._foreach_add_(ts, 1)

@@ -1,0 +1,220 @@
+"""GPU tests (pytest -m gpu) of the finetune-step kernels (csrc/train.hip) and of the autograd Functions built on them
+(ossid_code_amd/dtoid/train_ops.py), each against a plain PyTorch restatement of the same op (float64 on the CPU where a
+sum is long). fp32 throughout; summation orders differ (MFMA tiles / split-K slabs vs torch), tolerances are stated at
+each check, relative to the largest magnitude of the expected tensor."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ossid_code_amd.dtoid import backbones
+from ossid_code_amd.dtoid import train_ops as T
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+def cl(t):
+    return t.cuda().contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("N,C,Ct,off", [(1000, 32, 96, 32), (4097, 640, 640, 0), (77, 8, 8, 0), (50000, 128, 128, 0),
+                                        (3, 256, 512, 128)])
+@pytest.mark.parametrize("mask_mode,sum_mode,acc", [(0, 1, False), (1, 1, True), (2, 2, False), (0, 0, True), (1, 0, False)])
+def test_chan_op_all_modes(hiplib, N, C, Ct, off, mask_mode, sum_mode, acc):
+    g = torch.Generator().manual_seed(N + C + mask_mode)
+    G, X, O = (torch.randn(N, Ct, generator=g) for _ in range(3))
+    al, be, ka, ms, mt = (torch.randn(C, generator=g) for _ in range(5))
+    gs, xs = G[:, off:off + C].double(), X[:, off:off + C].double()
+    if mask_mode == 0:
+        m = torch.ones_like(xs)
+    elif mask_mode == 1:
+        m = ((ms.float() * X[:, off:off + C] + mt.float()) > 0).double()
+    else:
+        m = torch.where(xs > 0, torch.ones_like(xs), xs + 1)
+    r = (al.double() * gs + be.double() * xs + ka.double()) * m
+    want_out = O.double().clone()
+    want_out[:, off:off + C] = (want_out[:, off:off + C] + r) if acc else r
+    Gd, Xd, Od = G.cuda(), X.cuda(), O.cuda()
+    sums = T.chan_op(Gd.view(-1)[off:], N, C, x=Xd.view(-1)[off:], out=Od.view(-1)[off:], g_cs=Ct, x_cs=Ct, out_cs=Ct,
+                     alpha=al.cuda(), beta=be.cuda(), kappa=ka.cuda(), mask_mode=mask_mode, mask_scale=ms.cuda(),
+                     mask_shift=mt.cuda(), accumulate=acc, sum_mode=sum_mode)
+    assert rel(Od, want_out) < 1e-5
+    if sum_mode == 1:
+        assert rel(sums[0], (gs * m).sum(0)) < 2e-5 and rel(sums[1], (gs * m * xs).sum(0)) < 2e-5
+    elif sum_mode == 2:
+        assert rel(sums[0], r.sum(0)) < 2e-5 and rel(sums[1], (r * xs).sum(0)) < 2e-5
+    else:
+        assert sums is None
+
+
+def test_chan_op_sums_only_and_strided_sum_table(hiplib):
+    x = torch.randn(5000, 64).cuda()
+    table = torch.zeros(2, 200).cuda()
+    T.chan_op(x, 5000, 64, x=x, sum_mode=1, sums=table.view(-1)[40:], sums_row_stride=200)
+    assert rel(table[0, 40:104], x.double().sum(0)) < 1e-5 and rel(table[1, 40:104], (x.double() ** 2).sum(0)) < 1e-5
+    assert float(table[:, :40].abs().sum()) == 0 and float(table[:, 104:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,taps,in_extra,dy_extra,pre,up", [
+    (8, 640, 256, 29, 39, 9, 0, 0, False, None),       # the head's correlation convs at batch 8
+    (2, 128, 32, 30, 40, 9, 0, 96, True, None),        # a dense layer's 3x3 (dy = a 32-channel slice of the block buffer)
+    (2, 96, 128, 15, 20, 1, 160, 0, True, None),       # a dense layer's 1x1 (x = a channel prefix of the block buffer)
+    (1, 16, 16, 5, 7, 9, 0, 0, False, None),
+    (2, 256, 48, 9, 13, 9, 0, 0, False, None),         # cls output layer
+    (2, 256, 96, 9, 13, 9, 0, 0, True, None),          # reg output layer
+    (2, 64, 32, 46, 62, 9, 0, 0, True, (23, 31)),      # decoder layer behind a 2x nearest up-sampling
+    (1, 32, 16, 48, 64, 9, 0, 0, True, (23, 31)),      # ... behind a non-integer one
+    (3, 512, 640, 7, 9, 1, 0, 0, True, None),
+    (1, 768, 512, 29, 39, 9, 0, 0, False, None),
+])
+def test_wgrad_matches_torch(hiplib, B, Cin, Cout, H, W, taps, in_extra, dy_extra, pre, up):
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    Hs, Ws = (H, W) if up is None else up
+    xs = torch.randn(B, Cin + in_extra, Hs, Ws, generator=g)
+    dy = torch.randn(B, Cout + dy_extra, H, W, generator=g)
+    ps, pt = torch.randn(Cin, generator=g), torch.randn(Cin, generator=g)
+    xin = xs[:, :Cin].double()
+    if pre:
+        xin = F.relu(xin * ps.double().view(1, -1, 1, 1) + pt.double().view(1, -1, 1, 1))
+    if up is not None:
+        xin = F.interpolate(xin, size=(H, W), mode="nearest")
+    k = 3 if taps == 9 else 1
+    w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin, w, padding=k // 2).backward(dy[:, dy_extra:dy_extra + Cout].double())
+    xd, dyd = cl(xs), cl(dy)
+    dw = torch.empty(Cout, Cin, k, k, device="cuda")
+    T.wgrad_raw(xd, T.flat(dyd, dy_extra), B, H, W, Cin, Cout, taps, dw, pre=(ps.cuda(), pt.cuda()) if pre else None,
+                pre_relu=pre, in_cs=Cin + in_extra, dy_cs=Cout + dy_extra, src_hw=(Hs, Ws) if up is not None else (0, 0))
+    assert rel(dw, w.grad) < 5e-5
+    dw2 = dw.clone()
+    T.wgrad_raw(xd, T.flat(dyd, dy_extra), B, H, W, Cin, Cout, taps, dw2, pre=(ps.cuda(), pt.cuda()) if pre else None,
+                pre_relu=pre, in_cs=Cin + in_extra, dy_cs=Cout + dy_extra, src_hw=(Hs, Ws) if up is not None else (0, 0),
+                accumulate=True)
+    assert torch.equal(dw2, dw + dw)                               # deterministic split-K: bit-reproducible, accumulates
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k", [(2, 64, 32, 9, 13, 3), (8, 256, 256, 29, 39, 3), (2, 224, 128, 15, 20, 1),
+                                              (1, 32, 16, 40, 52, 3), (2, 256, 48, 9, 11, 3)])
+def test_data_gradient_is_the_forward_kernel_on_dgrad_packed_weights(hiplib, B, Cin, Cout, H, W, k):
+    g = torch.Generator().manual_seed(Cin * 3 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).double().requires_grad_(True)
+    w = torch.randn(Cout, Cin, k, k, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    F.conv2d(x, w.double(), padding=k // 2).backward(dy.double())
+    wd = w.cuda()
+    dx = T.empty_nhwc(B, Cin, H, W, "cuda")
+    T.conv_raw(cl(dy), T._pack(wd, "dgrad"), B, H, W, Cout, Cin, k * k, dx)
+    assert rel(dx, x.grad) < 2e-5
+
+
+@pytest.mark.parametrize("stride,H,W", [(2, 120, 160), (1, 30, 40), (2, 7, 9)])
+def test_avgpool2_forward_backward(hiplib, stride, H, W):
+    x = torch.randn(2, 16, H, W).cuda().requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    y, yr = T.AvgPool2.apply(x, stride), F.avg_pool2d(xr, 2, stride)
+    go = torch.randn_like(yr)
+    y.backward(go)
+    yr.backward(go)
+    assert rel(y, yr) < 1e-6 and rel(x.grad, xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("Hs,Ws,H,W", [(29, 39, 58, 78), (232, 312, 480, 640), (5, 7, 5, 7), (3, 4, 10, 9)])
+def test_upsample_backward_is_the_window_sum(hiplib, Hs, Ws, H, W):
+    """The exact adjoint of the forward's index map min(floor(dst * in/out), in-1) = what torch's CPU autograd computes
+    (and what the reference-generated golden files pin). torch's GPU backward kernel derives its windows from a second,
+    ceil-based formula that disagrees with its own forward where src * out/in is an integer in exact arithmetic but not
+    in float32 (312 -> 640: 7 of 312 columns), so the comparison is against the CPU."""
+    x = torch.randn(2, 8, Hs, Ws).requires_grad_(True)
+    go = torch.randn(2, 8, H, W)
+    F.interpolate(x, size=(H, W), mode="nearest").backward(go)
+    got = T.upsample_bwd(cl(go), 2, Hs, Ws, H, W, 8)
+    assert rel(got, x.grad) < 1e-5
+
+
+def _copy_grads(mods):
+    return [p.grad.detach().clone() for m in mods for p in m.parameters()]
+
+
+def test_conv_elu_batchnorm_conv_chain_matches_torch_autograd(hiplib):
+    """`conv -> ELU -> BatchNorm(train) -> [nearest up-sample] -> conv -> ELU` (the decoder pattern, network.py:350-357),
+    BatchNorm folded into the second conv's input staging: outputs, every parameter gradient, the input gradient and the
+    running statistics against nn modules."""
+    torch.manual_seed(0)
+    c1, bn, c2 = torch.nn.Conv2d(32, 64, 3, padding=1).cuda(), torch.nn.BatchNorm2d(64).cuda(), torch.nn.Conv2d(64, 16, 3, padding=1).cuda()
+    with torch.no_grad():
+        bn.weight.normal_(1, 0.2)
+        bn.bias.normal_(0, 0.2)
+    x = torch.randn(3, 32, 11, 14, device="cuda")
+    go = torch.randn(3, 16, 22, 28, device="cuda")
+    import copy
+    r1, rbn, r2 = copy.deepcopy(c1), copy.deepcopy(bn), copy.deepcopy(c2)
+    xr = x.clone().requires_grad_(True)
+    yr = F.elu(r2(F.interpolate(rbn(F.elu(r1(xr))), scale_factor=2, mode="nearest")))
+    yr.backward(go)
+    xm = x.clone().requires_grad_(True)
+    u, sums = T.fused_conv(xm, c1, act_elu=True, want_stats=True)
+    scale, shift = T.bn_fold(sums, 3 * 11 * 14, bn)
+    y = T.fused_conv(u, c2, pre=(scale, shift), act_elu=True, size=(22, 28))
+    y.backward(go)
+    assert rel(y, yr) < 2e-5
+    assert rel(xm.grad, xr.grad) < 2e-4
+    for a, b in zip(_copy_grads((c1, bn, c2)), _copy_grads((r1, rbn, r2))):
+        assert rel(a, b) < 2e-4
+    assert rel(bn.running_mean, rbn.running_mean) < 1e-5 and rel(bn.running_var, rbn.running_var) < 1e-5
+
+
+def test_bn_relu_conv_matches_torch_autograd(hiplib):
+    """DenseNet's BN-ReLU-Conv (transition / norm5 pattern) through ColStats + BNFold + the conv's fused prologue."""
+    torch.manual_seed(1)
+    bn, conv = torch.nn.BatchNorm2d(96).cuda(), torch.nn.Conv2d(96, 48, 1, bias=False).cuda()
+    import copy
+    rbn, rconv = copy.deepcopy(bn), copy.deepcopy(conv)
+    x = (torch.randn(4, 96, 9, 12, device="cuda") * 2 + 0.5)
+    go = torch.randn(4, 48, 4, 6, device="cuda")
+    xr = x.clone().requires_grad_(True)
+    F.avg_pool2d(rconv(F.relu(rbn(xr))), 2, 2).backward(go)
+    xm = x.clone().requires_grad_(True)
+    T.AvgPool2.apply(T.bn_relu_conv(xm, bn, conv), 2).backward(go)
+    assert rel(xm.grad, xr.grad) < 2e-4
+    for a, b in zip(_copy_grads((bn, conv)), _copy_grads((rbn, rconv))):
+        assert rel(a, b) < 2e-4
+    assert rel(bn.running_var, rbn.running_var) < 1e-5
+
+
+@pytest.mark.parametrize("L,C0,B,H,W", [(3, 64, 2, 12, 16), (6, 64, 2, 30, 40), (4, 256, 1, 7, 9)])
+def test_dense_block_training_path_matches_module_path(hiplib, L, C0, B, H, W):
+    """One resident buffer + shared batch statistics + in-place gradient accumulation vs the nn.Module dense block
+    (torch.cat, one BatchNorm per layer over the whole concatenation): output, input gradient, every parameter gradient,
+    every running statistic."""
+    torch.manual_seed(2)
+    blk = backbones.DenseBlock(L, C0).cuda().train()
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.normal_(1, 0.2)
+                m.bias.normal_(0, 0.2)
+    import copy
+    ref = copy.deepcopy(blk)
+    x = torch.randn(B, C0, H, W, device="cuda")
+    go = torch.randn(B, C0 + 32 * L, H, W, device="cuda")
+    xr = x.clone().requires_grad_(True)
+    feats = [xr]
+    for layer in ref.values():
+        feats.append(layer(torch.cat(feats, 1)))
+    yr = torch.cat(feats, 1)
+    yr.backward(go)
+    xm = x.clone().requires_grad_(True)
+    y = T.dense_block_train(xm, blk)
+    y.backward(go)
+    assert rel(y, yr) < 5e-5
+    assert rel(xm.grad, xr.grad) < 5e-4
+    for (n, p), q in zip(blk.named_parameters(), ref.parameters()):
+        assert rel(p.grad, q.grad) < 1e-3, n
+    for (n, b), q in zip(blk.named_buffers(), ref.buffers()):
+        if b.dtype.is_floating_point:
+            assert rel(b, q) < 1e-4, n
