@@ -503,7 +503,9 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
                                                                             : tiles >= 2 ? (H + 3) / 4 : (H + 7) / 8);
     // under one workgroup per CU either way: row segments of 32 pixels, one channel tile, the reduction split over the
     // four waves in 128-channel chunks
-    if (plain_wgs < 160 || wide_wgs < 256) return launch_conv<1, 4, 1, true, 13, 9, 128>(a, B, s);
+    // (only for Cin >= 128: with fewer input channels three of the four waves would multiply the zero padding of the
+    // 128-channel chunk -- the data gradient of a dense layer's 128->32 conv is such a 32->128 layer)
+    if ((plain_wgs < 160 || wide_wgs < 256) && Cin >= 128) return launch_conv<1, 4, 1, true, 13, 9, 128>(a, B, s);
     // medium problems on narrow images (the 29x39 head at n_t ~ 10 or batch 8: ~1 plain workgroup per CU, i.e. one or
     // two waves per SIMD and a ragged tail): one channel tile x 32 flat pixels per workgroup, reduction split over the
     // four waves in 32-channel chunks -> 8x as many, 4x shorter work items

@@ -12,6 +12,8 @@
 //                       LDS, the input's BatchNorm(+ReLU) prologue re-applied on the fly, deterministic split-K
 //   pack_dgrad_kernel   conv weights -> MFMA layout of the TRANSPOSED, 180-degree-rotated kernel: the data gradient is
 //                       ossid_conv_nhwc_fwd on dy with these
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -95,14 +97,34 @@ __global__ __launch_bounds__(256) void chan_op_kernel(const ChanOpArgs A) {
     }
 }
 
-// sums[s][c] = sum over the P row-chunk partials, in a fixed order, accumulated in double
+// sums[s][c] = sum over the P row-chunk partials, in a fixed order, accumulated in double. A block owns 64 columns; its
+// four waves each take a quarter of the partials (independent, unrolled loads), the quarters meet in LDS.
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int P, int C,
                                                               float* __restrict__ sums, int row_stride) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * C) return;
+    __shared__ double red[4][64];
+    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
+    const int C2 = 2 * C;
     double s = 0.0;
-    for (int p = 0; p < P; ++p) s += (double)partials[(size_t)p * 2 * C + i];
-    sums[i < C ? i : row_stride + (i - C)] = (float)s;
+    if (i < C2) {
+        const int per = (P + 3) / 4, p0 = part * per, p1 = min(P, p0 + per);
+        const float* src = partials + i;
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(p + k) * C2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += (double)v[k];
+        }
+        for (; p < p1; ++p) s += (double)src[(size_t)p * C2];
+    }
+    red[part][col] = s;
+    __syncthreads();
+    if (part == 0 && i < C2) {
+        const double t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        sums[i < C ? i : row_stride + (i - C)] = (float)t;
+    }
 }
 
 // =====================================================================================================================
@@ -263,7 +285,7 @@ struct WgradArgs {
     long long n_chunks;     // B * H * chunks_per_row
 };
 
-template <int TAPS, int KYB, int TM, int TN, int WM, int WN>
+template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
     constexpr int CO_T = WM * TM * 32, CI_T = WN * TN * 32;
     constexpr int KX = TAPS == 9 ? 3 : 1;
@@ -272,22 +294,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
     constexpr int KTMAX = 48;
     constexpr int DY4 = CO_T / 4, X4 = CI_T / 4;              // float4 per staged pixel
     constexpr int NLD_DY = (KTMAX * DY4 + 255) / 256, NLD_X = (KYB * (KTMAX + HALO) * X4 + 255) / 256;
-    static_assert(WM * WN == 4 && 256 % DY4 == 0 && 256 % X4 == 0, "bad tiling");
+    static_assert(WM * WN * WK == 4 && 256 % DY4 == 0 && 256 % X4 == 0, "bad tiling");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int KT = A.KT;
     const int dy_buf = KT * CO_T, x_buf = KYB * (KT + HALO) * CI_T;      // floats per buffer
     float* dyl = lds;                                // [2][KT][CO_T]
     float* xl = lds + 2 * dy_buf;                    // [2][KYB][KT + HALO][CI_T]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
-    const int wm = wave % WM, wn = wave / WM;
+    // WK > 1 (layers with few channels): the waves of a workgroup share ONE (co, ci) tile and take every WK-th k-step of
+    // a chunk; each writes its own slab (slab index split * WK + wk), so there is no cross-wave reduction in the kernel
+    const int wm = wave % WM, wn = (wave / WM) % WN, wk = wave / (WM * WN);
 
-    // ---- which tile / split: XCD x takes splits x, x+8, ...; consecutive workgroups of an XCD walk the tiles of ONE
-    // split, i.e. re-read the same dY / X rows from that XCD's L2 (placement only -- any mapping computes the same sums)
+    // ---- which tile / split: consecutive workgroup ids walk the tiles of ONE split (they read the same dY / X rows,
+    // which then hit in L2), splits follow each other (placement only -- any mapping computes the same sums)
     const int L = blockIdx.x;
-    const int j = L >> 3;
-    const int split = (L & 7) + 8 * (j / A.ntiles);
-    int tile = j % A.ntiles;
-    if (split >= A.nsplit) return;
+    const int split = L / A.ntiles;
+    int tile = L - split * A.ntiles;
     int ky0 = 0;
     if (TAPS == 9 && KYB == 1) {
         ky0 = tile % 3;
@@ -402,16 +424,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
                             acc[t] = mfma(aa[m], bb[kr][n][kx], acc[t]);
                         }
         };
-        // operands of k-step k+1 are read from LDS while the MFMAs of step k run (KT is even; two steps per trip)
-        fetch(0, a[0], bv[0]);
+        // operands of this wave's next k-step are read from LDS while the MFMAs of the current one run (two per trip)
+        if (wk < ksteps) fetch(wk, a[0], bv[0]);
 #pragma unroll 1
-        for (int k = 0; k < ksteps; k += 2) {
-            if (k + 1 < ksteps) fetch(k + 1, a[1], bv[1]);
+        for (int k = wk; k < ksteps; k += 2 * WK) {
+            if (k + WK < ksteps) fetch(k + WK, a[1], bv[1]);
             __builtin_amdgcn_sched_barrier(0);
             run(a[0], bv[0]);
             __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < ksteps) {
-                if (k + 2 < ksteps) fetch(k + 2, a[0], bv[0]);
+            if (k + WK < ksteps) {
+                if (k + 2 * WK < ksteps) fetch(k + 2 * WK, a[0], bv[0]);
                 __builtin_amdgcn_sched_barrier(0);
                 run(a[1], bv[1]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -424,7 +446,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
 
     // ---- slab [split][tap][Cout][Cin]: rows of an accumulator tile = output channels (registers), columns = input
     // channels (lanes): 128-byte rows
-    float* slab = A.slabs + (size_t)split * TAPS * A.Cout * A.Cin;
+    float* slab = A.slabs + ((size_t)split * WK + wk) * TAPS * A.Cout * A.Cin;
 #pragma unroll
     for (int kr = 0; kr < KYB; ++kr)
 #pragma unroll
@@ -446,42 +468,71 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
             }
 }
 
-// dw[co][ci][tap] (+)= sum over splits of slabs[split][tap][co][ci]
+// dw[co][ci][tap] (+)= sum over splits of slabs[split][tap][co][ci], in a fixed order. PARTS threads share one output
+// element (each sums every PARTS-th slab with independent, unrolled loads; the partial sums meet in LDS): with hundreds
+// of slabs and a small dW (layers with few channels and millions of pixels) one thread per element would be a serial
+// chain of L2 latencies.
+template <int PARTS>
 __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restrict__ slabs, int nsplit, int taps, int Cout,
                                                             int Cin, float* __restrict__ dw, int accumulate) {
+    constexpr int EPB = 256 / PARTS;                                    // elements per block
+    __shared__ float red[PARTS][EPB];
     const size_t n = (size_t)taps * Cout * Cin;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // index in [tap][co][ci] order: coalesced reads
+    const int e = threadIdx.x % EPB, part = threadIdx.x / EPB;
+    const size_t i = (size_t)blockIdx.x * EPB + e;                      // index in [tap][co][ci] order: coalesced reads
+    float s = 0.0f;
+    if (i < n) {
+        int k = part;
+        for (; k + 7 * PARTS < nsplit; k += 8 * PARTS) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slabs[(size_t)(k + u * PARTS) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nsplit; k += PARTS) s += slabs[(size_t)k * n + i];
+    }
+    if (PARTS > 1) {
+        red[part][e] = s;
+        __syncthreads();
+        if (part != 0) return;
+#pragma unroll
+        for (int p = 1; p < PARTS; ++p) s += red[p][e];
+    }
     if (i >= n) return;
     const int ci = (int)(i % Cin);
     const size_t r = i / Cin;
     const int co = (int)(r % Cout), tap = (int)(r / Cout);
-    float s = 0.0f;
-    for (int k = 0; k < nsplit; ++k) s += slabs[(size_t)k * n + i];
     float* o = dw + ((size_t)co * Cin + ci) * taps + tap;
     *o = accumulate ? *o + s : s;
 }
 
 struct WgradPlan {
-    int variant;     // 0: <9,1,2,1,2,2> 128 co x 64 ci   1: <9,1,1,2,2,2> 64 x 128   2: <9,1,1,1,1,4> 32 x 128
-                     // 3: <1,1,2,2,2,2> 128 x 128 (1x1)  4: <1,1,1,2,2,2> 64 x 128 (1x1)
-    int co_t, ci_t, KT, chunks_per_row, nsplit, co_blocks, ci_blocks, ntiles, B, H, W;
+    // variant: 0 <9,1,2,1,2,2,1> 128 co x 64 ci    1 <9,1,1,2,2,2,1> 64 x 128     2 <9,1,1,1,1,4,1> 32 x 128
+    //          3 <1,1,2,2,2,2,1> 128 x 128 (1x1)   4 <1,1,1,2,2,2,1> 64 x 128 (1x1)
+    //          5 <9,3,1,1,1,1,4> 32 x 32, all nine taps, k-steps shared out over the waves   6 <9,3,1,1,1,2,2> 32 x 64
+    int variant, co_t, ci_t, kyb, wk, tiles_per_wave;
+    int KT, chunks_per_row, nsplit, co_blocks, ci_blocks, ntiles, B, H, W;
     long long n_chunks;
     size_t lds;
 };
 
 bool wgrad_plan(int B, int H, int W, int Cin, int Cout, int taps, WgradPlan& p) {
     if ((long long)B * H * W > 0x3fffffffLL) return false;
+    p.kyb = 1, p.wk = 1;
+    int ktmax = 48;
     if (taps == 9) {
-        if (Cout <= 32) p.variant = 2, p.co_t = 32, p.ci_t = 128;
-        else if (Cout <= 64 || Cout == 96) p.variant = 1, p.co_t = 64, p.ci_t = 128;
-        else p.variant = 0, p.co_t = 128, p.ci_t = 64;
+        if (Cout <= 32 && Cin <= 32) p.variant = 5, p.co_t = 32, p.ci_t = 32, p.kyb = 3, p.wk = 4, p.tiles_per_wave = 9;
+        else if (Cout <= 32 && Cin <= 64) p.variant = 6, p.co_t = 32, p.ci_t = 64, p.kyb = 3, p.wk = 2, p.tiles_per_wave = 9, ktmax = 40;
+        else if (Cout <= 32) p.variant = 2, p.co_t = 32, p.ci_t = 128, p.tiles_per_wave = 3;
+        else if (Cout <= 64 || Cout == 96) p.variant = 1, p.co_t = 64, p.ci_t = 128, p.tiles_per_wave = 6;
+        else p.variant = 0, p.co_t = 128, p.ci_t = 64, p.tiles_per_wave = 6;
         p.B = B, p.H = H, p.W = W;
-        const int ktmax = 48;
         p.chunks_per_row = (W + ktmax - 1) / ktmax;
         p.KT = ((W + p.chunks_per_row - 1) / p.chunks_per_row + 1) & ~1;
     } else if (taps == 1) {
-        if (Cout <= 64) p.variant = 4, p.co_t = 64, p.ci_t = 128;
-        else p.variant = 3, p.co_t = 128, p.ci_t = 128;
+        if (Cout <= 64) p.variant = 4, p.co_t = 64, p.ci_t = 128, p.tiles_per_wave = 2;
+        else p.variant = 3, p.co_t = 128, p.ci_t = 128, p.tiles_per_wave = 4;
         p.B = 1, p.H = 1, p.W = B * H * W;          // no halo: the whole tensor is one long pixel row
         p.KT = 32;
         p.chunks_per_row = (p.W + p.KT - 1) / p.KT;
@@ -491,23 +542,36 @@ bool wgrad_plan(int B, int H, int W, int Cin, int Cout, int taps, WgradPlan& p) 
     p.n_chunks = (long long)p.B * p.H * p.chunks_per_row;
     p.co_blocks = (Cout + p.co_t - 1) / p.co_t;
     p.ci_blocks = (Cin + p.ci_t - 1) / p.ci_t;
-    p.ntiles = p.co_blocks * p.ci_blocks * (taps == 9 ? 3 : 1);
-    // two to three workgroups per CU in all, in multiples of 8 splits (one per XCD); every split costs a slab
-    long want = (640 + p.ntiles - 1) / p.ntiles;
-    want = (want + 7) / 8 * 8;
-    if (want < 8) want = 8;
-    while (want > 8 && want > p.n_chunks) want -= 8;
-    p.nsplit = (int)want;
+    p.ntiles = p.co_blocks * p.ci_blocks * ((taps == 9 && p.kyb == 1) ? 3 : 1);
     const int halo = taps == 9 ? 2 : 0;
-    p.lds = (size_t)2 * (p.KT * p.co_t + (p.KT + halo) * p.ci_t) * sizeof(float);
+    p.lds = (size_t)2 * (p.KT * p.co_t + p.kyb * (p.KT + halo) * p.ci_t) * sizeof(float);
+    // How many K-splits (multiples of 8: one per XCD)? More splits = more workgroups in flight but every split costs a
+    // slab (written here, read by the reduction). Model, in microseconds: rounds of resident workgroups x (chunks per
+    // workgroup x MFMA time of a chunk + a fixed ~4 us to fill the pipeline and store the tiles) + slab traffic at ~3 TB/s.
+    const int per_cu = p.lds > 80 * 1024 ? 1 : (p.lds > 53 * 1024 ? 2 : 3);
+    const double t_chunk = (double)(p.KT / 2) * p.tiles_per_wave / p.wk * 64.0 / 2400.0 + 0.35;
+    const double dw_bytes = (double)taps * Cout * Cin * 4.0;
+    double best = 1e30;
+    int best_s = 1;
+    for (int sp = 1; sp <= 1024; ++sp) {
+        if (sp > 1 && sp > p.n_chunks) break;
+        const double blocks = (double)p.ntiles * sp;
+        const double rounds = ceil(blocks / (256.0 * per_cu));
+        const double chunks_pb = ceil((double)p.n_chunks / sp);
+        const int slabs = sp * p.wk;
+        const double t_red = (slabs <= 16 ? slabs : slabs <= 128 ? slabs / 4.0 : slabs / 32.0) * 0.12;   // dependent L2 round trips
+        const double t = rounds * (chunks_pb * t_chunk + 4.0) + slabs * dw_bytes * 2.0 / 3.0e6 + t_red;
+        if (t < best) best = t, best_s = sp;
+    }
+    p.nsplit = best_s;
     return true;
 }
 
-template <int TAPS, int KYB, int TM, int TN, int WM, int WN>
+template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
 int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t s) {
-    auto kern = wgrad_kernel<TAPS, KYB, TM, TN, WM, WN>;
+    auto kern = wgrad_kernel<TAPS, KYB, TM, TN, WM, WN, WK>;
     OSSID_ENSURE_LDS(kern, p.lds);
-    const long nwg = 8L * ((long)(p.nsplit + 7) / 8) * p.ntiles;
+    const long nwg = (long)p.nsplit * p.ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), p.lds, s, a);
     return ossid_launch_status();
 }
@@ -527,7 +591,8 @@ int ossid_chan_op_partials(long long n_rows, int C) {
     const int C4 = (C + 3) / 4;
     const int QX = C4 <= 8 ? 8 : C4 <= 16 ? 16 : C4 <= 32 ? 32 : 64;
     const int gx = (C4 + QX - 1) / QX, RY = 256 / QX;
-    long P = (2048 + gx - 1) / gx;
+    long P = (1024 + gx - 1) / gx;
+    if (P > 256) P = 256;
     const long maxP = (long)((n_rows + 4 * RY - 1) / (4 * RY));          // at least 4 rows per thread
     if (P > maxP) P = maxP;
     if (P < 1) P = 1;
@@ -562,7 +627,7 @@ int ossid_chan_op(const ossid_chan_op_desc* d, void* stream) {
     else rc = launch_chan_op<64>(a, P, s);
     if (rc != OSSID_OK || d->sum_mode == 0) return rc;
     const int C2 = 2 * d->channels;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C2 + 255) / 256), dim3(256), 0, s, (const float*)d->partials, P,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C2 + 63) / 64), dim3(256), 0, s, (const float*)d->partials, P,
                        d->channels, d->sums, d->sums_row_stride > 0 ? d->sums_row_stride : d->channels);
     return ossid_launch_status();
 }
@@ -623,7 +688,7 @@ int ossid_conv_pack_weights_dgrad(const float* w, int Cout, int Cin, int taps, f
 size_t ossid_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps) {
     WgradPlan p;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !wgrad_plan(B, H, W, Cin, Cout, taps, p)) return 0;
-    return (size_t)p.nsplit * taps * Cout * Cin * sizeof(float);
+    return (size_t)p.nsplit * p.wk * taps * Cout * Cin * sizeof(float);
 }
 
 int ossid_conv_wgrad(const ossid_wgrad_desc* d, void* stream) {
@@ -633,7 +698,7 @@ int ossid_conv_wgrad(const ossid_wgrad_desc* d, void* stream) {
     if (!d->x || !d->dy || !d->dw || !d->workspace || (d->pre_scale && !d->pre_shift)) return OSSID_EINVAL;
     WgradPlan p;
     if (!wgrad_plan(B, H, W, Cin, Cout, taps, p)) return OSSID_EINVAL;
-    if (d->workspace_bytes < (size_t)p.nsplit * taps * Cout * Cin * sizeof(float)) return OSSID_EINVAL;
+    if (d->workspace_bytes < (size_t)p.nsplit * p.wk * taps * Cout * Cin * sizeof(float)) return OSSID_EINVAL;
     WgradArgs a;
     a.x = d->x, a.dy = d->dy, a.pre_scale = d->pre_scale, a.pre_shift = d->pre_shift, a.slabs = (float*)d->workspace;
     a.B = p.B, a.H = p.H, a.W = p.W, a.Cin = Cin, a.Cout = Cout;
@@ -648,16 +713,26 @@ int ossid_conv_wgrad(const ossid_wgrad_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc;
     switch (p.variant) {
-        case 0: rc = launch_wgrad<9, 1, 2, 1, 2, 2>(a, p, s); break;
-        case 1: rc = launch_wgrad<9, 1, 1, 2, 2, 2>(a, p, s); break;
-        case 2: rc = launch_wgrad<9, 1, 1, 1, 1, 4>(a, p, s); break;
-        case 3: rc = launch_wgrad<1, 1, 2, 2, 2, 2>(a, p, s); break;
-        default: rc = launch_wgrad<1, 1, 1, 2, 2, 2>(a, p, s); break;
+        case 0: rc = launch_wgrad<9, 1, 2, 1, 2, 2, 1>(a, p, s); break;
+        case 1: rc = launch_wgrad<9, 1, 1, 2, 2, 2, 1>(a, p, s); break;
+        case 2: rc = launch_wgrad<9, 1, 1, 1, 1, 4, 1>(a, p, s); break;
+        case 3: rc = launch_wgrad<1, 1, 2, 2, 2, 2, 1>(a, p, s); break;
+        case 4: rc = launch_wgrad<1, 1, 1, 2, 2, 2, 1>(a, p, s); break;
+        case 5: rc = launch_wgrad<9, 3, 1, 1, 1, 1, 4>(a, p, s); break;
+        default: rc = launch_wgrad<9, 3, 1, 1, 1, 2, 2>(a, p, s); break;
     }
     if (rc != OSSID_OK) return rc;
     const size_t n = (size_t)taps * Cout * Cin;
-    hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)d->workspace,
-                       p.nsplit, taps, Cout, Cin, d->dw, d->accumulate);
+    const int slabs = p.nsplit * p.wk;
+    if (slabs <= 16)
+        hipLaunchKernelGGL(wgrad_reduce2_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)d->workspace,
+                           slabs, taps, Cout, Cin, d->dw, d->accumulate);
+    else if (slabs <= 128)
+        hipLaunchKernelGGL(wgrad_reduce2_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, (const float*)d->workspace,
+                           slabs, taps, Cout, Cin, d->dw, d->accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce2_kernel<32>, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, s, (const float*)d->workspace,
+                           slabs, taps, Cout, Cin, d->dw, d->accumulate);
     return ossid_launch_status();
 }
 

@@ -532,11 +532,88 @@ class Network(nn.Module):
     def compute_template_global(self, img):
         return self.template_feature_extractor_global(img)
 
+    # finetune forward/backward on the hand-written kernels (train_ops.py); False = the nn.Module path (MIOpen)
+    use_hip_training = os.environ.get("OSSID_TRAIN_IMPL", "hip") != "miopen"
+
+    def _forward_train_hip(self, image, g, local):
+        """Training-mode forward of everything behind the two template encoders on csrc/conv.hip + csrc/train.hip,
+        channels-last end to end (same arithmetic as the module path below; BatchNorm batch statistics folded into the
+        next convolution's input staging). Returns (classifications, regression, anchors, heat_map, segmentation)."""
+        from . import train_ops as T
+        from .backbones import DenseBlock, Transition
+        ife, corr = self.image_feature_extractor, self.correlation_model
+        x0 = ife.backdense_0(image)
+        x0 = x0 + ops.dw_xcorr(x0, g)
+        seq = list(ife.backdense_1) + list(ife.backdense_2)      # norm0 relu0 pool0 block1 | trans1 block2 ... norm5
+        x = x0
+        for m in seq[:3]:                                        # stem: 64 channels at 240x320, on torch
+            x = m(x)
+        x = T.nhwc(x)
+        norm5 = None
+        for m in seq[3:]:
+            if isinstance(m, DenseBlock):
+                x = T.dense_block_train(x, m)
+            elif isinstance(m, Transition):
+                stride = m.pool.stride if isinstance(m.pool.stride, int) else m.pool.stride[0]
+                x = T.AvgPool2.apply(T.bn_relu_conv(x, m.norm, m.conv), stride)
+            else:
+                norm5 = m
+        B = x.shape[0]
+        n_px = B * x.shape[2] * x.shape[3]
+        u, sums = T.bn_relu_conv(x, norm5, ife.c1, relu=False, act_elu=True, want_stats=True)
+        s, t = T.bn_fold(sums, n_px, ife.n1)
+        feat = u * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)                 # n1(elu(c1(norm5(.)))), [B,640,29,39]
+
+        def cab(inp, conv, bn, pre=None, size=None):
+            """conv -> ELU, and the folded BatchNorm that follows it as (scale, shift) for whoever reads u next"""
+            u, sums = T.fused_conv(inp, conv, pre=pre, act_elu=True, size=size, want_stats=True)
+            sc, sh = T.bn_fold(sums, u.shape[0] * u.shape[2] * u.shape[3], bn)
+            return u, sc, sh
+
+        t2 = corr._cab(corr.c2, corr.n2, corr._cab(corr.c1, corr.n1, local))      # 7x7 -> 5x5 -> 3x3 (tiny: torch)
+        dot3x3 = ops.dw_xcorr(feat, t2)
+        avg = F.avg_pool2d(local, 7)
+        parts = [cab(feat * avg, corr.corr_conv_dot, corr.norm_corr_dot),
+                 cab(feat - avg, corr.corr_conv_sub, corr.norm_corr_sub),
+                 cab(dot3x3, corr.corr_conv_dot3x3, corr.norm_corr_dot3x3)]
+        ucat = torch.cat([p[0] for p in parts], 1)
+        pre = (torch.cat([p[1] for p in parts]), torch.cat([p[2] for p in parts]))
+        u2, s2, t2_ = cab(ucat, corr.cf, corr.nf, pre=pre)
+        x2 = u2 * s2.view(1, -1, 1, 1) + t2_.view(1, -1, 1, 1)              # materialised once, for the 1-channel heat conv
+        heat_map = torch.sigmoid(corr.corr_conv_heatmap(x2))
+        u, sc, sh = cab(u2, corr.s1, corr.ns1, pre=(s2, t2_))
+        for i in (2, 3, 4):
+            u, sc, sh = cab(u, getattr(corr, "s%d" % i), getattr(corr, "ns%d" % i), pre=(sc, sh),
+                            size=(2 * u.shape[2], 2 * u.shape[3]))
+        u, sc, sh = cab(u, corr.s5, corr.ns5, pre=(sc, sh), size=corr.img_size)
+        segmentation = corr.seg_final(u * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+
+        def trunk(mod):
+            h = T.fused_conv(u2, mod.conv1, pre=(s2, t2_), act_elu=True)
+            for i in (2, 3, 4):
+                h = T.fused_conv(h, getattr(mod, "conv%d" % i), act_elu=True)
+            return T.fused_conv(h, mod.output)
+        cls = torch.sigmoid(trunk(self.classification))
+        classifications = cls.permute(0, 2, 3, 1).reshape(B, -1, self.classification.num_classes)
+        regression = trunk(self.regression).permute(0, 2, 3, 1).reshape(B, -1, 4)
+        anchors = self.anchors([[u2.size(2), u2.size(3)]], device=u2.device)
+        # the folded BatchNorms update running_mean / running_var in their kernel; the counters in one launch
+        ts = self.__dict__.get("_folded_bn_counters")
+        if ts is None:
+            mods = [m for m in seq[3:]] + [ife.n1, corr.norm_corr_dot, corr.norm_corr_sub, corr.norm_corr_dot3x3, corr.nf] + \
+                [getattr(corr, "ns%d" % i) for i in (1, 2, 3, 4, 5)]
+            ts = [b.num_batches_tracked for m in mods for b in m.modules() if isinstance(b, nn.BatchNorm2d)]
+            self.__dict__["_folded_bn_counters"] = ts
+        torch._foreach_add_(ts, 1)
+        return classifications, regression, anchors, heat_map, segmentation
+
     def forward(self, image, template, template_mask, global_template, global_template_mask):
         """(B,3,H,W), (B,3,h,w), (B,1,h,w), (B,3,h,w), (B,1,h,w) ->
         classifications [B,A,2], regression [B,A,4], anchors [1,A,4], heat_map [B,1,hh,hw], segmentation [B,1,H,W]"""
         g = self.template_feature_extractor_global(torch.cat([global_template, global_template_mask], dim=1))
         local = self.template_feature_extractor(torch.cat([template, template_mask], dim=1))
+        if image.is_cuda and self.training and torch.is_grad_enabled() and self.use_hip_training:
+            return self._forward_train_hip(image, g, local)
         if image.is_cuda and not self.training and not torch.is_grad_enabled() and self.use_fused_head:
             # inference on (image, template) PAIRS (BASELINE configs[2] (ii)): backbone and head on csrc/conv.hip
             features = self._features(image, g)

@@ -676,3 +676,41 @@ def test_network_forward_on_pairs_eval_runs_on_the_fused_kernels_and_matches_the
     assert got[0].shape == (B, 27144, 2) and got[1].shape == (B, 27144, 4) and got[4].shape == (B, 1, 480, 640)
     for name, a, b in zip(("cls", "reg", "anchors", "heat", "seg"), got, want):
         assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max().clamp(min=1e-6)), name
+
+
+@pytest.mark.gpu
+def test_hip_training_path_matches_module_path_whole_network(hiplib):
+    """DtoidNet.forward + 4-term loss + backward at 480x640 on the hand-written training kernels (channels-last,
+    BatchNorm folded into the next conv, dense blocks with shared batch statistics) vs the nn.Module path (MIOpen):
+    every output, the loss, EVERY parameter gradient and every BatchNorm buffer. fp32 through ~130 layers and ~125
+    training-mode BatchNorms: 2e-3 of each tensor's largest magnitude (most agree to 1e-4)."""
+    import copy
+    cfg = dtoid.DtoidConfig()
+    torch.manual_seed(21)
+    m = dtoid.DtoidNet(cfg).cuda().train()
+    with torch.no_grad():   # the zero-initialised output layers would make three of the four losses blind to the trunk
+        for conv in (m.model.classification.output, m.model.regression.output, m.model.correlation_model.seg_final,
+                     m.model.correlation_model.corr_conv_heatmap):
+            conv.weight.normal_(0, 0.02)
+    ref = copy.deepcopy(m)
+    batch = _batch(cfg, 2, "cuda", seed=5)
+    m.model.use_hip_training, ref.model.use_hip_training = True, False
+    out, outr = m(batch), ref(batch)
+    out["loss"].backward()
+    outr["loss"].backward()
+
+    def rel(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp(min=1e-12))
+    for k in ("classifications", "regressions", "heat_map", "segmentation", "loss", "loss_seg", "loss_center", "loss_cls",
+              "loss_reg"):
+        assert rel(out[k], outr[k]) < 2e-4, (k, rel(out[k], outr[k]))
+    table = []
+    for (n, p), q in zip(m.named_parameters(), ref.parameters()):
+        if q.grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0, n
+            continue
+        table.append((rel(p.grad, q.grad), n, float(q.grad.abs().max())))
+    table.sort(reverse=True)
+    assert table[0][0] < 2e-3, table[:12]
+    for (n, b), q in zip(m.named_buffers(), ref.buffers()):
+        assert rel(b, q) < 1e-4 or not b.dtype.is_floating_point and torch.equal(b, q), n
