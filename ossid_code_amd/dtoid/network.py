@@ -541,7 +541,7 @@ class Network(nn.Module):
         next convolution's input staging). Returns (classifications, regression, anchors, heat_map, segmentation)."""
         from . import train_ops as T
         from .backbones import DenseBlock, Transition
-        ife, corr = self.image_feature_extractor, self.correlation_model
+        ife = self.image_feature_extractor
         x0 = ife.backdense_0(image)
         x0 = x0 + ops.dw_xcorr(x0, g)
         seq = list(ife.backdense_1) + list(ife.backdense_2)      # norm0 relu0 pool0 block1 | trans1 block2 ... norm5
@@ -563,6 +563,21 @@ class Network(nn.Module):
         u, sums = T.bn_relu_conv(x, norm5, ife.c1, relu=False, act_elu=True, want_stats=True)
         s, t = T.bn_fold(sums, n_px, ife.n1)
         feat = u * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)                 # n1(elu(c1(norm5(.)))), [B,640,29,39]
+        out = self._head_train_hip(feat, local)
+        # the folded BatchNorms update running_mean / running_var in their kernel; the counters in one launch
+        ts = self.__dict__.get("_folded_bn_counters")
+        if ts is None:
+            ts = [b.num_batches_tracked for m in seq[3:] + [ife.n1] for b in m.modules() if isinstance(b, nn.BatchNorm2d)]
+            self.__dict__["_folded_bn_counters"] = ts
+        torch._foreach_add_(ts, 1)
+        return out
+
+    def _head_train_hip(self, feat, local):
+        """CorrelationModel + ClassificationModel + RegressionModel in training mode (network.py:328-363, :113-157) on the
+        hand-written kernels: feat [B,640,h,w] image features, local [B,640,7,7] template features."""
+        from . import train_ops as T
+        corr = self.correlation_model
+        B = feat.shape[0]
 
         def cab(inp, conv, bn, pre=None, size=None):
             """conv -> ELU, and the folded BatchNorm that follows it as (scale, shift) for whoever reads u next"""
@@ -597,13 +612,12 @@ class Network(nn.Module):
         classifications = cls.permute(0, 2, 3, 1).reshape(B, -1, self.classification.num_classes)
         regression = trunk(self.regression).permute(0, 2, 3, 1).reshape(B, -1, 4)
         anchors = self.anchors([[u2.size(2), u2.size(3)]], device=u2.device)
-        # the folded BatchNorms update running_mean / running_var in their kernel; the counters in one launch
-        ts = self.__dict__.get("_folded_bn_counters")
+        ts = self.__dict__.get("_folded_bn_counters_head")
         if ts is None:
-            mods = [m for m in seq[3:]] + [ife.n1, corr.norm_corr_dot, corr.norm_corr_sub, corr.norm_corr_dot3x3, corr.nf] + \
+            mods = [corr.norm_corr_dot, corr.norm_corr_sub, corr.norm_corr_dot3x3, corr.nf] + \
                 [getattr(corr, "ns%d" % i) for i in (1, 2, 3, 4, 5)]
-            ts = [b.num_batches_tracked for m in mods for b in m.modules() if isinstance(b, nn.BatchNorm2d)]
-            self.__dict__["_folded_bn_counters"] = ts
+            ts = [m.num_batches_tracked for m in mods]
+            self.__dict__["_folded_bn_counters_head"] = ts
         torch._foreach_add_(ts, 1)
         return classifications, regression, anchors, heat_map, segmentation
 
