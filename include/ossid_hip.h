@@ -235,6 +235,11 @@ typedef struct ossid_wgrad_desc {
 } ossid_wgrad_desc;
 size_t ossid_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps);
 int ossid_conv_wgrad(const ossid_wgrad_desc* desc_host, void* stream);
+/* Up to 48 INDEPENDENT weight gradients (e.g. the 2 x L of one DenseNet block, each too small to fill the chip) as one
+ * launch per tiling variant plus one grouped slab reduction; each descriptor's `workspace` field is ignored, the slabs
+ * of all problems live in the one `workspace` of ossid_conv_wgrad_group_workspace_bytes(descs, n) bytes. */
+size_t ossid_conv_wgrad_group_workspace_bytes(const ossid_wgrad_desc* descs_host, int n);
+int ossid_conv_wgrad_group(const ossid_wgrad_desc* descs_host, int n, void* workspace, size_t workspace_bytes, void* stream);
 
 /* D16  packed weights of the DATA gradient: dx = conv(dy, W') with W'[ci][co][tap] = w[co][ci][taps-1-tap] (transposed,
  * rotated by 180 degrees), in the layout ossid_conv_nhwc_fwd reads for a [cout' = Cin][cin' = Cout] layer -- the data
@@ -267,6 +272,9 @@ typedef struct ossid_chan_op_desc {
     int32_t channels, g_stride, x_stride, out_stride, mask_mode, accumulate, sum_mode;
     int32_t sums_row_stride;         /* floats between sums[0][.] and sums[1][.] (0 = channels): lets a layer write the
                                         statistics of its channel slice into a block-wide [2][C_total] table */
+    int32_t defer_finalize;          /* != 0: leave the column sums as the ossid_chan_op_partials(rows, channels)
+                                        per-block partials in `partials` (sums may be NULL); the consumer --
+                                        ossid_bn_fold_fwd / _bwd with n_partials > 0 -- combines them itself */
 } ossid_chan_op_desc;
 int ossid_chan_op_partials(long long n_rows, int channels);
 int ossid_chan_op(const ossid_chan_op_desc* desc_host, void* stream);
@@ -276,13 +284,26 @@ int ossid_chan_op(const ossid_chan_op_desc* desc_host, void* stream);
  *   (sums[c], sums[sums_row_stride + c]; 0 = C) mean, biased var -> scale = gamma * rstd, shift = beta - mean * scale; running statistics updated in place with
  *   `momentum` (unbiased variance), as torch does. Backward: (d scale, d shift) -> d gamma, d beta and the coefficients of
  *   the statistics' own gradient  dx += coef_x[c] * x + coef_1[c]  (= d mean / n + 2 (x - mean) d var / n), which the
- *   producer's ossid_chan_op pass applies (accumulate != 0: += onto coef_x / coef_1, several consumers of one tensor). */
-int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, int C, double n, const float* gamma, const float* beta, float eps, float momentum,
-                      float* running_mean, float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out,
-                      void* stream);
-int ossid_bn_fold_bwd(const float* dscale, const float* dshift, const float* gamma, const float* mean, const float* rstd,
-                      int C, double n, float* dgamma, float* dbeta, float* coef_x, float* coef_1, int accumulate,
-                      void* stream);
+ *   producer's ossid_chan_op pass applies (accumulate != 0: += onto coef_x / coef_1, several consumers of one tensor).
+ *   n_partials > 0: the two sums (forward: sum x, sum x^2; backward: d shift, d scale) are read as the per-block partials a
+ *   deferred ossid_chan_op left in `partials` and combined here, in the same fixed order. */
+int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, const float* partials, int n_partials, int C, double n,
+                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, void* stream);
+int ossid_bn_fold_bwd(const float* dscale, const float* dshift, const float* partials, int n_partials, const float* gamma,
+                      const float* mean, const float* rstd, int C, double n, float* dgamma, float* dbeta, float* coef_x,
+                      float* coef_1, int accumulate, void* stream);
+
+/* D16  all convolution weights of a training step re-packed in ONE launch (they change every optimizer step): a device
+ * table with one row per (layer, layout): kind 0 = the forward layout of ossid_conv_pack_weights, 1 = the data-gradient
+ * layout of ossid_conv_pack_weights_dgrad; first_block = prefix sum of ceil(packed float4 / 256) over the rows before. */
+typedef struct ossid_pack_row {
+    const float* w;
+    float* wpk;
+    int64_t first_block;
+    int32_t cout, cin, taps, kind;
+} ossid_pack_row;
+int ossid_conv_pack_weights_table(const ossid_pack_row* rows_device, int n_rows, long long total_blocks, void* stream);
 
 /* D4  nn.AvgPool2d(2, stride) of the DenseNet transitions (stride 2; the third one stride 1, network.py:165),
  * channels-last. backward != 0: x is d out [B][Ho][Wo][C] and out receives d in [B][H][W][C]. */

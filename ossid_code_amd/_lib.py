@@ -40,7 +40,13 @@ class ChanOpDesc(C.Structure):
     _fields_ = [(n, _vp) for n in ("g", "x", "out", "alpha", "beta", "kappa", "mask_scale", "mask_shift", "partials",
                                    "sums")] + [("n_rows", C.c_int64)] + \
                [(n, C.c_int32) for n in ("channels", "g_stride", "x_stride", "out_stride", "mask_mode", "accumulate",
-                                         "sum_mode", "sums_row_stride")]
+                                         "sum_mode", "sums_row_stride", "defer_finalize")]
+
+
+class PackRow(C.Structure):
+    """struct ossid_pack_row (include/ossid_hip.h)."""
+    _fields_ = [("w", _vp), ("wpk", _vp), ("first_block", C.c_int64), ("cout", C.c_int32), ("cin", C.c_int32),
+                ("taps", C.c_int32), ("kind", C.c_int32)]
 
 
 _PROTOS = {
@@ -81,11 +87,14 @@ _PROTOS = {
     "ossid_conv3x3_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),
     "ossid_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "ossid_conv_wgrad": (_i, [_vp, _vp]),
+    "ossid_conv_wgrad_group_workspace_bytes": (_sz, [_vp, _i]),
+    "ossid_conv_wgrad_group": (_i, [_vp, _i, _vp, _sz, _vp]),
     "ossid_conv_pack_weights_dgrad": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ossid_chan_op_partials": (_i, [C.c_longlong, _i]),
     "ossid_chan_op": (_i, [_vp, _vp]),
-    "ossid_bn_fold_fwd": (_i, [_vp, _i, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ossid_bn_fold_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ossid_bn_fold_fwd": (_i, [_vp, _i, _vp, _i, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ossid_bn_fold_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, C.c_double, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ossid_conv_pack_weights_table": (_i, [_vp, _i, C.c_longlong, _vp]),
     "ossid_avgpool2_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "ossid_upsample_nearest_bwd_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ossid_nms_workspace_bytes": (_sz, [_i]),

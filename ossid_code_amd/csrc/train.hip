@@ -128,17 +128,53 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 }
 
 // =====================================================================================================================
-// training-mode BatchNorm as a folded affine. sums = (sum x, sum x^2) over n rows.
-__global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restrict__ sums, int sums_row_stride, int C, double n,
+// training-mode BatchNorm as a folded affine. The two column sums of a channel come either finished (sums[c],
+// sums[row_stride + c]) or as the P per-block partials an ossid_chan_op launch with defer_finalize left behind
+// ([P][2][C]); in the second case this kernel does the finalize itself (same fixed order, in double): one launch less
+// per BatchNorm. Block = 64 channels x 4 quarter-sums.
+__device__ __forceinline__ void column_sums(const float* sums, int row_stride, const float* partials, int P, int C, int c,
+                                            int part, double (&red)[4][64][2], double& s0, double& s1) {
+    s0 = s1 = 0.0;
+    const int col = threadIdx.x & 63;
+    if (P <= 0) {
+        if (part == 0 && c < C) s0 = (double)sums[c], s1 = (double)sums[row_stride + c];
+        return;
+    }
+    if (c < C) {
+        const int per = (P + 3) / 4, p0 = part * per, p1 = min(P, p0 + per);
+        const float* src = partials + c;
+        int p = p0;
+        for (; p + 4 <= p1; p += 4) {
+            float a[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = src[(size_t)(p + k) * 2 * C], b[k] = src[(size_t)(p + k) * 2 * C + C];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s0 += (double)a[k], s1 += (double)b[k];
+        }
+        for (; p < p1; ++p) s0 += (double)src[(size_t)p * 2 * C], s1 += (double)src[(size_t)p * 2 * C + C];
+    }
+    red[part][col][0] = s0, red[part][col][1] = s1;
+    __syncthreads();
+    if (part == 0) {
+        s0 = (red[0][col][0] + red[1][col][0]) + (red[2][col][0] + red[3][col][0]);
+        s1 = (red[0][col][1] + red[1][col][1]) + (red[2][col][1] + red[3][col][1]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restrict__ sums, int sums_row_stride,
+                                                          const float* __restrict__ partials, int P, int C, double n,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, float* __restrict__ scale,
                                                           float* __restrict__ shift, float* __restrict__ mean_out,
                                                           float* __restrict__ rstd_out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const double mean = (double)sums[c] / n;
-    double var = (double)sums[sums_row_stride + c] / n - mean * mean;
+    __shared__ double red[4][64][2];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    double s0, s1;
+    column_sums(sums, sums_row_stride, partials, P, C, c, part, red, s0, s1);
+    if (part != 0 || c >= C) return;
+    const double mean = s0 / n;
+    double var = s1 / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
     const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
@@ -156,15 +192,24 @@ __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restric
 
 // (d scale, d shift) -> d gamma, d beta and the two per-channel coefficients of the statistics' own gradient:
 //   dx += cb[c] * x + ck[c]     (= d mean / n + 2 (x - mean) d var / n)
+// With P > 0 the pair comes as chan_op partials: row 0 = d shift (sum of g*m), row 1 = d scale (sum of g*m*x).
 __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
+                                                          const float* __restrict__ partials, int P,
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, int C, double n,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                           float* __restrict__ cb, float* __restrict__ ck, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[4][64][2];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    double s0 = 0.0, s1 = 0.0;
+    if (P > 0) {
+        column_sums(nullptr, 0, partials, P, C, c, part, red, s0, s1);
+    } else if (part == 0 && c < C) {
+        s0 = (double)dshift[c], s1 = (double)dscale[c];
+    }
+    if (part != 0 || c >= C) return;
     const double g = gamma ? (double)gamma[c] : 1.0, mu = (double)mean[c], r = (double)rstd[c];
-    const double dt = (double)dshift[c], ds = (double)dscale[c] - dt * mu;     // shift = beta - mean * scale
+    const double dt = s0, ds = s1 - dt * mu;     // shift = beta - mean * scale
     const double s = g * r;
     const double dmean = -dt * s, dvar = -0.5 * ds * g * r * r * r;
     if (dgamma) dgamma[c] = (float)(ds * r);
@@ -267,6 +312,47 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict
     wpk[i] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// every convolution weight of the training step packed in ONE launch (forward and data-gradient layouts): `table` has
+// one row per (layer, layout): {w, wpk, first block, Cout, Cin, taps, kind}; a block finds its row by binary search
+struct PackRow {
+    const float* w;
+    float4* wpk;
+    long long first_block;      // prefix sum of blocks (256 float4 each)
+    int Cout, Cin, taps, kind;  // kind 0: forward layout, 1: data-gradient layout
+};
+
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackRow* __restrict__ table, int n_rows) {
+    int lo = 0, hi = n_rows - 1;
+    const long long b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    const PackRow R = table[lo];
+    const size_t i = (size_t)(b - R.first_block) * 256 + threadIdx.x;
+    const int KB = (R.kind == 0 ? R.Cin : R.Cout) / 8;
+    const int MT = ((R.kind == 0 ? R.Cout : R.Cin) + 31) / 32;
+    const size_t total = (size_t)MT * KB * R.taps * 64;
+    if (i >= total) return;
+    const int lane = i & 63;
+    size_t r = i >> 6;
+    const int tap = r % R.taps;
+    r /= R.taps;
+    const int kb = r % KB, mt = r / KB;
+    float v[4];
+    if (R.kind == 0) {
+        const int co = mt * 32 + (lane & 31), ci = kb * 8 + 4 * (lane >> 5);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (co < R.Cout) ? R.w[((size_t)co * R.Cin + ci + e) * R.taps + tap] : 0.0f;
+    } else {
+        const int ci = mt * 32 + (lane & 31), co = kb * 8 + 4 * (lane >> 5);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[e] = (ci < R.Cin) ? R.w[((size_t)(co + e) * R.Cin + ci) * R.taps + (R.taps - 1 - tap)] : 0.0f;
+    }
+    R.wpk[i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // =====================================================================================================================
 // weight gradient: dW[co][ci][tap] = sum_px dY[px][co] * P(X)[px + tap][ci],  P = the forward's input prologue
 // (per-channel affine (+ReLU) on real pixels, zero outside the image). GEMM with the PIXELS on K:
@@ -286,7 +372,7 @@ struct WgradArgs {
 };
 
 template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& A, const int L) {
     constexpr int CO_T = WM * TM * 32, CI_T = WN * TN * 32;
     constexpr int KX = TAPS == 9 ? 3 : 1;
     constexpr int NT = TM * TN * KX * KYB;                   // accumulator tiles per wave
@@ -307,7 +393,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
 
     // ---- which tile / split: consecutive workgroup ids walk the tiles of ONE split (they read the same dY / X rows,
     // which then hit in L2), splits follow each other (placement only -- any mapping computes the same sums)
-    const int L = blockIdx.x;
     const int split = L / A.ntiles;
     int tile = L - split * A.ntiles;
     int ky0 = 0;
@@ -468,6 +553,71 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
             }
 }
 
+template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
+    wgrad_body<TAPS, KYB, TM, TN, WM, WN, WK>(A, blockIdx.x);
+}
+
+// Several independent weight gradients of ONE tiling variant in one launch (the 2 x L small problems of a dense block,
+// each too small to fill the chip and too short to hide a launch): the descriptors travel in the kernel arguments.
+#define OSSID_WGRAD_GROUP_MAX 24
+struct WgradGroup {
+    WgradArgs a[OSSID_WGRAD_GROUP_MAX];
+    int first_block[OSSID_WGRAD_GROUP_MAX + 1];
+    int n;
+};
+
+template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
+__global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradGroup G) {
+    int i = 0;
+    const int b = blockIdx.x;
+    while (i + 1 < G.n && G.first_block[i + 1] <= b) ++i;
+    wgrad_body<TAPS, KYB, TM, TN, WM, WN, WK>(G.a[i], b - G.first_block[i]);
+}
+
+struct ReduceRow {
+    const float* slabs;
+    float* dw;
+    int nslabs, taps, Cout, Cin, accumulate, first_block;
+};
+struct ReduceGroup {
+    ReduceRow r[2 * OSSID_WGRAD_GROUP_MAX];
+    int n;
+};
+
+// grouped form of wgrad_reduce2_kernel<4>: 64 elements x 4 partial sums per block
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(const ReduceGroup R) {
+    __shared__ float red[4][64];
+    int g = 0;
+    const int b = blockIdx.x;
+    while (g + 1 < R.n && R.r[g + 1].first_block <= b) ++g;
+    const ReduceRow& row = R.r[g];
+    const size_t n = (size_t)row.taps * row.Cout * row.Cin;
+    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const size_t i = (size_t)(b - row.first_block) * 64 + e;
+    float s = 0.0f;
+    if (i < n) {
+        int k = part;
+        for (; k + 28 < row.nslabs; k += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = row.slabs[(size_t)(k + 4 * u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < row.nslabs; k += 4) s += row.slabs[(size_t)k * n + i];
+    }
+    red[part][e] = s;
+    __syncthreads();
+    if (part != 0 || i >= n) return;
+    s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    const int ci = (int)(i % row.Cin);
+    const size_t r = i / row.Cin;
+    const int co = (int)(r % row.Cout), tap = (int)(r / row.Cout);
+    float* o = row.dw + ((size_t)co * row.Cin + ci) * row.taps + tap;
+    *o = row.accumulate ? *o + s : s;
+}
+
 // dw[co][ci][tap] (+)= sum over splits of slabs[split][tap][co][ci], in a fixed order. PARTS threads share one output
 // element (each sums every PARTS-th slab with independent, unrolled loads; the partial sums meet in LDS): with hundreds
 // of slabs and a small dW (layers with few channels and millions of pixels) one thread per element would be a serial
@@ -568,6 +718,14 @@ bool wgrad_plan(int B, int H, int W, int Cin, int Cout, int taps, WgradPlan& p) 
 }
 
 template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
+int launch_wgrad_group(const WgradGroup& g, size_t lds, hipStream_t s) {
+    auto kern = wgrad_group_kernel<TAPS, KYB, TM, TN, WM, WN, WK>;
+    OSSID_ENSURE_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)g.first_block[g.n]), dim3(256), lds, s, g);
+    return ossid_launch_status();
+}
+
+template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
 int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t s) {
     auto kern = wgrad_kernel<TAPS, KYB, TM, TN, WM, WN, WK>;
     OSSID_ENSURE_LDS(kern, p.lds);
@@ -605,7 +763,7 @@ int ossid_chan_op(const ossid_chan_op_desc* d, void* stream) {
     if (d->n_rows == 0) return OSSID_OK;
     if (!d->g || (d->mask_mode != 0 && !d->x) || d->mask_mode < 0 || d->mask_mode > 2 || d->sum_mode < 0 || d->sum_mode > 2)
         return OSSID_EINVAL;
-    if (d->sum_mode != 0 && (!d->partials || !d->sums)) return OSSID_EINVAL;
+    if (d->sum_mode != 0 && (!d->partials || (!d->sums && !d->defer_finalize))) return OSSID_EINVAL;
     if (!d->out && d->sum_mode == 0) return OSSID_EINVAL;
     ChanOpArgs a;
     a.g = d->g, a.x = d->x, a.out = d->out, a.alpha = d->alpha, a.beta = d->beta, a.kappa = d->kappa;
@@ -625,29 +783,41 @@ int ossid_chan_op(const ossid_chan_op_desc* d, void* stream) {
     else if (C4 <= 16) rc = launch_chan_op<16>(a, P, s);
     else if (C4 <= 32) rc = launch_chan_op<32>(a, P, s);
     else rc = launch_chan_op<64>(a, P, s);
-    if (rc != OSSID_OK || d->sum_mode == 0) return rc;
+    if (rc != OSSID_OK || d->sum_mode == 0 || d->defer_finalize) return rc;
     const int C2 = 2 * d->channels;
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C2 + 63) / 64), dim3(256), 0, s, (const float*)d->partials, P,
                        d->channels, d->sums, d->sums_row_stride > 0 ? d->sums_row_stride : d->channels);
     return ossid_launch_status();
 }
 
-int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, int C, double n, const float* gamma, const float* beta, float eps, float momentum,
-                      float* running_mean, float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out,
-                      void* stream) {
-    if (!sums || C <= 0 || n <= 0 || !scale || !shift || !mean_out || !rstd_out || (!running_mean != !running_var))
+int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, const float* partials, int n_partials, int C, double n,
+                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, void* stream) {
+    if ((!sums && n_partials <= 0) || (n_partials > 0 && !partials) || C <= 0 || n <= 0 || !scale || !shift || !mean_out ||
+        !rstd_out || (!running_mean != !running_var))
         return OSSID_EINVAL;
-    hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums,
-                       sums_row_stride > 0 ? sums_row_stride : C, C, n, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean_out, rstd_out);
+    hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, sums,
+                       sums_row_stride > 0 ? sums_row_stride : C, partials, n_partials, C, n, gamma, beta, eps, momentum,
+                       running_mean, running_var, scale, shift, mean_out, rstd_out);
     return ossid_launch_status();
 }
 
-int ossid_bn_fold_bwd(const float* dscale, const float* dshift, const float* gamma, const float* mean, const float* rstd,
-                      int C, double n, float* dgamma, float* dbeta, float* coef_x, float* coef_1, int accumulate,
-                      void* stream) {
-    if (!dscale || !dshift || !mean || !rstd || C <= 0 || n <= 0 || !coef_x || !coef_1) return OSSID_EINVAL;
-    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dscale, dshift, gamma,
-                       mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate);
+int ossid_bn_fold_bwd(const float* dscale, const float* dshift, const float* partials, int n_partials, const float* gamma,
+                      const float* mean, const float* rstd, int C, double n, float* dgamma, float* dbeta, float* coef_x,
+                      float* coef_1, int accumulate, void* stream) {
+    if (((!dscale || !dshift) && n_partials <= 0) || (n_partials > 0 && !partials) || !mean || !rstd || C <= 0 || n <= 0 ||
+        !coef_x || !coef_1)
+        return OSSID_EINVAL;
+    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, dscale, dshift, partials,
+                       n_partials, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate);
+    return ossid_launch_status();
+}
+
+int ossid_conv_pack_weights_table(const ossid_pack_row* rows_device, int n_rows, long long total_blocks, void* stream) {
+    if (!rows_device || n_rows <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL) return OSSID_EINVAL;
+    static_assert(sizeof(PackRow) == sizeof(ossid_pack_row), "pack row layout");
+    hipLaunchKernelGGL(pack_all_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const PackRow*)rows_device, n_rows);
     return ossid_launch_status();
 }
 
@@ -733,6 +903,121 @@ int ossid_conv_wgrad(const ossid_wgrad_desc* d, void* stream) {
     else
         hipLaunchKernelGGL(wgrad_reduce2_kernel<32>, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, s, (const float*)d->workspace,
                            slabs, taps, Cout, Cin, d->dw, d->accumulate);
+    return ossid_launch_status();
+}
+
+static int fill_wgrad_args(const ossid_wgrad_desc* d, const WgradPlan& p, WgradArgs& a) {
+    const int H = d->height, W = d->width, Cin = d->cin, Cout = d->cout, taps = d->taps;
+    a.x = d->x, a.dy = d->dy, a.pre_scale = d->pre_scale, a.pre_shift = d->pre_shift, a.slabs = (float*)d->workspace;
+    a.B = p.B, a.H = p.H, a.W = p.W, a.Cin = Cin, a.Cout = Cout;
+    a.in_cs = d->in_channel_stride > 0 ? d->in_channel_stride : Cin;
+    a.dy_cs = d->dy_channel_stride > 0 ? d->dy_channel_stride : Cout;
+    if ((a.in_cs % 4) || (a.dy_cs % 4) || a.in_cs < Cin || a.dy_cs < Cout) return OSSID_EINVAL;
+    a.Hs = d->src_height > 0 ? d->src_height : p.H, a.Ws = d->src_width > 0 ? d->src_width : p.W;
+    if ((a.Hs != p.H || a.Ws != p.W) && (taps != 9 || a.Hs > H || a.Ws > W)) return OSSID_EINVAL;
+    a.scale_h = (float)a.Hs / (float)p.H, a.scale_w = (float)a.Ws / (float)p.W;
+    a.pre_relu = d->pre_relu, a.KT = p.KT, a.chunks_per_row = p.chunks_per_row, a.nsplit = p.nsplit;
+    a.co_blocks = p.co_blocks, a.ci_blocks = p.ci_blocks, a.ntiles = p.ntiles, a.n_chunks = p.n_chunks;
+    return OSSID_OK;
+}
+
+// How many K-splits each problem of a GROUP gets: the group shares the chip, so the target is ~2.5 workgroups per CU
+// over the whole group, shared out in proportion to each problem's work (chunks x tiles).
+static void group_splits(WgradPlan* plans, int n) {
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) total += (double)plans[i].n_chunks * plans[i].ntiles;
+    for (int i = 0; i < n; ++i) {
+        const double share = (double)plans[i].n_chunks * plans[i].ntiles / total;
+        long sp = (long)(640.0 * share / plans[i].ntiles + 0.5);
+        if (sp < 1) sp = 1;
+        if (sp > plans[i].n_chunks) sp = (long)plans[i].n_chunks;
+        if (sp > 256) sp = 256;
+        plans[i].nsplit = (int)sp;
+    }
+}
+
+size_t ossid_conv_wgrad_group_workspace_bytes(const ossid_wgrad_desc* descs, int n) {
+    if (!descs || n <= 0 || n > 2 * OSSID_WGRAD_GROUP_MAX) return 0;
+    WgradPlan plans[4 * OSSID_WGRAD_GROUP_MAX];
+    for (int i = 0; i < n; ++i)
+        if (!wgrad_plan(descs[i].batch, descs[i].height, descs[i].width, descs[i].cin, descs[i].cout, descs[i].taps, plans[i]))
+            return 0;
+    // splits are chosen per variant bucket, as ossid_conv_wgrad_group does
+    size_t total = 0;
+    for (int v = 0; v < 7; ++v) {
+        WgradPlan sub[4 * OSSID_WGRAD_GROUP_MAX];
+        int idx[4 * OSSID_WGRAD_GROUP_MAX], m = 0;
+        for (int i = 0; i < n; ++i)
+            if (plans[i].variant == v) sub[m] = plans[i], idx[m++] = i;
+        for (int c0 = 0; c0 < m; c0 += OSSID_WGRAD_GROUP_MAX) {
+            const int cnt = m - c0 < OSSID_WGRAD_GROUP_MAX ? m - c0 : OSSID_WGRAD_GROUP_MAX;
+            group_splits(sub + c0, cnt);
+            for (int j = 0; j < cnt; ++j) {
+                const ossid_wgrad_desc& d = descs[idx[c0 + j]];
+                total += ((size_t)sub[c0 + j].nsplit * sub[c0 + j].wk * d.taps * d.cout * d.cin * sizeof(float) + 255) & ~(size_t)255;
+            }
+        }
+    }
+    return total;
+}
+
+int ossid_conv_wgrad_group(const ossid_wgrad_desc* descs, int n, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!descs || n <= 0 || n > 2 * OSSID_WGRAD_GROUP_MAX || !workspace) return OSSID_EINVAL;
+    if (workspace_bytes < ossid_conv_wgrad_group_workspace_bytes(descs, n)) return OSSID_EINVAL;
+    WgradPlan plans[4 * OSSID_WGRAD_GROUP_MAX];
+    for (int i = 0; i < n; ++i) {
+        const ossid_wgrad_desc& d = descs[i];
+        if (d.batch <= 0 || d.height <= 0 || d.width <= 0 || d.cin <= 0 || d.cout <= 0 || (d.cin % 4) || (d.cout % 4) || !d.x ||
+            !d.dy || !d.dw || (d.pre_scale && !d.pre_shift))
+            return OSSID_EINVAL;
+        if (!wgrad_plan(d.batch, d.height, d.width, d.cin, d.cout, d.taps, plans[i])) return OSSID_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    ReduceGroup red;
+    red.n = 0;
+    int red_blocks = 0;
+    for (int v = 0; v < 7; ++v) {
+        int idx[4 * OSSID_WGRAD_GROUP_MAX], m = 0;
+        for (int i = 0; i < n; ++i)
+            if (plans[i].variant == v) idx[m++] = i;
+        for (int c0 = 0; c0 < m; c0 += OSSID_WGRAD_GROUP_MAX) {
+            const int cnt = m - c0 < OSSID_WGRAD_GROUP_MAX ? m - c0 : OSSID_WGRAD_GROUP_MAX;
+            WgradPlan sub[OSSID_WGRAD_GROUP_MAX];
+            for (int j = 0; j < cnt; ++j) sub[j] = plans[idx[c0 + j]];
+            group_splits(sub, cnt);
+            WgradGroup g;
+            g.n = cnt;
+            g.first_block[0] = 0;
+            size_t lds = 0;
+            for (int j = 0; j < cnt; ++j) {
+                ossid_wgrad_desc d = descs[idx[c0 + j]];
+                d.workspace = ws;
+                const size_t bytes = (size_t)sub[j].nsplit * sub[j].wk * d.taps * d.cout * d.cin * sizeof(float);
+                ws += (bytes + 255) & ~(size_t)255;
+                const int rc = fill_wgrad_args(&d, sub[j], g.a[j]);
+                if (rc != OSSID_OK) return rc;
+                g.first_block[j + 1] = g.first_block[j] + sub[j].nsplit * sub[j].ntiles;
+                if (sub[j].lds > lds) lds = sub[j].lds;
+                ReduceRow& r = red.r[red.n++];
+                r.slabs = (const float*)d.workspace, r.dw = d.dw, r.nslabs = sub[j].nsplit * sub[j].wk, r.taps = d.taps;
+                r.Cout = d.cout, r.Cin = d.cin, r.accumulate = d.accumulate, r.first_block = red_blocks;
+                red_blocks += (int)(((size_t)d.taps * d.cout * d.cin + 63) / 64);
+            }
+            int rc;
+            switch (v) {
+                case 0: rc = launch_wgrad_group<9, 1, 2, 1, 2, 2, 1>(g, lds, s); break;
+                case 1: rc = launch_wgrad_group<9, 1, 1, 2, 2, 2, 1>(g, lds, s); break;
+                case 2: rc = launch_wgrad_group<9, 1, 1, 1, 1, 4, 1>(g, lds, s); break;
+                case 3: rc = launch_wgrad_group<1, 1, 2, 2, 2, 2, 1>(g, lds, s); break;
+                case 4: rc = launch_wgrad_group<1, 1, 1, 2, 2, 2, 1>(g, lds, s); break;
+                case 5: rc = launch_wgrad_group<9, 3, 1, 1, 1, 1, 4>(g, lds, s); break;
+                default: rc = launch_wgrad_group<9, 3, 1, 1, 1, 2, 2>(g, lds, s); break;
+            }
+            if (rc != OSSID_OK) return rc;
+        }
+    }
+    if (red.n > 0) hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3((unsigned)red_blocks), dim3(256), 0, s, red);
     return ossid_launch_status();
 }
 

@@ -138,11 +138,41 @@ def _squeezenet_trunk(mod):
     mod.norm_2 = nn.BatchNorm2d(512, affine=True)
 
 
+_BILINEAR = {}
+
+
+def _bilinear_matrix(n_in, n_out, device):
+    """[n_out, n_in] matrix of F.interpolate(mode="bilinear", align_corners=False) along one axis (the torch formula:
+    src = (dst + 0.5) * in/out - 0.5 clamped at 0, neighbours floor(src) and min(floor(src)+1, in-1))."""
+    key = (n_in, n_out, str(device))
+    if key not in _BILINEAR:
+        src = ((torch.arange(n_out, dtype=torch.float32) + 0.5) * (float(n_in) / float(n_out)) - 0.5).clamp(min=0)
+        i0 = src.floor().long().clamp(max=n_in - 1)
+        i1 = (i0 + 1).clamp(max=n_in - 1)
+        lam = src - i0.float()
+        A = torch.zeros(n_out, n_in)
+        A[torch.arange(n_out), i0] += 1.0 - lam
+        A[torch.arange(n_out), i1] += lam
+        _BILINEAR[key] = A.to(device)
+    return _BILINEAR[key]
+
+
+def _bilinear_resize(x, size):
+    """F.interpolate(x, size=size, mode="bilinear", align_corners=False). On the GPU as two small matrix products (the
+    30x30 -> 7x7 resize of the template encoders, network.py:236/:276: torch's kernel takes 0.3 ms per call there --
+    one thread per output pixel looping over batch x channels -- and its backward as long again)."""
+    if not x.is_cuda:
+        return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    A = _bilinear_matrix(x.shape[2], int(size), x.device)
+    Bm = _bilinear_matrix(x.shape[3], int(size), x.device)
+    return torch.matmul(torch.matmul(A, x), Bm.t())
+
+
 def _squeezenet_features(mod, img):
     x1 = mod.backbone_1(mod.backbone_0(img))
     x2 = mod.backbone_2(x1)
     x1n, x2n = mod.norm_1(x1), mod.norm_2(x2)
-    x1d = F.interpolate(x1n, size=x2.size(3), mode="bilinear", align_corners=False)
+    x1d = _bilinear_resize(x1n, x2.size(3))
     return torch.cat([x2n, x1d], dim=1)
 
 
@@ -542,6 +572,7 @@ class Network(nn.Module):
         from . import train_ops as T
         from .backbones import DenseBlock, Transition
         ife = self.image_feature_extractor
+        self._train_pack_plan().run()                            # every conv weight -> MFMA layouts, one launch
         x0 = ife.backdense_0(image)
         x0 = x0 + ops.dw_xcorr(x0, g)
         seq = list(ife.backdense_1) + list(ife.backdense_2)      # norm0 relu0 pool0 block1 | trans1 block2 ... norm5
@@ -571,6 +602,28 @@ class Network(nn.Module):
             self.__dict__["_folded_bn_counters"] = ts
         torch._foreach_add_(ts, 1)
         return out
+
+    def _train_pack_plan(self):
+        """The PackPlan over every convolution the hip training path runs (DenseNet blocks and transitions, c1, the head's
+        3x3 convolutions), rebuilt when a weight tensor was re-homed."""
+        from . import train_ops as T
+        from .backbones import DenseBlock, Transition
+        ife, corr = self.image_feature_extractor, self.correlation_model
+        convs = []
+        for m in list(ife.backdense_1) + list(ife.backdense_2):
+            if isinstance(m, DenseBlock):
+                for layer in m.values():
+                    convs += [layer.conv1, layer.conv2]
+            elif isinstance(m, Transition):
+                convs.append(m.conv)
+        convs += [ife.c1, corr.corr_conv_dot, corr.corr_conv_sub, corr.corr_conv_dot3x3, corr.cf] + \
+            [getattr(corr, "s%d" % i) for i in (1, 2, 3, 4, 5)]
+        for mod in (self.classification, self.regression):
+            convs += [getattr(mod, "conv%d" % i) for i in (1, 2, 3, 4)] + [mod.output]
+        plan = self.__dict__.get("_pack_plan")
+        if plan is None or not plan.valid_for(convs):
+            plan = self.__dict__["_pack_plan"] = T.PackPlan(convs)
+        return plan
 
     def _head_train_hip(self, feat, local):
         """CorrelationModel + ClassificationModel + RegressionModel in training mode (network.py:328-363, :113-157) on the

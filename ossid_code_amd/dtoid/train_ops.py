@@ -61,10 +61,12 @@ def _scratch(name, nbytes, device):
 
 # ---- raw ops (no autograd) --------------------------------------------------------------------------------------------
 def chan_op(g, n_rows, C, x=None, out=None, g_cs=0, x_cs=0, out_cs=0, alpha=None, beta=None, kappa=None, mask_mode=0,
-            mask_scale=None, mask_shift=None, accumulate=False, sum_mode=0, sums=None, sums_row_stride=0):
+            mask_scale=None, mask_shift=None, accumulate=False, sum_mode=0, sums=None, sums_row_stride=0, defer=False):
     """include/ossid_hip.h ossid_chan_op on raw channels-last buffers (tensors only provide pointers; a tensor that is a
     channel slice of a wider buffer is passed as its first-element pointer + the buffer's channel count as stride).
-    Returns `sums` ([2, C] float32, allocated when sum_mode != 0 and none was given)."""
+    Returns `sums` ([2, C] float32, allocated when sum_mode != 0 and none was given). defer=True: the column sums stay
+    as per-block partials in a scratch buffer and (scratch, P) is returned for bn_fold_fwd / bn_fold_bwd to combine --
+    valid until the next deferred chan_op on this stream."""
     d = _lib.ChanOpDesc()
     dev = g.device
     d.g, d.x, d.out = g.data_ptr(), _p(x), _p(out)
@@ -72,11 +74,16 @@ def chan_op(g, n_rows, C, x=None, out=None, g_cs=0, x_cs=0, out_cs=0, alpha=None
     d.n_rows, d.channels, d.g_stride, d.x_stride, d.out_stride = int(n_rows), int(C), int(g_cs), int(x_cs), int(out_cs)
     d.mask_mode, d.accumulate, d.sum_mode, d.sums_row_stride = int(mask_mode), 1 if accumulate else 0, int(sum_mode), int(sums_row_stride)
     if sum_mode:
-        if sums is None:
-            sums = torch.empty((2, C), dtype=torch.float32, device=dev)
         P = _lib.fn("ossid_chan_op_partials")(int(n_rows), int(C))
-        d.partials = _scratch("chan", P * 2 * C * 4, dev).data_ptr()
-        d.sums = sums.data_ptr()
+        if defer:
+            part = _scratch("chan_defer", P * 2 * C * 4, dev)
+            d.partials, d.defer_finalize = part.data_ptr(), 1
+            sums = (part, P)
+        else:
+            if sums is None:
+                sums = torch.empty((2, C), dtype=torch.float32, device=dev)
+            d.partials = _scratch("chan", P * 2 * C * 4, dev).data_ptr()
+            d.sums = sums.data_ptr()
     with torch.cuda.device(dev):
         _lib.check(_lib.fn("ossid_chan_op")(_byref(d), _lib.stream()), "ossid_chan_op")
     return sums
@@ -102,15 +109,68 @@ class _Packed:
         return ent
 
 
+_FRESH = {}         # (weight pointer, shape, kind) -> the weight's version counter when the step's PackPlan packed it:
+#                     _pack() skips its own launch while the weight has not been written since
+
+
 def _pack(w, kind):
     w = w.detach()
     assert w.is_contiguous() and w.dtype == torch.float32
     cout, cin, taps = int(w.shape[0]), int(w.shape[1]), int(w.shape[2] * w.shape[3])
     buf = _Packed.get(w, kind)
+    if _FRESH.get((w.data_ptr(), tuple(w.shape), kind)) == w._version:
+        return buf
     name = "ossid_conv_pack_weights" if kind == "fwd" else "ossid_conv_pack_weights_dgrad"
     with torch.cuda.device(w.device):
         _lib.check(_lib.fn(name)(w.data_ptr(), cout, cin, taps, buf.data_ptr(), _lib.stream()), name)
     return buf
+
+
+class PackPlan:
+    """All convolution weights of the training step re-packed (forward + data-gradient layouts) by ONE launch at the top
+    of the forward pass instead of two small launches per layer. Built once per set of weight tensors (their addresses
+    are stable: FlatParams views); `run()` marks them fresh so the per-layer _pack() calls only look the buffers up."""
+
+    def __init__(self, convs):
+        rows, keys, first = [], [], 0
+        for conv in convs:
+            w = conv.weight.detach()
+            cout, cin, taps = int(w.shape[0]), int(w.shape[1]), int(w.shape[2] * w.shape[3])
+            for kind in ("fwd", "dgrad"):
+                if kind == "dgrad" and cout % 16:
+                    continue
+                if kind == "fwd" and (cin % 16 or cout % 4):
+                    continue
+                buf = _Packed.get(w, kind)
+                rows.append((w.data_ptr(), buf.data_ptr(), first, cout, cin, taps, 0 if kind == "fwd" else 1))
+                keys.append((w.data_ptr(), tuple(w.shape), kind))
+                first += (buf.numel() // 4 + 255) // 256
+        arr = (_lib.PackRow * len(rows))()
+        for i, r in enumerate(rows):
+            arr[i].w, arr[i].wpk, arr[i].first_block, arr[i].cout, arr[i].cin, arr[i].taps, arr[i].kind = r
+        raw = bytes(arr)
+        self.device = convs[0].weight.device
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self.n_rows, self.total_blocks, self.keys = len(rows), first, keys
+        self.weights = [c.weight for c in convs]
+        self.sig = tuple(w.data_ptr() for w in self.weights)
+
+    def valid_for(self, convs):
+        return len(convs) == len(self.sig) and all(c.weight.data_ptr() == p for c, p in zip(convs, self.sig))
+
+    def run(self):
+        with torch.cuda.device(self.device):
+            rc = _lib.fn("ossid_conv_pack_weights_table")(self.table.data_ptr(), self.n_rows, self.total_blocks, _lib.stream())
+        _lib.check(rc, "ossid_conv_pack_weights_table")
+        _FRESH.clear()
+        vers = {w.data_ptr(): w._version for w in self.weights}
+        for k in self.keys:
+            _FRESH[k] = vers[k[0]]
+
+
+def end_step():
+    """Weights are about to change (optimizer step): nothing is fresh any more."""
+    _FRESH.clear()
 
 
 def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_relu=False, act=0, in_cs=0, out_cs=0,
@@ -147,20 +207,48 @@ def wgrad_raw(x, dy, B, H, W, cin, cout, taps, dw, pre=None, pre_relu=False, in_
     return dw
 
 
+def wgrad_group(items):
+    """Several independent weight gradients in one launch per tiling variant (ossid_conv_wgrad_group). items: dicts with
+    the keyword arguments of wgrad_raw (x, dy, B, H, W, cin, cout, taps, dw, pre, pre_relu, in_cs, dy_cs)."""
+    n = len(items)
+    arr = (_lib.WgradDesc * n)()
+    for d, it in zip(arr, items):
+        d.x, d.dy, d.dw = it["x"].data_ptr(), it["dy"].data_ptr(), it["dw"].data_ptr()
+        pre = it.get("pre")
+        if pre is not None:
+            d.pre_scale, d.pre_shift = pre[0].data_ptr(), pre[1].data_ptr()
+        d.batch, d.height, d.width, d.cin, d.cout, d.taps = it["B"], it["H"], it["W"], it["cin"], it["cout"], it["taps"]
+        d.pre_relu, d.accumulate = 1 if it.get("pre_relu") else 0, 0
+        d.in_channel_stride, d.dy_channel_stride = int(it.get("in_cs", 0)), int(it.get("dy_cs", 0))
+    dev = items[0]["dw"].device
+    nbytes = _lib.fn("ossid_conv_wgrad_group_workspace_bytes")(arr, n)
+    if nbytes == 0:
+        raise RuntimeError("ossid_conv_wgrad_group_workspace_bytes rejected the group")
+    ws = _scratch("wgrad_group", nbytes, dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.fn("ossid_conv_wgrad_group")(arr, n, ws.data_ptr(), nbytes, _lib.stream()), "ossid_conv_wgrad_group")
+
+
 def bn_fold_fwd(sums, C, n, gamma, beta, eps, momentum, running_mean, running_var, sums_row_stride=0):
-    dev = sums.device
+    """sums: a [2, C] tensor (or a pointer into a wider table, with sums_row_stride), or the (scratch, P) pair of a deferred
+    chan_op. Returns [4, C] = scale, shift, mean, rstd."""
+    part, P = (sums if isinstance(sums, tuple) else (None, 0))
+    dev = part.device if part is not None else sums.device
     out = torch.empty((4, C), dtype=torch.float32, device=dev)          # scale, shift, mean, rstd
     with torch.cuda.device(dev):
-        rc = _lib.fn("ossid_bn_fold_fwd")(sums.data_ptr(), int(sums_row_stride), C, float(n), _p(gamma), _p(beta), float(eps),
+        rc = _lib.fn("ossid_bn_fold_fwd")(None if part is not None else sums.data_ptr(), int(sums_row_stride), _p(part), int(P),
+                                          C, float(n), _p(gamma), _p(beta), float(eps),
                                           float(momentum), _p(running_mean), _p(running_var), out[0].data_ptr(),
                                           out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _lib.stream())
     _lib.check(rc, "ossid_bn_fold_fwd")
     return out
 
 
-def bn_fold_bwd(dscale, dshift, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate=False):
+def bn_fold_bwd(dscale, dshift, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate=False, partials=None):
+    """partials = (scratch, P) of a deferred chan_op (row 0 = d shift, row 1 = d scale) instead of dscale / dshift."""
+    part, P = partials if partials is not None else (None, 0)
     with torch.cuda.device(coef_x.device):
-        rc = _lib.fn("ossid_bn_fold_bwd")(dscale.data_ptr(), dshift.data_ptr(), _p(gamma), mean.data_ptr(), rstd.data_ptr(),
+        rc = _lib.fn("ossid_bn_fold_bwd")(_p(dscale), _p(dshift), _p(part), int(P), _p(gamma), mean.data_ptr(), rstd.data_ptr(),
                                           C, float(n), _p(dgamma), _p(dbeta), coef_x.data_ptr(), coef_1.data_ptr(),
                                           1 if accumulate else 0, _lib.stream())
     _lib.check(rc, "ossid_bn_fold_bwd")
@@ -391,7 +479,7 @@ class DenseBlockTrain(torch.autograd.Function):
             mid = int(w1.shape[0])
             y1 = empty_nhwc(B, mid, H, W, dev)
             conv_raw(buf, _pack(w1, "fwd"), B, H, W, c, mid, 1, y1, pre=(f1[0], f1[1]), pre_relu=True, in_cs=Ct)
-            s2 = chan_op(y1, N, mid, x=y1, sum_mode=1)
+            s2 = chan_op(y1, N, mid, x=y1, sum_mode=1, defer=True)
             f2 = bn_fold_fwd(s2, mid, N, g2, b2, layer.norm2.eps, _mom(layer.norm2), layer.norm2.running_mean,
                              layer.norm2.running_var)
             conv_raw(y1, _pack(w2, "fwd"), B, H, W, mid, growth, 9, buf, pre=(f2[0], f2[1]), pre_relu=True, out_cs=Ct,
@@ -414,35 +502,41 @@ class DenseBlockTrain(torch.autograd.Function):
         coef = torch.zeros((2, Ct), dtype=torch.float32, device=dev)          # [coef_x, coef_1] of the statistics' gradient
         grads = [None] * len(params)
         mid = int(params[2].shape[0])
-        db = empty_nhwc(B, mid, H, W, dev)
+        dz_all = torch.empty((L, B, H, W, mid), dtype=torch.float32, device=dev)   # per layer: the 1x1 wgrad runs at the end
         da = empty_nhwc(B, Ct, H, W, dev)          # data gradient of the 1x1: c_l <= Ct channels, written densely [N][c_l]
+        deferred = []                              # the block's 2 L weight gradients: ONE grouped launch below
         c = C0 + L * growth
         for li in range(L - 1, -1, -1):
             c -= growth
             g1, b1, w1, g2, b2, w2 = params[6 * li:6 * li + 6]
             f1, y1, f2 = saved[li]
+            db = dz_all[li]
             # the layer's own 32 channels: every later consumer has added its share; add the statistics term
             gs, xs = flat(G, c), flat(buf, c)
             chan_op(gs, N, growth, x=xs, out=gs, g_cs=Ct, x_cs=Ct, out_cs=Ct, beta=coef[0, c:c + growth],
                     kappa=coef[1, c:c + growth])
-            # 3x3: weight gradient on relu(bn2(y1)), data gradient to the bottleneck
+            # 3x3: weight gradient on relu(bn2(y1)) (deferred: this slice of G is final from here on), data gradient
+            # to the bottleneck (reads the strided slice: in_cs = Ct)
             dw2 = torch.empty_like(w2)
-            wgrad_raw(y1, gs, B, H, W, mid, growth, 9, dw2, pre=(f2[0], f2[1]), pre_relu=True, dy_cs=Ct)
-            # (the data gradient reads the strided slice: in_cs = Ct)
+            deferred.append(dict(x=y1, dy=gs, B=B, H=H, W=W, cin=mid, cout=growth, taps=9, dw=dw2, pre=(f2[0], f2[1]),
+                                 pre_relu=True, dy_cs=Ct))
             conv_raw(gs, _pack(w2, "dgrad"), B, H, W, growth, mid, 9, db, in_cs=Ct)
-            s = chan_op(db, N, mid, x=y1, out=db, alpha=f2[0], mask_mode=1, mask_scale=f2[0], mask_shift=f2[1], sum_mode=1)
+            s = chan_op(db, N, mid, x=y1, out=db, alpha=f2[0], mask_mode=1, mask_scale=f2[0], mask_shift=f2[1], sum_mode=1,
+                        defer=True)
             r2 = torch.empty((4, mid), dtype=torch.float32, device=dev)
-            bn_fold_bwd(s[1], s[0], g2, f2[2], f2[3], mid, N, r2[0], r2[1], r2[2], r2[3])
+            bn_fold_bwd(None, None, g2, f2[2], f2[3], mid, N, r2[0], r2[1], r2[2], r2[3], partials=s)
             chan_op(db, N, mid, x=y1, out=db, beta=r2[2], kappa=r2[3])          # dz = scale*db*mask + coef_x*y1 + coef_1
-            # 1x1: weight gradient on relu(bn1(buf[:, :c])), data gradient to the c input channels
+            # 1x1: weight gradient on relu(bn1(buf[:, :c])) (deferred), data gradient to the c input channels
             dw1 = torch.empty_like(w1)
-            wgrad_raw(buf, db, B, H, W, c, mid, 1, dw1, pre=(f1[0], f1[1]), pre_relu=True, in_cs=Ct)
+            deferred.append(dict(x=buf, dy=db, B=B, H=H, W=W, cin=c, cout=mid, taps=1, dw=dw1, pre=(f1[0], f1[1]),
+                                 pre_relu=True, in_cs=Ct))
             conv_raw(db, _pack(w1, "dgrad"), B, H, W, mid, c, 1, da)
             s = chan_op(da, N, c, x=buf, out=G, x_cs=Ct, out_cs=Ct, alpha=f1[0], mask_mode=1, mask_scale=f1[0],
-                        mask_shift=f1[1], accumulate=True, sum_mode=1)
+                        mask_shift=f1[1], accumulate=True, sum_mode=1, defer=True)
             r1 = torch.empty((2, c), dtype=torch.float32, device=dev)
-            bn_fold_bwd(s[1], s[0], g1, f1[2], f1[3], c, N, r1[0], r1[1], coef[0], coef[1], accumulate=True)
+            bn_fold_bwd(None, None, g1, f1[2], f1[3], c, N, r1[0], r1[1], coef[0], coef[1], accumulate=True, partials=s)
             grads[6 * li:6 * li + 6] = [r1[0], r1[1], dw1, r2[0], r2[1], dw2]
+        wgrad_group(deferred)
         # the block's input channels
         chan_op(G, N, C0, x=buf, out=G, g_cs=Ct, x_cs=Ct, out_cs=Ct, beta=coef[0, :C0], kappa=coef[1, :C0])
         dx = G[:, :C0].contiguous(memory_format=torch.channels_last)
