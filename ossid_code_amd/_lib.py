@@ -25,7 +25,10 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, _vp) for n in ("x", "wpk", "bias", "pre_scale", "pre_shift", "post_scale", "post_shift", "out")] + \
                [(n, C.c_int32) for n in ("batch", "height", "width", "cin", "cout", "taps", "act", "pre_relu",
                                          "src_height", "src_width", "in_channel_stride", "out_channel_stride",
-                                         "out_channel_offset", "pre_batch_stride")] + [("in_batch_stride", C.c_int64)]
+                                         "out_channel_offset", "pre_batch_stride")] + [("in_batch_stride", C.c_int64)] + \
+               [(n, _vp) for n in ("epi_aux", "epi_alpha", "epi_mask_scale", "epi_mask_shift", "epi_partials")] + \
+               [("epi_partials_rows", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("epi_aux_channel_stride", "epi_mask_mode", "epi_accumulate", "epi_sum_mode")]
 
 
 class WgradDesc(C.Structure):
@@ -79,6 +82,7 @@ _PROTOS = {
     "ossid_conv_packed_floats": (_sz, [_i, _i, _i]),
     "ossid_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ossid_conv_nhwc_fwd": (_i, [_vp, _vp]),
+    "ossid_conv_last_partial_rows": (C.c_longlong, []),
     "ossid_seg_tail_packed_floats": (_sz, []),
     "ossid_seg_tail_pack_weights": (_i, [_vp, _vp, _vp]),
     "ossid_seg_tail_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -95,6 +99,7 @@ _PROTOS = {
     "ossid_bn_fold_fwd": (_i, [_vp, _i, _vp, _i, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_bn_fold_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, C.c_double, _vp, _vp, _vp, _vp, _i, _vp]),
     "ossid_conv_pack_weights_table": (_i, [_vp, _i, C.c_longlong, _vp]),
+    "ossid_colsum_finalize": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "ossid_avgpool2_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "ossid_upsample_nearest_bwd_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ossid_nms_workspace_bytes": (_sz, [_i]),

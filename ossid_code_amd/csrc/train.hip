@@ -132,16 +132,18 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 // sums[row_stride + c]) or as the P per-block partials an ossid_chan_op launch with defer_finalize left behind
 // ([P][2][C]); in the second case this kernel does the finalize itself (same fixed order, in double): one launch less
 // per BatchNorm. Block = 64 channels x 4 quarter-sums.
+template <int PARTS>
 __device__ __forceinline__ void column_sums(const float* sums, int row_stride, const float* partials, int P, int C, int c,
-                                            int part, double (&red)[4][64][2], double& s0, double& s1) {
+                                            int part, double (&red)[PARTS][256 / PARTS][2], double& s0, double& s1) {
+    constexpr int CPB = 256 / PARTS;
     s0 = s1 = 0.0;
-    const int col = threadIdx.x & 63;
+    const int col = threadIdx.x % CPB;
     if (P <= 0) {
         if (part == 0 && c < C) s0 = (double)sums[c], s1 = (double)sums[row_stride + c];
         return;
     }
     if (c < C) {
-        const int per = (P + 3) / 4, p0 = part * per, p1 = min(P, p0 + per);
+        const int per = (P + PARTS - 1) / PARTS, p0 = part * per, p1 = min(P, p0 + per);
         const float* src = partials + c;
         int p = p0;
         for (; p + 4 <= p1; p += 4) {
@@ -156,11 +158,13 @@ __device__ __forceinline__ void column_sums(const float* sums, int row_stride, c
     red[part][col][0] = s0, red[part][col][1] = s1;
     __syncthreads();
     if (part == 0) {
-        s0 = (red[0][col][0] + red[1][col][0]) + (red[2][col][0] + red[3][col][0]);
-        s1 = (red[0][col][1] + red[1][col][1]) + (red[2][col][1] + red[3][col][1]);
+        s0 = red[0][col][0], s1 = red[0][col][1];
+#pragma unroll
+        for (int k = 1; k < PARTS; ++k) s0 += red[k][col][0], s1 += red[k][col][1];
     }
 }
 
+template <int PARTS>
 __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restrict__ sums, int sums_row_stride,
                                                           const float* __restrict__ partials, int P, int C, double n,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -168,10 +172,11 @@ __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restric
                                                           float* __restrict__ running_var, float* __restrict__ scale,
                                                           float* __restrict__ shift, float* __restrict__ mean_out,
                                                           float* __restrict__ rstd_out) {
-    __shared__ double red[4][64][2];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    constexpr int CPB = 256 / PARTS;
+    __shared__ double red[PARTS][CPB][2];
+    const int c = blockIdx.x * CPB + (threadIdx.x % CPB), part = threadIdx.x / CPB;
     double s0, s1;
-    column_sums(sums, sums_row_stride, partials, P, C, c, part, red, s0, s1);
+    column_sums<PARTS>(sums, sums_row_stride, partials, P, C, c, part, red, s0, s1);
     if (part != 0 || c >= C) return;
     const double mean = s0 / n;
     double var = s1 / n - mean * mean;
@@ -192,18 +197,20 @@ __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restric
 
 // (d scale, d shift) -> d gamma, d beta and the two per-channel coefficients of the statistics' own gradient:
 //   dx += cb[c] * x + ck[c]     (= d mean / n + 2 (x - mean) d var / n)
-// With P > 0 the pair comes as chan_op partials: row 0 = d shift (sum of g*m), row 1 = d scale (sum of g*m*x).
+// With P > 0 the pair comes as partial rows: row 0 = d shift (sum of g*m), row 1 = d scale (sum of g*m*x).
+template <int PARTS>
 __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
                                                           const float* __restrict__ partials, int P,
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, int C, double n,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                           float* __restrict__ cb, float* __restrict__ ck, int accumulate) {
-    __shared__ double red[4][64][2];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    constexpr int CPB = 256 / PARTS;
+    __shared__ double red[PARTS][CPB][2];
+    const int c = blockIdx.x * CPB + (threadIdx.x % CPB), part = threadIdx.x / CPB;
     double s0 = 0.0, s1 = 0.0;
     if (P > 0) {
-        column_sums(nullptr, 0, partials, P, C, c, part, red, s0, s1);
+        column_sums<PARTS>(nullptr, 0, partials, P, C, c, part, red, s0, s1);
     } else if (part == 0 && c < C) {
         s0 = (double)dshift[c], s1 = (double)dscale[c];
     }
@@ -222,6 +229,18 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const float* __restric
         cb[c] = (float)b;
         ck[c] = (float)k;
     }
+}
+
+// stand-alone finalize of partial rows into a (possibly strided) sums table, many rows: 16 channels x 16 partial sums
+__global__ __launch_bounds__(256) void colsum_finalize16_kernel(const float* __restrict__ partials, int P, int C,
+                                                                float* __restrict__ sums, int row_stride) {
+    __shared__ double red[16][16][2];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+    double s0, s1;
+    column_sums<16>(nullptr, 0, partials, P, C, c, part, red, s0, s1);
+    if (part != 0 || c >= C) return;
+    sums[c] = (float)s0;
+    sums[row_stride + c] = (float)s1;
 }
 
 // =====================================================================================================================
@@ -796,9 +815,14 @@ int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, const float* parti
     if ((!sums && n_partials <= 0) || (n_partials > 0 && !partials) || C <= 0 || n <= 0 || !scale || !shift || !mean_out ||
         !rstd_out || (!running_mean != !running_var))
         return OSSID_EINVAL;
-    hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, sums,
-                       sums_row_stride > 0 ? sums_row_stride : C, partials, n_partials, C, n, gamma, beta, eps, momentum,
-                       running_mean, running_var, scale, shift, mean_out, rstd_out);
+    if (n_partials > 64)
+        hipLaunchKernelGGL(bn_fold_fwd_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, sums,
+                           sums_row_stride > 0 ? sums_row_stride : C, partials, n_partials, C, n, gamma, beta, eps, momentum,
+                           running_mean, running_var, scale, shift, mean_out, rstd_out);
+    else
+        hipLaunchKernelGGL(bn_fold_fwd_kernel<4>, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, sums,
+                           sums_row_stride > 0 ? sums_row_stride : C, partials, n_partials, C, n, gamma, beta, eps, momentum,
+                           running_mean, running_var, scale, shift, mean_out, rstd_out);
     return ossid_launch_status();
 }
 
@@ -808,8 +832,20 @@ int ossid_bn_fold_bwd(const float* dscale, const float* dshift, const float* par
     if (((!dscale || !dshift) && n_partials <= 0) || (n_partials > 0 && !partials) || !mean || !rstd || C <= 0 || n <= 0 ||
         !coef_x || !coef_1)
         return OSSID_EINVAL;
-    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, dscale, dshift, partials,
-                       n_partials, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate);
+    if (n_partials > 64)
+        hipLaunchKernelGGL(bn_fold_bwd_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, dscale, dshift,
+                           partials, n_partials, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate);
+    else
+        hipLaunchKernelGGL(bn_fold_bwd_kernel<4>, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, dscale, dshift,
+                           partials, n_partials, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate);
+    return ossid_launch_status();
+
+}
+
+int ossid_colsum_finalize(const float* partials, int n_partials, int C, float* sums, int sums_row_stride, void* stream) {
+    if (!partials || n_partials <= 0 || C <= 0 || !sums) return OSSID_EINVAL;
+    hipLaunchKernelGGL(colsum_finalize16_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, n_partials,
+                       C, sums, sums_row_stride > 0 ? sums_row_stride : C);
     return ossid_launch_status();
 }
 

@@ -18,12 +18,16 @@ autograd sees a handful of coarse Functions (FusedConv, BNFold, ColStats, AvgPoo
 logical NCHW in torch.channels_last memory format, so torch ops (losses, the few layers left on MIOpen) interoperate.
 """
 import ctypes
+import os
 
 import torch
 
 from .. import _lib
 
 _byref = ctypes.byref
+# A/B switch (measurement only): 0 = the dense block's statistics / mask / accumulate steps as separate generic passes
+_FUSE = int(os.environ.get("OSSID_FUSE_EPILOGUE", "0"))      # bit 0: forward statistics, 1: 3x3 dgrad mask, 2: 1x1 dgrad accumulate
+FUSE_STATS, FUSE_DGRAD3, FUSE_DGRAD1 = bool(_FUSE & 1), bool(_FUSE & 2), bool(_FUSE & 4)
 
 
 def _p(t):
@@ -174,7 +178,11 @@ def end_step():
 
 
 def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_relu=False, act=0, in_cs=0, out_cs=0,
-             out_coff=0, src_hw=(0, 0)):
+             out_coff=0, src_hw=(0, 0), epi=None):
+    """ossid_conv_nhwc_fwd on raw channels-last buffers. epi (training extras, include/ossid_hip.h "epilogue extras"):
+    dict(aux=, aux_cs=, alpha=, mask=(scale, shift), accumulate=, sum_mode=) -- with sum_mode the per-wave partial rows
+    land in a scratch buffer and (scratch, rows) is returned for bn_fold_fwd / bn_fold_bwd / colsum_finalize (valid until
+    the next conv with sum_mode on this stream)."""
     d = _lib.ConvDesc()
     d.x, d.wpk, d.bias, d.out = x.data_ptr(), wpk.data_ptr(), _p(bias), out.data_ptr()
     if pre is not None:
@@ -184,9 +192,30 @@ def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_rel
     d.act, d.pre_relu = int(act), 1 if pre_relu else 0
     d.src_height, d.src_width = int(src_hw[0]), int(src_hw[1])
     d.in_channel_stride, d.out_channel_stride, d.out_channel_offset = int(in_cs), int(out_cs), int(out_coff)
+    part = None
+    if epi is not None:
+        d.epi_aux, d.epi_aux_channel_stride = _p(epi.get("aux")), int(epi.get("aux_cs", 0))
+        d.epi_alpha = _p(epi.get("alpha"))
+        mask = epi.get("mask")
+        if mask is not None:
+            d.epi_mask_scale, d.epi_mask_shift, d.epi_mask_mode = mask[0].data_ptr(), mask[1].data_ptr(), 1
+        d.epi_accumulate, d.epi_sum_mode = 1 if epi.get("accumulate") else 0, int(epi.get("sum_mode", 0))
+        if d.epi_sum_mode:
+            rows = B * (H + 4) * ((W + 31) // 32) + 8      # upper bound over every tiling the dispatcher may pick
+            part = _scratch("conv_partials", rows * 2 * cout * 4, out.device)
+            d.epi_partials, d.epi_partials_rows = part.data_ptr(), rows
     with torch.cuda.device(out.device):
         _lib.check(_lib.fn("ossid_conv_nhwc_fwd")(_byref(d), _lib.stream()), "ossid_conv_nhwc_fwd")
+        if part is not None:
+            return part, int(_lib.fn("ossid_conv_last_partial_rows")())
     return out
+
+
+def colsum_finalize(partials, C, sums, sums_row_stride=0):
+    part, P = partials
+    with torch.cuda.device(part.device):
+        _lib.check(_lib.fn("ossid_colsum_finalize")(part.data_ptr(), int(P), int(C), sums.data_ptr(), int(sums_row_stride),
+                                                    _lib.stream()), "ossid_colsum_finalize")
 
 
 def wgrad_raw(x, dy, B, H, W, cin, cout, taps, dw, pre=None, pre_relu=False, in_cs=0, dy_cs=0, src_hw=(0, 0),
@@ -478,14 +507,20 @@ class DenseBlockTrain(torch.autograd.Function):
                              layer.norm1.running_var, sums_row_stride=Ct)
             mid = int(w1.shape[0])
             y1 = empty_nhwc(B, mid, H, W, dev)
-            conv_raw(buf, _pack(w1, "fwd"), B, H, W, c, mid, 1, y1, pre=(f1[0], f1[1]), pre_relu=True, in_cs=Ct)
-            s2 = chan_op(y1, N, mid, x=y1, sum_mode=1, defer=True)
+            # 1x1 with the batch statistics of its output summed in the epilogue; 3x3 likewise for the 32 new channels
+            s2 = conv_raw(buf, _pack(w1, "fwd"), B, H, W, c, mid, 1, y1, pre=(f1[0], f1[1]), pre_relu=True, in_cs=Ct,
+                          epi=dict(sum_mode=2) if FUSE_STATS else None)
+            if not FUSE_STATS:
+                s2 = chan_op(y1, N, mid, x=y1, sum_mode=1, defer=True)
             f2 = bn_fold_fwd(s2, mid, N, g2, b2, layer.norm2.eps, _mom(layer.norm2), layer.norm2.running_mean,
                              layer.norm2.running_var)
-            conv_raw(y1, _pack(w2, "fwd"), B, H, W, mid, growth, 9, buf, pre=(f2[0], f2[1]), pre_relu=True, out_cs=Ct,
-                     out_coff=c)
-            new = flat(buf, c)                                      # pointer to channel c of pixel 0
-            chan_op(new, N, growth, x=new, g_cs=Ct, x_cs=Ct, sum_mode=1, sums=table.view(-1)[c:], sums_row_stride=Ct)
+            s3 = conv_raw(y1, _pack(w2, "fwd"), B, H, W, mid, growth, 9, buf, pre=(f2[0], f2[1]), pre_relu=True, out_cs=Ct,
+                          out_coff=c, epi=dict(sum_mode=2) if FUSE_STATS else None)
+            if FUSE_STATS:
+                colsum_finalize(s3, growth, table.view(-1)[c:], sums_row_stride=Ct)
+            else:
+                new = flat(buf, c)
+                chan_op(new, N, growth, x=new, g_cs=Ct, x_cs=Ct, sum_mode=1, sums=table.view(-1)[c:], sums_row_stride=Ct)
             saved.append((f1, y1, f2))
             c += growth
         ctx.block, ctx.saved, ctx.buf, ctx.params, ctx.C0 = block, saved, buf, params, C0
@@ -503,8 +538,8 @@ class DenseBlockTrain(torch.autograd.Function):
         grads = [None] * len(params)
         mid = int(params[2].shape[0])
         dz_all = torch.empty((L, B, H, W, mid), dtype=torch.float32, device=dev)   # per layer: the 1x1 wgrad runs at the end
-        da = empty_nhwc(B, Ct, H, W, dev)          # data gradient of the 1x1: c_l <= Ct channels, written densely [N][c_l]
         deferred = []                              # the block's 2 L weight gradients: ONE grouped launch below
+        da = None
         c = C0 + L * growth
         for li in range(L - 1, -1, -1):
             c -= growth
@@ -520,9 +555,14 @@ class DenseBlockTrain(torch.autograd.Function):
             dw2 = torch.empty_like(w2)
             deferred.append(dict(x=y1, dy=gs, B=B, H=H, W=W, cin=mid, cout=growth, taps=9, dw=dw2, pre=(f2[0], f2[1]),
                                  pre_relu=True, dy_cs=Ct))
-            conv_raw(gs, _pack(w2, "dgrad"), B, H, W, growth, mid, 9, db, in_cs=Ct)
-            s = chan_op(db, N, mid, x=y1, out=db, alpha=f2[0], mask_mode=1, mask_scale=f2[0], mask_shift=f2[1], sum_mode=1,
-                        defer=True)
+            # ... with the ReLU mask of relu(bn2(y1)), the scale and the (d shift, d scale) sums in its epilogue
+            if FUSE_DGRAD3:
+                s = conv_raw(gs, _pack(w2, "dgrad"), B, H, W, growth, mid, 9, db, in_cs=Ct,
+                             epi=dict(aux=y1, alpha=f2[0], mask=(f2[0], f2[1]), sum_mode=1))
+            else:
+                conv_raw(gs, _pack(w2, "dgrad"), B, H, W, growth, mid, 9, db, in_cs=Ct)
+                s = chan_op(db, N, mid, x=y1, out=db, alpha=f2[0], mask_mode=1, mask_scale=f2[0], mask_shift=f2[1],
+                            sum_mode=1, defer=True)
             r2 = torch.empty((4, mid), dtype=torch.float32, device=dev)
             bn_fold_bwd(None, None, g2, f2[2], f2[3], mid, N, r2[0], r2[1], r2[2], r2[3], partials=s)
             chan_op(db, N, mid, x=y1, out=db, beta=r2[2], kappa=r2[3])          # dz = scale*db*mask + coef_x*y1 + coef_1
@@ -530,9 +570,17 @@ class DenseBlockTrain(torch.autograd.Function):
             dw1 = torch.empty_like(w1)
             deferred.append(dict(x=buf, dy=db, B=B, H=H, W=W, cin=c, cout=mid, taps=1, dw=dw1, pre=(f1[0], f1[1]),
                                  pre_relu=True, in_cs=Ct))
-            conv_raw(db, _pack(w1, "dgrad"), B, H, W, mid, c, 1, da)
-            s = chan_op(da, N, c, x=buf, out=G, x_cs=Ct, out_cs=Ct, alpha=f1[0], mask_mode=1, mask_scale=f1[0],
-                        mask_shift=f1[1], accumulate=True, sum_mode=1, defer=True)
+            # ... whose epilogue masks with relu(bn1(buf)), scales, ACCUMULATES onto the gradient buffer's channel prefix
+            # and sums (d shift, d scale): the c-channel data gradient itself is never written
+            if FUSE_DGRAD1:
+                s = conv_raw(db, _pack(w1, "dgrad"), B, H, W, mid, c, 1, G, out_cs=Ct,
+                             epi=dict(aux=buf, aux_cs=Ct, alpha=f1[0], mask=(f1[0], f1[1]), accumulate=True, sum_mode=1))
+            else:
+                if da is None:
+                    da = empty_nhwc(B, Ct, H, W, dev)
+                conv_raw(db, _pack(w1, "dgrad"), B, H, W, mid, c, 1, da)
+                s = chan_op(da, N, c, x=buf, out=G, x_cs=Ct, out_cs=Ct, alpha=f1[0], mask_mode=1, mask_scale=f1[0],
+                            mask_shift=f1[1], accumulate=True, sum_mode=1, defer=True)
             r1 = torch.empty((2, c), dtype=torch.float32, device=dev)
             bn_fold_bwd(None, None, g1, f1[2], f1[3], c, N, r1[0], r1[1], coef[0], coef[1], accumulate=True, partials=s)
             grads[6 * li:6 * li + 6] = [r1[0], r1[1], dw1, r2[0], r2[1], dw2]

@@ -186,11 +186,17 @@ def test_bn_relu_conv_matches_torch_autograd(hiplib):
     assert rel(bn.running_var, rbn.running_var) < 1e-5
 
 
+@pytest.mark.parametrize("fuse", [0, 7])
 @pytest.mark.parametrize("L,C0,B,H,W", [(3, 64, 2, 12, 16), (6, 64, 2, 30, 40), (4, 256, 1, 7, 9)])
-def test_dense_block_training_path_matches_module_path(hiplib, L, C0, B, H, W):
+def test_dense_block_training_path_matches_module_path(hiplib, L, C0, B, H, W, fuse, monkeypatch):
     """One resident buffer + shared batch statistics + in-place gradient accumulation vs the nn.Module dense block
     (torch.cat, one BatchNorm per layer over the whole concatenation): output, input gradient, every parameter gradient,
     every running statistic."""
+    # fuse = 7: statistics / ReLU mask / gradient accumulation inside the convolutions' epilogues (csrc/conv.hip "training
+    # extras": measured 0.3-0.9 ms SLOWER per step than the separate generic passes, so off by default, kept and tested)
+    monkeypatch.setattr(T, "FUSE_STATS", bool(fuse & 1))
+    monkeypatch.setattr(T, "FUSE_DGRAD3", bool(fuse & 2))
+    monkeypatch.setattr(T, "FUSE_DGRAD1", bool(fuse & 4))
     torch.manual_seed(2)
     blk = backbones.DenseBlock(L, C0).cuda().train()
     with torch.no_grad():
