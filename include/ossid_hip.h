@@ -336,6 +336,30 @@ int ossid_avgpool2_nhwc(const float* x, int B, int H, int W, int C, int stride, 
 int ossid_upsample_nearest_bwd_nhwc(const float* dup, int B, int Hs, int Ws, int H, int W, int C, const int32_t* row_start,
                                     const int32_t* col_start, float* dsrc, void* stream);
 
+/* D15  DetectionLoss.forward (models/dtoid/loss.py:46-175) and its gradient in three launches: focal classification
+ * loss (alpha, gamma) with IoU anchor assignment (>= 0.5 positive, < 0.4 negative, else ignored; probabilities clamped to
+ * [1e-4, 1 - 1e-4]) + smooth-L1 (beta 1/9) box regression on the positives against the encoded assigned box
+ * ((dx, dy) / 0.1, (log dw, log dh) / 0.2), per image normalised by #positives (x 4), averaged over the batch.
+ * cls [B][A][C] probabilities, reg [B][A][4], anchors [A][4], annotations [B][G][5] (x1,y1,x2,y2,label; label -1 = padding;
+ * G <= 16). fwd writes losses2 = (cls_loss, reg_loss), the un-normalised gradients dcls_raw / dreg_raw (same shapes as
+ * cls / reg) and scales2B [2][B]; bwd: dcls = grad_losses2[0] * scales[0][b] * dcls_raw, dreg likewise (grad_losses2 =
+ * the upstream gradient of the two losses, device). workspace: ossid_focal_smoothl1_loss_workspace_floats(B, A) floats.
+ * Sums are formed in a fixed order (per-block partials, one wave per image): bit-reproducible. */
+size_t ossid_focal_smoothl1_loss_workspace_floats(int B, int A);
+int ossid_focal_smoothl1_loss_fwd(const float* cls, const float* reg, const float* anchors, const float* annotations, int B,
+                                  int A, int C, int G, float alpha, float gamma, float* dcls_raw, float* dreg_raw,
+                                  float* workspace, float* losses2, float* scales2B, void* stream);
+int ossid_focal_smoothl1_loss_bwd(const float* dcls_raw, const float* dreg_raw, const float* scales2B, const float* grad_losses2,
+                                  int B, int A, int C, float* dcls, float* dreg, void* stream);
+
+/* D12  torch.topk(scores, k) (network.py:555: the 1000 best of the ~570 k (template, anchor) object scores of a frame):
+ * values [k] in decreasing order and their int64 indices; equal scores are ordered (and, at the cut, chosen) by increasing
+ * index. Radix select (three histogram passes) + ordered gather + one-workgroup sort of the k survivors; k <= 2048.
+ * NaN scores order above +inf. workspace: ossid_topk_workspace_bytes(n, k) bytes. */
+size_t ossid_topk_workspace_bytes(int n, int k);
+int ossid_topk(const float* scores, int n, int k, void* workspace, size_t workspace_bytes, float* values, long long* indices,
+               void* stream);
+
 /* D12  torchvision.ops.nms(boxes, scores, iou_threshold)      network.py:563, models/dtoid/utils.py:33
  * boxes [n][4] (x1,y1,x2,y2) ALREADY sorted by descending score (network.py:555 feeds it the top-k order);
  * keep [n] receives the indices of the survivors in that order, *num_keep their count. n <= 16384. */

@@ -102,6 +102,11 @@ _PROTOS = {
     "ossid_colsum_finalize": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "ossid_avgpool2_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "ossid_upsample_nearest_bwd_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ossid_focal_smoothl1_loss_workspace_floats": (_sz, [_i, _i]),
+    "ossid_focal_smoothl1_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ossid_focal_smoothl1_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ossid_topk_workspace_bytes": (_sz, [_i, _i]),
+    "ossid_topk": (_i, [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "ossid_nms_workspace_bytes": (_sz, [_i]),
     "ossid_nms": (_i, [_vp, _i, _f, _vp, _sz, _vp, _vp, _vp]),
     "ossid_decode_clip_boxes": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),

@@ -504,3 +504,199 @@ int ossid_amsgrad_step(float* param, const float* grad, float* exp_avg, float* e
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// D12  torch.topk(scores, k) over the ~570 k anchor scores of a frame (network.py:555) as a radix SELECT instead of a sort:
+// three 11/11/10-bit histogram passes find the exact k-th largest value T, two ordered passes gather the elements > T and
+// the lowest-index elements == T that fill up to k (positions by block-prefix sums: no atomics on the output, the result is
+// deterministic), one workgroup sorts the k survivors by (value descending, index ascending). Six small launches over
+// 2.3 MB instead of a full merge sort.
+namespace {
+
+__device__ __forceinline__ unsigned topk_key(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // unsigned order == float order (NaNs sort as largest)
+}
+
+// which bin of `hist` (nbins entries, counts of the keys under the current prefix) holds the rem-th largest key:
+// returns the bin, and through `rem` the rank that remains inside it. Every thread of the block returns the same values.
+__device__ int topk_find_bin(const int* __restrict__ hist, int nbins, int& rem, int* lds /* 257 ints */) {
+    const int t = threadIdx.x, per = nbins / 256;               // blockDim.x == 256, nbins a multiple of 256
+    int seg = 0;
+    for (int j = 0; j < per; ++j) seg += hist[nbins - 1 - (t * per + j)];      // thread t owns the t-th segment FROM THE TOP
+    lds[t] = seg;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0, found = 0;
+        for (int i = 0; i < 256; ++i) {
+            if (run + lds[i] >= rem) { found = i; break; }
+            run += lds[i];
+        }
+        lds[256] = found;
+        lds[0] = run;                                            // keys above the segment
+    }
+    __syncthreads();
+    const int segi = lds[256];
+    int run = lds[0];
+    __syncthreads();
+    int bin = nbins - 1 - segi * per;
+    for (int j = 0; j < per; ++j, --bin) {
+        const int c = hist[bin];
+        if (run + c >= rem) break;
+        run += c;
+    }
+    rem -= run;
+    return bin;
+}
+
+struct TopkState {
+    unsigned prefix, mask;      // keys of interest: (key & mask) == prefix
+    int rem;
+};
+
+__device__ TopkState topk_state(const int* __restrict__ hist, int level, int k, int* lds) {
+    TopkState s;
+    s.prefix = 0, s.mask = 0, s.rem = k;
+    if (level >= 2) {
+        const int b = topk_find_bin(hist, 2048, s.rem, lds);
+        s.prefix = (unsigned)b << 21, s.mask = 0xFFE00000u;
+    }
+    if (level >= 3) {
+        const int b = topk_find_bin(hist + 2048, 2048, s.rem, lds);
+        s.prefix |= (unsigned)b << 10, s.mask = 0xFFFFFC00u;
+    }
+    if (level >= 4) {
+        const int b = topk_find_bin(hist + 4096, 1024, s.rem, lds);
+        s.prefix |= (unsigned)b, s.mask = 0xFFFFFFFFu;
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict__ x, int n, int level, int k, int* __restrict__ hist) {
+    __shared__ int lh[2048];
+    __shared__ int scratch[257];
+    const TopkState s = topk_state(hist, level, k, scratch);
+    for (int i = threadIdx.x; i < 2048; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int shift = level == 1 ? 21 : (level == 2 ? 10 : 0), bmask = level == 3 ? 1023 : 2047;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const unsigned key = topk_key(x[i]);
+        if ((key & s.mask) == s.prefix) atomicAdd(&lh[(key >> shift) & bmask], 1);
+    }
+    __syncthreads();
+    int* out = hist + (level - 1) * 2048;
+    for (int i = threadIdx.x; i < 2048; i += 256)
+        if (lh[i]) atomicAdd(&out[i], lh[i]);
+}
+
+// pass 1 (write == 0): per-block counts of (key > T, key == T) over the block's CONTIGUOUS chunk -> counts[block][2].
+// pass 2 (write == 1): positions from the counts of the blocks before; greater elements first (k_gt of them), then ties.
+__global__ __launch_bounds__(256) void topk_gather_kernel(const float* __restrict__ x, int n, int k, const int* __restrict__ hist,
+                                                          int* __restrict__ counts, int write, float* __restrict__ sel_val,
+                                                          int* __restrict__ sel_idx) {
+    __shared__ int scratch[257];
+    __shared__ int wsum[4][2];
+    const TopkState s = topk_state(hist, 4, k, scratch);
+    const unsigned T = s.prefix;
+    const int need_ties = s.rem, k_gt = k - need_ties;
+    const int chunk = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    int base_gt = 0, base_eq = 0;
+    if (write) {
+        for (int bq = threadIdx.x; bq < (int)blockIdx.x; bq += 256) base_gt += counts[2 * bq], base_eq += counts[2 * bq + 1];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) base_gt += __shfl_xor(base_gt, m), base_eq += __shfl_xor(base_eq, m);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6][0] = base_gt, wsum[threadIdx.x >> 6][1] = base_eq;
+        __syncthreads();
+        base_gt = wsum[0][0] + wsum[1][0] + wsum[2][0] + wsum[3][0];
+        base_eq = wsum[0][1] + wsum[1][1] + wsum[2][1] + wsum[3][1];
+        __syncthreads();
+    }
+    int run_gt = 0, run_eq = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i0 = lo; i0 < hi; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        const bool in = i < hi;
+        const float v = in ? x[i] : 0.0f;
+        const unsigned key = topk_key(v);
+        const bool gt = in && key > T, eq = in && key == T;
+        const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+        if (lane == 0) wsum[wave][0] = __popcll(mg), wsum[wave][1] = __popcll(me);
+        __syncthreads();
+        int pre_gt = 0, pre_eq = 0, tot_gt = 0, tot_eq = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) pre_gt += wsum[w][0], pre_eq += wsum[w][1];
+            tot_gt += wsum[w][0], tot_eq += wsum[w][1];
+        }
+        if (write) {
+            const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+            if (gt) {
+                const int pos = base_gt + run_gt + pre_gt + __popcll(mg & below);
+                sel_val[pos] = v, sel_idx[pos] = i;
+            } else if (eq) {
+                const int rank = base_eq + run_eq + pre_eq + __popcll(me & below);       // index order
+                if (rank < need_ties) sel_val[k_gt + rank] = v, sel_idx[k_gt + rank] = i;
+            }
+        }
+        run_gt += tot_gt, run_eq += tot_eq;
+        __syncthreads();
+    }
+    if (!write && threadIdx.x == 0) counts[2 * blockIdx.x] = run_gt, counts[2 * blockIdx.x + 1] = run_eq;
+}
+
+// one workgroup: bitonic sort of the k (<= 2048) selected (value, index) pairs, value descending, index ascending
+__global__ __launch_bounds__(1024) void topk_sort_kernel(const float* __restrict__ sel_val, const int* __restrict__ sel_idx, int k,
+                                                         float* __restrict__ out_val, long long* __restrict__ out_idx) {
+    __shared__ unsigned long long keys[2048];
+    for (int i = threadIdx.x; i < 2048; i += 1024)
+        keys[i] = i < k ? (((unsigned long long)topk_key(sel_val[i]) << 32) | (unsigned)(~sel_idx[i])) : 0ull;
+    __syncthreads();
+    for (int size = 2; size <= 2048; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int t = threadIdx.x;                      // 1024 compare-exchange pairs per step
+            const int i = ((t / stride) * stride * 2) + (t % stride), j = i + stride;
+            const bool desc = ((i & size) == 0);
+            const unsigned long long a = keys[i], b = keys[j];
+            if ((a < b) == desc) keys[i] = b, keys[j] = a;
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < k; i += 1024) {
+        const unsigned long long kk = keys[i];
+        const unsigned hi = (unsigned)(kk >> 32);
+        const unsigned u = (hi & 0x80000000u) ? (hi & 0x7FFFFFFFu) : ~hi;
+        out_val[i] = __uint_as_float(u);
+        out_idx[i] = (long long)(~(unsigned)(kk & 0xFFFFFFFFu));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ossid_topk_workspace_bytes(int n, int k) {
+    (void)n;
+    // histograms (3 levels) + per-block counts (512 blocks x 2) + selected values / indices
+    return (size_t)(3 * 2048 + 2 * 512) * sizeof(int) + (size_t)k * (sizeof(float) + sizeof(int)) + 64;
+}
+
+int ossid_topk(const float* scores, int n, int k, void* workspace, size_t workspace_bytes, float* values, long long* indices,
+               void* stream) {
+    if (!scores || !workspace || !values || !indices || n <= 0 || k <= 0 || k > n || k > 2048) return OSSID_EINVAL;
+    if (workspace_bytes < ossid_topk_workspace_bytes(n, k)) return OSSID_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int* hist = (int*)workspace;
+    int* counts = hist + 3 * 2048;
+    float* sel_val = (float*)(counts + 2 * 512);
+    int* sel_idx = (int*)(sel_val + k);
+    if (hipMemsetAsync(hist, 0, 3 * 2048 * sizeof(int), s) != hipSuccess) return OSSID_ELAUNCH;
+    int blocks = (n + 2047) / 2048;
+    if (blocks > 512) blocks = 512;
+    for (int level = 1; level <= 3; ++level)
+        hipLaunchKernelGGL(topk_hist_kernel, dim3(blocks), dim3(256), 0, s, scores, n, level, k, hist);
+    hipLaunchKernelGGL(topk_gather_kernel, dim3(blocks), dim3(256), 0, s, scores, n, k, (const int*)hist, counts, 0, sel_val, sel_idx);
+    hipLaunchKernelGGL(topk_gather_kernel, dim3(blocks), dim3(256), 0, s, scores, n, k, (const int*)hist, counts, 1, sel_val, sel_idx);
+    hipLaunchKernelGGL(topk_sort_kernel, dim3(1), dim3(1024), 0, s, (const float*)sel_val, (const int*)sel_idx, k, values, indices);
+    return ossid_launch_status();
+}
+
+}  // extern "C"

@@ -1058,3 +1058,180 @@ int ossid_conv_wgrad_group(const ossid_wgrad_desc* descs, int n, void* workspace
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// D15  DetectionLoss (models/dtoid/loss.py:46-175): focal classification loss with IoU anchor assignment + smooth-L1 box
+// regression, forward and the gradients with respect to both network outputs in one pass over the anchors.
+//   per image b: valid annotations = rows with label != -1; IoU of every anchor with every valid annotation (calc_iou,
+//   loss.py:10-37, union clamped at 1e-8); max / first argmax; positive: IoU >= 0.5, negative: IoU < 0.4, in between ignored;
+//   p = clamp(prob, 1e-4, 1 - 1e-4); target 1 for the assigned annotation's class of a positive anchor, 0 for the other
+//   classes of positives and for all classes of negatives: L = alpha (1-p)^gamma (-log p) | (1-alpha) p^gamma (-log(1-p));
+//   sum / max(#positives, 1)  (an image without annotation: every anchor negative, sum not divided, loss.py:78-93);
+//   smooth-L1 (beta 1/9) on the positives between reg and the encoded box ((dx, dy)/0.1, (log dw, log dh)/0.2, widths
+//   clamped at 1), mean over #positives x 4; both losses are then averaged over the batch.
+// Kernel 1 writes UN-normalised gradients and per-block partial sums; kernel 2 (one wave per image) adds the partials
+// in a fixed order, writes the two losses and the per-image normalisers; the backward kernel scales the stored gradients.
+namespace {
+
+constexpr int LOSS_MAXG = 16;
+
+__global__ __launch_bounds__(256) void det_loss_fwd_kernel(const float* __restrict__ cls, const float* __restrict__ reg,
+                                                           const float4* __restrict__ anchors, const float* __restrict__ ann,
+                                                           int A, int C, int G, float alpha, float gamma,
+                                                           float* __restrict__ dcls_raw, float* __restrict__ dreg_raw,
+                                                           float* __restrict__ partials) {
+    __shared__ float sg[LOSS_MAXG][5];
+    __shared__ float red[4][3];
+    const int b = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < G * 5) sg[threadIdx.x / 5][threadIdx.x % 5] = ann[((size_t)b * G) * 5 + threadIdx.x];
+    __syncthreads();
+    float s_cls = 0.0f, s_reg = 0.0f, s_pos = 0.0f;
+    if (a < A) {
+        const float4 an = anchors[a];
+        const float aw = an.z - an.x, ah = an.w - an.y, area_a = aw * ah;
+        float best = -1.0f;
+        int arg = -1;
+        for (int g = 0; g < G; ++g) {
+            if (sg[g][4] == -1.0f) continue;
+            float iw = fminf(an.z, sg[g][2]) - fmaxf(an.x, sg[g][0]), ih = fminf(an.w, sg[g][3]) - fmaxf(an.y, sg[g][1]);
+            iw = fmaxf(iw, 0.0f), ih = fmaxf(ih, 0.0f);
+            const float inter = iw * ih;
+            const float ua = fmaxf(area_a + (sg[g][2] - sg[g][0]) * (sg[g][3] - sg[g][1]) - inter, 1e-8f);
+            const float iou = inter / ua;
+            if (iou > best) best = iou, arg = g;
+        }
+        const bool has_gt = arg >= 0;
+        const bool positive = has_gt && best >= 0.5f;
+        const bool negative = !has_gt || best < 0.4f;
+        const int label = positive ? (int)sg[arg][4] : -1;
+        const float* pc = cls + ((size_t)b * A + a) * C;
+        float* gc = dcls_raw + ((size_t)b * A + a) * C;
+        for (int k = 0; k < C; ++k) {
+            const float praw = pc[k];
+            const float p = fminf(fmaxf(praw, 1e-4f), 1.0f - 1e-4f);
+            const float pass = (praw >= 1e-4f && praw <= 1.0f - 1e-4f) ? 1.0f : 0.0f;     // clamp's gradient
+            float L = 0.0f, dL = 0.0f;
+            if (positive && k == label) {
+                const float q = 1.0f - p, lg = logf(p), w = powf(q, gamma);
+                L = -alpha * w * lg;
+                dL = alpha * (gamma * powf(q, gamma - 1.0f) * lg - w / p);
+            } else if (positive || negative) {
+                const float lg = logf(1.0f - p), w = powf(p, gamma);
+                L = -(1.0f - alpha) * w * lg;
+                dL = (1.0f - alpha) * (-gamma * powf(p, gamma - 1.0f) * lg + w / (1.0f - p));
+            }
+            s_cls += L;
+            gc[k] = dL * pass;
+        }
+        float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (positive) {
+            s_pos = 1.0f;
+            const float acx = an.x + 0.5f * aw, acy = an.y + 0.5f * ah;
+            float gw = sg[arg][2] - sg[arg][0], gh = sg[arg][3] - sg[arg][1];
+            const float gcx = sg[arg][0] + 0.5f * gw, gcy = sg[arg][1] + 0.5f * gh;
+            gw = fmaxf(gw, 1.0f), gh = fmaxf(gh, 1.0f);
+            const float t[4] = {(gcx - acx) / aw / 0.1f, (gcy - acy) / ah / 0.1f, logf(gw / aw) / 0.2f, logf(gh / ah) / 0.2f};
+            const float4 r4 = *(const float4*)(reg + ((size_t)b * A + a) * 4);
+            const float r[4] = {r4.x, r4.y, r4.z, r4.w};
+            float g4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float diff = t[k] - r[k], d = fabsf(diff);
+                const bool quad = d <= 1.0f / 9.0f;
+                s_reg += quad ? 0.5f * 9.0f * d * d : d - 0.5f / 9.0f;
+                const float sgn = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
+                g4[k] = -sgn * (quad ? 9.0f * d : 1.0f);
+            }
+            gr = make_float4(g4[0], g4[1], g4[2], g4[3]);
+        }
+        *(float4*)(dreg_raw + ((size_t)b * A + a) * 4) = gr;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s_cls += __shfl_xor(s_cls, m);
+        s_reg += __shfl_xor(s_reg, m);
+        s_pos += __shfl_xor(s_pos, m);
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][0] = s_cls, red[threadIdx.x >> 6][1] = s_reg, red[threadIdx.x >> 6][2] = s_pos;
+    __syncthreads();
+    if (threadIdx.x < 3)
+        partials[((size_t)b * gridDim.x + blockIdx.x) * 3 + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// one wave per image: partial sums in a fixed order (lane-strided, then a fixed butterfly); wave 0 lane 0 of the LAST
+// step is replaced by a second launch-free trick: the batch means are formed by block 0 after a grid of B waves has
+// written the per-image values -- here simply ONE block handles all images (B <= 1024 / 64 waves at a time, looped).
+__global__ __launch_bounds__(64) void det_loss_finalize_kernel(const float* __restrict__ partials, const float* __restrict__ ann,
+                                                               int B, int G, int nblk, float* __restrict__ losses,
+                                                               float* __restrict__ scales) {
+    double tot_cls = 0.0, tot_reg = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double s[3] = {0.0, 0.0, 0.0};
+        for (int i = threadIdx.x; i < nblk; i += 64)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s[k] += (double)partials[((size_t)b * nblk + i) * 3 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) s[k] += __shfl_xor(s[k], m);
+        bool has_gt = false;
+        for (int g = 0; g < G; ++g) has_gt |= ann[((size_t)b * G + g) * 5 + 4] != -1.0f;
+        const double ncls = has_gt ? fmax(s[2], 1.0) : 1.0;
+        const double nreg = s[2] > 0.0 ? 4.0 * s[2] : 1.0;
+        tot_cls += s[0] / ncls;
+        tot_reg += s[2] > 0.0 ? s[1] / nreg : 0.0;
+        if (threadIdx.x == 0) {
+            scales[b] = (float)(1.0 / (ncls * B));
+            scales[B + b] = (float)(s[2] > 0.0 ? 1.0 / (nreg * B) : 0.0);
+        }
+    }
+    if (threadIdx.x == 0) losses[0] = (float)(tot_cls / B), losses[1] = (float)(tot_reg / B);
+}
+
+__global__ __launch_bounds__(256) void det_loss_bwd_kernel(const float* __restrict__ dcls_raw, const float* __restrict__ dreg_raw,
+                                                           const float* __restrict__ scales, const float* __restrict__ gout,
+                                                           int B, int A, int C, float* __restrict__ dcls,
+                                                           float* __restrict__ dreg) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)B * A;
+    if (i >= n) return;
+    const int b = (int)(i / A);
+    const float sc = gout[0] * scales[b], sr = gout[1] * scales[B + b];
+    for (int k = 0; k < C; ++k) dcls[i * C + k] = sc * dcls_raw[i * C + k];
+    const float4 g = *(const float4*)(dreg_raw + i * 4);
+    *(float4*)(dreg + i * 4) = make_float4(sr * g.x, sr * g.y, sr * g.z, sr * g.w);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ossid_focal_smoothl1_loss_workspace_floats(int B, int A) {
+    return B > 0 && A > 0 ? (size_t)B * ((A + 255) / 256) * 3 : 0;
+}
+
+int ossid_focal_smoothl1_loss_fwd(const float* cls, const float* reg, const float* anchors, const float* annotations, int B,
+                                  int A, int C, int G, float alpha, float gamma, float* dcls_raw, float* dreg_raw,
+                                  float* workspace, float* losses2, float* scales2B, void* stream) {
+    if (!cls || !reg || !anchors || !annotations || !dcls_raw || !dreg_raw || !workspace || !losses2 || !scales2B) return OSSID_EINVAL;
+    if (B <= 0 || B > 65535 || A <= 0 || C <= 0 || C > 64 || G <= 0 || G > LOSS_MAXG) return OSSID_EINVAL;
+    const int nblk = (A + 255) / 256;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(det_loss_fwd_kernel, dim3(nblk, B), dim3(256), 0, s, cls, reg, (const float4*)anchors, annotations, A, C, G,
+                       alpha, gamma, dcls_raw, dreg_raw, workspace);
+    hipLaunchKernelGGL(det_loss_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, annotations, B, G, nblk,
+                       losses2, scales2B);
+    return ossid_launch_status();
+}
+
+int ossid_focal_smoothl1_loss_bwd(const float* dcls_raw, const float* dreg_raw, const float* scales2B, const float* grad_losses2,
+                                  int B, int A, int C, float* dcls, float* dreg, void* stream) {
+    if (!dcls_raw || !dreg_raw || !scales2B || !grad_losses2 || !dcls || !dreg || B <= 0 || A <= 0 || C <= 0) return OSSID_EINVAL;
+    const size_t n = (size_t)B * A;
+    hipLaunchKernelGGL(det_loss_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dcls_raw,
+                       dreg_raw, scales2B, grad_losses2, B, A, C, dcls, dreg);
+    return ossid_launch_status();
+}
+
+}  // extern "C"

@@ -7,6 +7,42 @@ arithmetic as whole-batch tensor expressions, so the loss stays on the device an
 import torch
 import torch.nn as nn
 
+from .. import _lib
+
+
+class _FusedDetectionLoss(torch.autograd.Function):
+    """ossid_focal_smoothl1_loss_{fwd,bwd}: the whole of DetectionLoss.forward and its gradient as three launches."""
+
+    @staticmethod
+    def forward(ctx, cls, reg, anchors, ann, alpha, gamma):
+        B, A, C = cls.shape
+        G = int(ann.shape[1])
+        cls, reg = cls.float().contiguous(), reg.float().contiguous()
+        anc, ann = anchors.reshape(-1, 4).float().contiguous(), ann.float().contiguous()
+        dev = cls.device
+        dcls, dreg = torch.empty_like(cls), torch.empty_like(reg)
+        ws = torch.empty(_lib.fn("ossid_focal_smoothl1_loss_workspace_floats")(B, A), dtype=torch.float32, device=dev)
+        losses, scales = torch.empty(2, dtype=torch.float32, device=dev), torch.empty(2 * B, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.fn("ossid_focal_smoothl1_loss_fwd")(cls.data_ptr(), reg.data_ptr(), anc.data_ptr(), ann.data_ptr(), B, A, C, G,
+                                                          float(alpha), float(gamma), dcls.data_ptr(), dreg.data_ptr(),
+                                                          ws.data_ptr(), losses.data_ptr(), scales.data_ptr(), _lib.stream())
+        _lib.check(rc, "ossid_focal_smoothl1_loss_fwd")
+        ctx.save_for_backward(dcls, dreg, scales)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        dcls_raw, dreg_raw, scales = ctx.saved_tensors
+        B, A, C = dcls_raw.shape
+        g = g.float().contiguous()
+        dcls, dreg = torch.empty_like(dcls_raw), torch.empty_like(dreg_raw)
+        with torch.cuda.device(g.device):
+            rc = _lib.fn("ossid_focal_smoothl1_loss_bwd")(dcls_raw.data_ptr(), dreg_raw.data_ptr(), scales.data_ptr(), g.data_ptr(),
+                                                          B, A, C, dcls.data_ptr(), dreg.data_ptr(), _lib.stream())
+        _lib.check(rc, "ossid_focal_smoothl1_loss_bwd")
+        return dcls, dreg, None, None, None, None
+
 
 def calc_iou(a, b):
     """pair-wise IoU of boxes a [n1,4] and b [n2,4] -> [n1,n2]"""
@@ -19,6 +55,8 @@ def calc_iou(a, b):
 
 
 class DetectionLoss(nn.Module):
+    use_fused = True     # on the GPU: csrc/train.hip's fused kernels; False = the tensor expressions below
+
     def __init__(self, alpha=0.25, gamma=2.0):
         super().__init__()
         self.alpha, self.gamma = alpha, gamma
@@ -29,6 +67,9 @@ class DetectionLoss(nn.Module):
         alpha, gamma = self.alpha, self.gamma
         B, A, C = classifications.shape
         dev = classifications.device
+        if classifications.is_cuda and self.use_fused and annotations.shape[1] <= 16 and C <= 64:
+            losses = _FusedDetectionLoss.apply(classifications, regressions, anchors, annotations.to(dev), alpha, gamma)
+            return losses[0:1], losses[1:2]
         annotations = annotations.to(dev)
         anchor = anchors[0]
         aw, ah = anchor[:, 2] - anchor[:, 0], anchor[:, 3] - anchor[:, 1]

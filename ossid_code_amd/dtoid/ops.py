@@ -100,9 +100,20 @@ def nms(boxes, scores, iou_threshold, sorted_desc=False):
 
 def topk_scores(scores, k):
     """(values, indices) of the k largest entries of a 1-D score vector, in decreasing order (network.py:555,
-    `torch.topk(classifications, 1000, dim=1)` on the object column). Ties between equal scores resolve to the lower
-    index."""
-    return torch.topk(scores, k)
+    `torch.topk(classifications, 1000, dim=1)` on the object column). Equal scores are ordered, and at the cut chosen,
+    by increasing index. On the GPU: ossid_topk (radix select + sort of the k survivors); k > 2048 or CPU: torch."""
+    n = int(scores.shape[0])
+    if not scores.is_cuda or k > 2048 or k <= 0:
+        return torch.topk(scores, k)
+    s = scores.float().contiguous()
+    vals = torch.empty(k, dtype=torch.float32, device=s.device)
+    idx = torch.empty(k, dtype=torch.int64, device=s.device)
+    nbytes = _lib.fn("ossid_topk_workspace_bytes")(n, k)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=s.device)
+    with torch.cuda.device(s.device):
+        _lib.check(_lib.fn("ossid_topk")(s.data_ptr(), n, k, ws.data_ptr(), nbytes, vals.data_ptr(), idx.data_ptr(),
+                                         _lib.stream()), "ossid_topk")
+    return vals, idx
 
 
 def gather_rows(src, idx, sigmoid=False):

@@ -750,3 +750,62 @@ def test_hip_training_path_matches_module_path_whole_network(hiplib):
     assert err < max(3e-2, 3 * floor), (err, floor)
     for (n, b), q in zip(m.named_buffers(), ref.buffers()):
         assert (rel(b, q) < 2e-4) if b.dtype.is_floating_point else torch.equal(b, q), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,kind", [(570024, 1000, "sigmoid"), (27144, 1000, "randn"), (5000, 1, "randn"), (1000, 1000, "randn"),
+                                      (570024, 1000, "all_equal"), (100000, 500, "ties"), (70000, 2048, "negative"), (3, 2, "randn")])
+def test_topk_radix_select_matches_torch(hiplib, n, k, kind):
+    """ossid_topk through the C ABI vs torch.topk: same values; same indices wherever the value is unique; equal values are
+    ordered -- and at the cut chosen -- by increasing index (zero-initialised output layers give 570 k identical scores)."""
+    g = torch.Generator().manual_seed(n + k)
+    if kind == "sigmoid":
+        x = torch.sigmoid(torch.randn(n, generator=g) * 3)
+    elif kind == "all_equal":
+        x = torch.full((n,), 0.01)
+    elif kind == "ties":
+        x = torch.randint(0, 50, (n,), generator=g).float() / 50
+    elif kind == "negative":
+        x = -torch.rand(n, generator=g) * 1e-3 - 1.0
+    else:
+        x = torch.randn(n, generator=g)
+    xd = x.cuda()
+    vals, idx = ops.topk_scores(xd, k)
+    rv, ri = torch.topk(x, k)
+    assert idx.dtype == torch.int64 and torch.equal(vals.cpu(), rv)
+    assert torch.equal(x[idx.cpu()], rv)                                   # the indices point at those values
+    assert idx.unique().numel() == k                                        # no element twice
+    # the deterministic rule: among equal values increasing index, and the cut takes the lowest indices
+    want = torch.sort(-x, stable=True).indices[:k]
+    assert torch.equal(idx.cpu(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["one_box", "no_box", "two_boxes_and_padding", "saturated_probabilities"])
+def test_fused_detection_loss_matches_tensor_expressions(hiplib, case):
+    """ossid_focal_smoothl1_loss_{fwd,bwd} (three launches) vs the whole-batch tensor form of dtoid/loss.py (itself
+    pinned on the reference's DetectionLoss through the golden file): both losses and both gradients."""
+    g = torch.Generator().manual_seed(len(case))
+    B, A = 3, 27144
+    anchors = dtoid.Anchors(pyramid_levels=[4], ratios=[0.5, 1, 2], sizes=[30], scales=[1, 2, 3, 4, 5, 6, 7, 8])([(29, 39)], device="cuda")
+    cls = torch.rand(B, A, 2, generator=g).cuda()
+    if case == "saturated_probabilities":
+        cls = (cls * 1.2 - 0.1).clamp(0, 1)                               # values at / beyond the 1e-4 clamps
+    reg = (torch.randn(B, A, 4, generator=g) * 0.3).cuda()
+    ann = torch.tensor([[[160.0, 120.0, 320.0, 240.0, 1.0], [-1.0] * 5], [[300.0, 200.0, 420.0, 330.0, 1.0], [-1.0] * 5],
+                        [[50.0, 60.0, 200.0, 300.0, 0.0], [-1.0] * 5]]).cuda()
+    if case == "no_box":
+        ann[1, 0] = -1.0
+    if case == "two_boxes_and_padding":
+        ann[0, 1] = torch.tensor([400.0, 100.0, 600.0, 400.0, 1.0])
+    res = {}
+    for fused in (True, False):
+        c, r = cls.clone().requires_grad_(True), reg.clone().requires_grad_(True)
+        lossf = dtoid.DetectionLoss()
+        lossf.use_fused = fused
+        lc, lr = lossf(c, r, anchors, ann)
+        (1.7 * lc + 0.6 * lr).sum().backward()
+        res[fused] = (lc.detach(), lr.detach(), c.grad, r.grad)
+    for a, b, name in zip(res[True], res[False], ("loss_cls", "loss_reg", "dcls", "dreg")):
+        scale = float(b.abs().max().clamp(min=1e-12))
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (case, name)
