@@ -189,16 +189,21 @@ def dtoid_leg(a, dev, dist, world):
              "heatmap": torch.rand(B, 1, 29, 39, generator=g).double(), "mask": mask}
     batch = {k: v.to(dev) for k, v in batch.items()}
     m.train()
+    from ossid_code_amd.dtoid.network import Network
+    use_graph = Network.use_graph       # off under a rocprofiler tool (network.py): the profile then shows the eager launches
     t_ft_eager = timed(lambda: finetune.finetune_step(m, batch, opt, sync), 2, 4)
-    graphed = finetune.GraphedForwardBackward(m, flat, batch)
-    t_ft = timed(lambda: finetune.finetune_step(m, batch, opt, sync, graphed=graphed), 2, 6)
-    del graphed
-    from ossid_code_amd.dtoid import ops as dops
-    dops.set_train_conv_impl("hip")      # the head's 3x3 convs (fwd, dgrad, wgrad) on csrc/conv.hip instead of MIOpen
+    if use_graph:
+        graphed = finetune.GraphedForwardBackward(m, flat, batch)
+        t_ft = timed(lambda: finetune.finetune_step(m, batch, opt, sync, graphed=graphed), 2, 6)
+        del graphed
+    else:
+        t_ft = t_ft_eager
+    # the nn.Module path (MIOpen convolutions / BatchNorm, torch elementwise) on the same batch, for comparison
+    m.model.use_hip_training = False
     try:
-        t_ft_hip = timed(lambda: finetune.finetune_step(m, batch, opt, sync), 2, 4)
+        t_ft_module = timed(lambda: finetune.finetune_step(m, batch, opt, sync), 2, 3)
     finally:
-        dops.set_train_conv_impl("miopen")
+        m.model.use_hip_training = True
     nominal, executed = dtoid_flops(nt)
     note = ("nominal = the reference's forward (39.7 + 45.96 n_t GFLOP) over the whole call incl. top-k / NMS / host "
             "latency; executed = what the build's kernels do after the exact reassociations (DESIGN.md 5, "
@@ -230,11 +235,21 @@ def dtoid_leg(a, dev, dist, world):
                               "roofline": roof(pair_flops, pair_flops - pair_saved, t_pairs)},
             "finetune": {"metric": "DTOID finetune samples/sec", "value": world * B / t_ft, "unit": "sample/s",
                          "ms_per_step": 1e3 * t_ft, "ms_per_step_eager": 1e3 * t_ft_eager,
-                         "ms_per_step_head_convs_hand_written": 1e3 * t_ft_hip, "global_batch": world * B,
-                         "config": "DtoidNet.forward + 4-term loss + backward (hipGraph replay) + fused AMSGrad, batch %d per GPU, BatchNorm "
-                                   "in train mode per rank, gradient mean over %d rank(s)%s" %
-                                   (B, world, " (RCCL all-reduce of the flat 136 MB buffer)" if world > 1 else ""),
-                         "tflops": world * B * 258e9 / t_ft / 1e12}}
+                         "ms_per_step_module_path_miopen": 1e3 * t_ft_module, "global_batch": world * B,
+                         "config": "DtoidNet.forward + 4-term loss + backward + fused AMSGrad on the hand-written training "
+                                   "kernels (channels-last; csrc/conv.hip fwd/dgrad, csrc/train.hip wgrad / BatchNorm fold / "
+                                   "generic passes / fused loss)%s, batch %d per GPU, BatchNorm batch statistics per rank, "
+                                   "gradient mean over %d rank(s)%s" %
+                                   (", hipGraph replay" if use_graph else "", B, world,
+                                    " (RCCL all-reduce of the flat 136 MB buffer)" if world > 1 else ""),
+                         "tflops": world * B * 258e9 / t_ft / 1e12,
+                         "roofline": {"bound": "mfma", "achieved": B * 258e9 / t_ft / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": B * 258e9 / t_ft / 1e12 / PEAK_F32_MATRIX_TFLOPS,
+                                      "note": "nominal 258 GFLOP per sample (3 x the 86 GFLOP forward, SURVEY.md 8d) over the "
+                                              "whole step incl. losses, optimizer and the layers still on torch (stem, "
+                                              "template encoders); per-layer fwd / dgrad / wgrad rates in "
+                                              "profiles/r02_train_layers.txt, per-kernel step time in "
+                                              "profiles/r02_finetune_step_kernels.txt"}}}
 
 
 def resolve_world(a, environ=None, spawn=None):

@@ -674,147 +674,28 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
 }  // extern "C"
 
 // =====================================================================================================================
-// Weight gradient of the 3x3 / stride 1 / pad 1 convolution (the finetune step, online_learning.py:670-672):
-//   dW[co][ci][ky][kx] = sum_{b,y,x} dY[b][y][x][co] * X[b][y+ky-1][x+kx-1][ci]
-// A GEMM with the PIXELS on K: v_mfma_f32_32x32x2_f32 with A = dY^T (rows = output channels, k = two consecutive pixels of
-// an image row, one per lane half) and B = X shifted by the tap (cols = input channels). Both operands are read straight
-// from the channels-last tensors: for a fixed pixel the 32 lanes of a half read 32 consecutive channels (128 B).
-// One WAVE owns 2 channel tiles x 2 input-channel tiles x one kernel row (3 taps) = 12 accumulator tiles, and a slice of
-// the image rows (split-K over rows); partial results go to slabs [split][Cout][Cin][3][3] that a second kernel sums in
-// a fixed order -- no float atomics, bit-reproducible gradients.
-namespace {
-
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                               float* __restrict__ slabs, int B, int H, int W, int Cin,
-                                                               int Cout, int in_cs, int dy_cs, int nsplit, int ci_pairs,
-                                                               int tiles_total) {
-    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);              // wave = (tile-set, split)
-    const int tile = wid / nsplit, split = wid - tile * nsplit;
-    if (tile >= tiles_total) return;
-    const int ky = tile % 3, cip = (tile / 3) % ci_pairs, cop = tile / (3 * ci_pairs);
-    const int co0 = cop * 64, ci0 = cip * 64;
-    const bool a_ok[2] = {co0 + c < Cout, co0 + 32 + c < Cout};
-    const bool b_ok[2] = {ci0 + c < Cin, ci0 + 32 + c < Cin};
-    v16f acc[2][2][3];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][k][r] = 0.0f;
-    const int rows = B * H;
-    for (int row = split; row < rows; row += nsplit) {
-        const int y = row % H;
-        const int ys = y + ky - 1;                                      // input row of this kernel row
-        if (ys < 0 || ys >= H) continue;                                // wave-uniform
-        const float* dyr = dy + (size_t)row * W * dy_cs + co0 + c;
-        const float* xr = x + (size_t)(row + ky - 1) * W * in_cs + ci0 + c;
-        // two-deep software pipeline over the pixel pairs of the row: the operands of step x0+2 are in flight while the
-        // twelve MFMAs of step x0 run
-        float a[2], bv[2][3], an[2], bn[2][3];
-        auto fetch = [&](int x0, float(&aa)[2], float(&bb)[2][3]) {
-            const int xp = x0 + h;                                      // this lane half's pixel
-            const bool pin = xp < W;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) aa[m] = (pin && a_ok[m]) ? dyr[(size_t)xp * dy_cs + 32 * m] : 0.0f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int xs = xp + k - 1;
-                const bool ok = pin && xs >= 0 && xs < W;
-#pragma unroll
-                for (int n = 0; n < 2; ++n) bb[n][k] = (ok && b_ok[n]) ? xr[(size_t)xs * in_cs + 32 * n] : 0.0f;
-            }
-        };
-        fetch(0, a, bv);
-        for (int x0 = 0; x0 < W; x0 += 2) {
-            fetch(x0 + 2, an, bn);                                      // x0+2 >= W: all lanes masked, loads nothing
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) acc[m][n][k] = mfma(a[m], bv[n][k], acc[m][n][k]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) a[m] = an[m];
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) bv[n][k] = bn[n][k];
-        }
-    }
-    // rows of an accumulator tile = output channels (registers), columns = input channels (lanes)
-    float* slab = slabs + (size_t)split * Cout * Cin * 9;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int ci = ci0 + 32 * n + c;
-            if (ci >= Cin) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (co >= Cout) continue;
-                float* o = slab + ((size_t)co * Cin + ci) * 9 + ky * 3;
-                o[0] = acc[m][n][0][r];
-                o[1] = acc[m][n][1][r];
-                o[2] = acc[m][n][2][r];
-            }
-        }
-}
-
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, size_t n,
-                                                           float* __restrict__ dw, int accumulate) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = accumulate ? dw[i] : 0.0f;
-    for (int k = 0; k < nsplit; ++k) s += slabs[(size_t)k * n + i];
-    dw[i] = s;
-}
-
-}  // namespace
-
+// Round-1 entry points of the 3x3 weight gradient, kept for ABI stability: thin wrappers around ossid_conv_wgrad
+// (csrc/train.hip: LDS-staged MFMA kernel, deterministic split-K).
 extern "C" {
 
 int ossid_conv3x3_wgrad_splits(int B, int H, int W, int Cin, int Cout) {
-    (void)W;
-    const long tiles = (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * 3;
-    // as many row-splits as keep ALL waves resident at once (two per SIMD on 256 CUs = 2048): a second, partly filled
-    // round of waves would double the run time
-    long want = 2048 / tiles;
-    const long rows = (long)B * H;
-    if (want > rows) want = rows;
-    if (want < 1) want = 1;
-    return (int)want;
+    const size_t per = (size_t)Cout * Cin * 9 * sizeof(float);
+    const size_t bytes = ossid_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, 9);
+    return per ? (int)(bytes / per) : 0;
 }
 
 size_t ossid_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
-    return (size_t)ossid_conv3x3_wgrad_splits(B, H, W, Cin, Cout) * Cout * Cin * 9 * sizeof(float);
+    return ossid_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, 9);
 }
 
 int ossid_conv3x3_wgrad(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int in_channel_stride,
                         int dy_channel_stride, void* workspace, size_t workspace_bytes, float* dw, int accumulate,
                         void* stream) {
-    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return OSSID_EINVAL;
-    if (!x || !dy || !dw || !workspace) return OSSID_EINVAL;
-    const int nsplit = ossid_conv3x3_wgrad_splits(B, H, W, Cin, Cout);
-    if (workspace_bytes < ossid_conv3x3_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return OSSID_EINVAL;
-    const int in_cs = in_channel_stride > 0 ? in_channel_stride : Cin, dy_cs = dy_channel_stride > 0 ? dy_channel_stride : Cout;
-    const int ci_pairs = (Cin + 63) / 64, co_pairs = (Cout + 63) / 64;
-    const int tiles = co_pairs * ci_pairs * 3;
-    const long waves = (long)tiles * nsplit;
-    hipStream_t s = (hipStream_t)stream;
-    // (no memset: every wave writes its whole 64x64x3 region of its slab, zeros included, so the slabs are fully defined)
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, dy, (float*)workspace, B,
-                       H, W, Cin, Cout, in_cs, dy_cs, nsplit, ci_pairs, tiles);
-    const size_t n = (size_t)Cout * Cin * 9;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
-                       nsplit, n, dw, accumulate);
-    return ossid_launch_status();
+    ossid_wgrad_desc d = {};
+    d.x = x, d.dy = dy, d.dw = dw, d.workspace = workspace, d.workspace_bytes = workspace_bytes;
+    d.batch = B, d.height = H, d.width = W, d.cin = Cin, d.cout = Cout, d.taps = 9, d.accumulate = accumulate;
+    d.in_channel_stride = in_channel_stride, d.dy_channel_stride = dy_channel_stride;
+    return ossid_conv_wgrad(&d, stream);
 }
 
 }  // extern "C"

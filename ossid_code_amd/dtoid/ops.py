@@ -324,95 +324,15 @@ class SegTail:
 PackedConv3x3 = PackedConv   # the head's name for it
 
 
-class _WeightPack:
-    """A bare (Cout, Cin, 3, 3) weight tensor packed for csrc/conv.hip (no fused neighbours)."""
-
-    def __init__(self, w):
-        self.cout, self.cin, self.taps = int(w.shape[0]), int(w.shape[1]), 9
-        n = _lib.fn("ossid_conv_packed_floats")(self.cout, self.cin, 9)
-        self.wpk = torch.empty(n, dtype=torch.float32, device=w.device)
-        w = w.contiguous()
-        with torch.cuda.device(w.device):
-            _lib.check(_lib.fn("ossid_conv_pack_weights")(w.data_ptr(), self.cout, self.cin, 9, self.wpk.data_ptr(),
-                                                          _lib.stream()), "ossid_conv_pack_weights")
-        self.bias = self.scale = self.shift = self.pre_scale = self.pre_shift = None
-        self.act = self.pre_relu = 0
-
-    run = PackedConv.run
-
-
-_WGRAD_WS = {}
-
-
-def _wgrad_workspace(nbytes, device):
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
-    ws = _WGRAD_WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _WGRAD_WS[key] = ws
-    return ws
-
-
-class _Conv3x3(torch.autograd.Function):
-    """y = conv2d(x, w, b, stride 1, padding 1) with all three passes on the hand-written MFMA kernels: forward and
-    data gradient are csrc/conv.hip's implicit GEMM (the latter on the rotated, transposed weights), the weight gradient
-    is the pixels-on-K kernel with deterministic split-K. Tensors are logical NCHW in channels_last memory format."""
-
-    @staticmethod
-    def forward(ctx, x, w, b):
-        B, C, H, W = x.shape
-        x = x.float().contiguous(memory_format=torch.channels_last)
-        pk = _WeightPack(w.detach().float())
-        pk.bias = None if b is None else b.detach().float().contiguous()
-        y = torch.empty((B, pk.cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        pk.run(x, B, H, W, y)
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        B, Cin, H, W = x.shape
-        Cout = w.shape[0]
-        dy = dy.float().contiguous(memory_format=torch.channels_last)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wt = _WeightPack(w.detach().float().flip(2, 3).transpose(0, 1).contiguous())   # [Cin][Cout][3][3], rot 180
-            dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-            wt.run(dy, B, H, W, dx)
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
-            nbytes = _lib.fn("ossid_conv3x3_wgrad_workspace_bytes")(B, H, W, Cin, Cout)
-            ws = _wgrad_workspace(nbytes, x.device)
-            with torch.cuda.device(x.device):
-                rc = _lib.fn("ossid_conv3x3_wgrad")(x.data_ptr(), dy.data_ptr(), B, H, W, Cin, Cout, 0, 0, ws.data_ptr(),
-                                                    nbytes, dw.data_ptr(), 0, _lib.stream())
-            _lib.check(rc, "ossid_conv3x3_wgrad")
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum((0, 2, 3))
-        return dx, dw, db
-
-
 def conv3x3(x, weight, bias=None):
-    """Differentiable 3x3 / stride 1 / padding 1 convolution on the hand-written kernels (needs Cin, Cout % 16 == 0)."""
+    """Differentiable 3x3 / stride 1 / padding 1 convolution on the hand-written kernels (forward, data gradient on the
+    rotated weights, LDS-staged MFMA weight gradient): train_ops.FusedConv without prologue or activation."""
+    from . import train_ops
     _lib.require_cuda(x, weight)
-    return _Conv3x3.apply(x, weight, bias)
-
-
-TRAIN_CONV_IMPL = "miopen"   # "hip": the head's 3x3 convolutions run forward/dgrad/wgrad on csrc/conv.hip in training too
-
-
-def set_train_conv_impl(name):
-    global TRAIN_CONV_IMPL
-    if name not in ("miopen", "hip"):
-        raise ValueError(name)
-    TRAIN_CONV_IMPL = name
+    return train_ops.FusedConv.apply(x, weight, bias, None, None, False, False, None, False)
 
 
 def conv_module(mod, x):
-    """Apply an nn.Conv2d: through the hand-written differentiable kernel when selected and eligible, else torch."""
-    if (TRAIN_CONV_IMPL == "hip" and x.is_cuda and mod.kernel_size == (3, 3) and mod.padding == (1, 1) and
-            mod.stride == (1, 1) and mod.groups == 1 and mod.in_channels % 16 == 0 and mod.out_channels % 16 == 0):
-        return conv3x3(x, mod.weight, mod.bias)
+    """Apply an nn.Conv2d of the nn.Module path (eval on the CPU, the MIOpen reference path of the tests). The training
+    step does not come through here: Network._forward_train_hip drives csrc/conv.hip + csrc/train.hip directly."""
     return mod(x)

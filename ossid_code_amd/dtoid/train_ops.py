@@ -113,8 +113,10 @@ class _Packed:
         return ent
 
 
-_FRESH = {}         # (weight pointer, shape, kind) -> the weight's version counter when the step's PackPlan packed it:
-#                     _pack() skips its own launch while the weight has not been written since
+_ACTIVE_PLAN = None  # weakref to the PackPlan that packed last. Its `fresh` dict maps (weight pointer, shape, kind) -> the
+#                      weight's version counter at that moment: _pack() skips its own launch while the weight has not been
+#                      written since. The plan holds its weights strongly, so while it lives their addresses cannot be
+#                      recycled for other tensors; when its network dies the weakref dies with it and nothing is "fresh".
 
 
 def _pack(w, kind):
@@ -122,7 +124,8 @@ def _pack(w, kind):
     assert w.is_contiguous() and w.dtype == torch.float32
     cout, cin, taps = int(w.shape[0]), int(w.shape[1]), int(w.shape[2] * w.shape[3])
     buf = _Packed.get(w, kind)
-    if _FRESH.get((w.data_ptr(), tuple(w.shape), kind)) == w._version:
+    plan = _ACTIVE_PLAN() if _ACTIVE_PLAN is not None else None
+    if plan is not None and plan.fresh.get((w.data_ptr(), tuple(w.shape), kind)) == w._version:
         return buf
     name = "ossid_conv_pack_weights" if kind == "fwd" else "ossid_conv_pack_weights_dgrad"
     with torch.cuda.device(w.device):
@@ -158,6 +161,7 @@ class PackPlan:
         self.n_rows, self.total_blocks, self.keys = len(rows), first, keys
         self.weights = [c.weight for c in convs]
         self.sig = tuple(w.data_ptr() for w in self.weights)
+        self.fresh = {}
 
     def valid_for(self, convs):
         return len(convs) == len(self.sig) and all(c.weight.data_ptr() == p for c, p in zip(convs, self.sig))
@@ -166,15 +170,17 @@ class PackPlan:
         with torch.cuda.device(self.device):
             rc = _lib.fn("ossid_conv_pack_weights_table")(self.table.data_ptr(), self.n_rows, self.total_blocks, _lib.stream())
         _lib.check(rc, "ossid_conv_pack_weights_table")
-        _FRESH.clear()
+        global _ACTIVE_PLAN
+        import weakref
         vers = {w.data_ptr(): w._version for w in self.weights}
-        for k in self.keys:
-            _FRESH[k] = vers[k[0]]
+        self.fresh = {k: vers[k[0]] for k in self.keys}
+        _ACTIVE_PLAN = weakref.ref(self)
 
 
 def end_step():
-    """Weights are about to change (optimizer step): nothing is fresh any more."""
-    _FRESH.clear()
+    """Forget the active plan (nothing is fresh any more)."""
+    global _ACTIVE_PLAN
+    _ACTIVE_PLAN = None
 
 
 def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_relu=False, act=0, in_cs=0, out_cs=0,

@@ -356,44 +356,6 @@ def test_fused_backbone_matches_module_path(hiplib):
     assert float((got - ref).abs().max()) <= 1e-3 * float(ref.abs().max())   # 120 chained layers, two f32 sum orders
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 32, 9, 13), (8, 256, 256, 29, 39), (2, 640, 256, 29, 39), (1, 32, 16, 40, 52),
-                                             (3, 48, 96, 7, 5), (2, 128, 64, 58, 78)])
-def test_conv3x3_autograd_all_three_passes(hiplib, B, Cin, Cout, H, W):
-    """forward, data gradient and weight gradient of the hand-written conv vs torch autograd in float64."""
-    g = torch.Generator().manual_seed(Cin + 3 * Cout + H)
-    x = torch.randn(B, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (1.0 / (Cin * 9)) ** 0.5
-    b = torch.randn(Cout, generator=g) * 0.1
-    go = torch.randn(B, Cout, H, W, generator=g)
-    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
-    torch.nn.functional.conv2d(xr, wr, br, padding=1).backward(go.double())
-    xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x, w, b))
-    y = ops.conv3x3(xd, wd, bd)
-    y.backward(go.cuda())
-
-    def rel(a, ref):
-        return float((a.cpu().double() - ref).abs().max() / ref.abs().max())
-    assert rel(xd.grad, xr.grad) < 2e-5 and rel(bd.grad, br.grad) < 2e-5
-    assert rel(wd.grad, wr.grad) < 5e-5                     # sums over B*H*W pixels
-    y2 = ops.conv3x3(xd, wd, bd)                             # the weight gradient is bit-reproducible (no atomics)
-    g1 = wd.grad.clone()
-    wd.grad = None
-    y2.backward(go.cuda())
-    assert torch.equal(wd.grad, g1)
-
-
-def test_head_training_on_hand_written_convs_matches_reference_golden(hiplib):
-    """The reference-golden forward/backward check of the head with every eligible 3x3 convolution (forward, data
-    gradient, weight gradient) on csrc/conv.hip instead of MIOpen."""
-    ops.set_train_conv_impl("hip")
-    try:
-        out, _ = run_head("cuda")
-    finally:
-        ops.set_train_conv_impl("miopen")
-    for k, v in out.items():
-        assert close(v, G[k], rtol=2e-3, atol=2e-4), k
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,Hs,Ws,H,W", [(2, 232, 312, 480, 640), (1, 29, 39, 61, 83), (3, 20, 24, 40, 48),
                                          (1, 7, 9, 30, 31)])

@@ -124,16 +124,14 @@ def main():
         b = {k: (v.contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v) for k, v in b.items()}
         t = timeit(lambda: finetune.finetune_step(m, b, opt), warm=3, reps=4)
         out["finetune channels_last B=%d" % a.batch] = {"ms": t * 1e3, "samples_per_s": a.batch / t}
-    if "finetune_hip" in a.what:   # head convolutions (fwd, dgrad, wgrad) on the hand-written kernels in training
-        from ossid_code_amd.dtoid import ops as _ops
-        _ops.set_train_conv_impl("hip")
+    if "finetune_miopen" in a.what:   # the nn.Module path (MIOpen) for comparison; the default is the hip training path
         m = dtoid.DtoidNet(cfg).cuda().train()
+        m.model.use_hip_training = False
         flat = finetune.FlatParams(m)
         opt = finetune.FusedAMSGrad(flat)
         b = _batch(cfg, a.batch, "cuda")
         t = timeit(lambda: finetune.finetune_step(m, b, opt), warm=3, reps=4)
-        out["finetune hip-convs B=%d" % a.batch] = {"ms": t * 1e3, "samples_per_s": a.batch / t}
-        _ops.set_train_conv_impl("miopen")
+        out["finetune module-path B=%d" % a.batch] = {"ms": t * 1e3, "samples_per_s": a.batch / t}
     if "finetune" in a.what.split(","):
         m = dtoid.DtoidNet(cfg).cuda().train()
         flat = finetune.FlatParams(m)
