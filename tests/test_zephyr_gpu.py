@@ -121,6 +121,30 @@ def test_fps_and_ball_query_bit_exact(hiplib, ozr, n, npoint, stride):
         assert np.array_equal(ball.cpu().numpy(), ozr.ball_query(xyz, want_cen, radius, 64))
 
 
+@pytest.mark.parametrize("n,npoint", [(2048, 512), (1024, 128), (625, 128)])
+def test_fps_on_a_lattice_resolves_every_tie_to_the_lowest_index(hiplib, ozr, n, npoint):
+    """SPEC.md 4.1's tie rule under stress: points on an integer lattice in the plane (the featurizer's point sets ARE
+    planar), so nearly every round of farthest-point sampling has many exactly-equal running distances. The HIP kernels
+    (register-resident DPP max-scan and the LDS fallback) and the oracle must pick the same -- lowest -- index every time;
+    pointnet2_ops' CUDA block reduction would keep the lower THREAD's candidate instead (strided ownership), a
+    difference that only exact ties expose (SPEC.md 4.1)."""
+    side = int(np.ceil(np.sqrt(n)))
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 2)[:n].astype(np.float32)
+    xyz = np.zeros((2, n, 8), np.float32)
+    xyz[0, :, :2] = g / side * 2 - 0.97                        # |p|^2 > 1e-3 everywhere except near the centre
+    rng = np.random.default_rng(0)
+    xyz[1, :, :2] = (g / side * 2 - 0.97)[rng.permutation(n)]  # the same lattice in shuffled index order
+    want = ozr.fps(xyz, npoint)
+    # ties really occur: in the first rounds several points share the maximum distance
+    d0 = ((xyz[0, :, :2] - xyz[0, 0, :2]) ** 2).sum(1)
+    assert (d0 == d0.max()).sum() >= 1 and len(np.unique(d0)) < n // 2
+    dx = torch.from_numpy(xyz).cuda()
+    idx = torch.empty(2, npoint, dtype=torch.int32, device="cuda")
+    cen = torch.empty(2, npoint, 3, dtype=torch.float32, device="cuda")
+    rc = hiplib.fn("ossid_pn2_fps")(dx.data_ptr(), 8, 2, n, npoint, idx.data_ptr(), cen.data_ptr(), hiplib.stream())
+    assert rc == 0 and np.array_equal(idx.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("B,M", [(5, 640), (1, 512), (9, 2048), (13, 777)])
 def test_scorer_every_stage_bit_exact(z, ozr, B, M):
     d = small_inputs(N=B, M=M)
@@ -183,6 +207,20 @@ def test_network_inference_matches_oracle(z, ozr, th):
         assert np.array_equal(np.argsort(-scores[:, 0], kind="stable"), np.argsort(-wscores, kind="stable"))
         assert scores.argmax() == wscores.argmax()
     assert dt > 0
+
+
+def test_network_inference_many_on_two_streams_equals_per_frame_calls(z, ozr):
+    """The batched entry point (two frames in flight on alternating HIP streams, the product default for several
+    frames) returns bit-for-bit what per-frame networkInference returns, in order."""
+    from ossid_code_amd.scoring import networkInference, networkInferenceMany
+    frames = [synth.make_scoring_inputs(N=24 + 8 * i, M=640, seed=30 + i, H=120, W=160) for i in range(5)]
+    dataset = z.ScoreDataset([], "", "lmo", _Args(), mode="test")
+    model = synth.random_pn2_state(z.PointNet2SSG(dataset.dim_point, _Args(), num_class=1), 3).cuda().eval()
+    many = networkInferenceMany(model, dataset, frames, streams=2)
+    for d, got in zip(frames, many):
+        poses, scores, errs, uv = networkInference(model, dataset, d)
+        assert np.array_equal(got[1], scores) and np.array_equal(got[0], poses)
+        assert np.array_equal(got[3].cpu().numpy(), uv.cpu().numpy())
 
 
 def test_filter_hypo_by_mask(z):
