@@ -154,7 +154,7 @@ int ossid_dw_xcorr_bwd_k(const float* x, const float* dout, int planes, int H, i
  * taps 9: 3x3 / stride 1 / padding 1 (zero halo);  taps 1: 1x1.
  * pre  = x * pre_scale[ci] + pre_shift[ci] (then ReLU if pre_relu) on real pixels only -- eval-mode BatchNorm(+ReLU)
  *        in FRONT of the conv (DenseNet's BN-ReLU-Conv); NULL = identity.
- * act  = 0 none, 1 ELU(alpha 1);  post = * post_scale[co] + post_shift[co] -- eval-mode BatchNorm BEHIND the ELU
+ * act  = 0 none, 1 ELU(alpha 1), 2 ReLU (SqueezeNet's Fire modules);  post = * post_scale[co] + post_shift[co] -- eval-mode BatchNorm BEHIND the ELU
  *        (`norm(F.elu(conv(x)))`); NULL = identity.
  * src_height/width > 0 (3x3 only): x is [B][src_h][src_w][..] and is nearest-neighbour up-sampled to [H][W] on the fly
  *        (F.interpolate(mode="nearest") in front of the conv, network.py:354-357).
@@ -351,6 +351,24 @@ int ossid_focal_smoothl1_loss_fwd(const float* cls, const float* reg, const floa
                                   float* workspace, float* losses2, float* scales2B, void* stream);
 int ossid_focal_smoothl1_loss_bwd(const float* dcls_raw, const float* dreg_raw, const float* scales2B, const float* grad_losses2,
                                   int B, int A, int C, float* dcls, float* dreg, void* stream);
+
+/* D1-D4  the strided stems of the two backbones (too few input channels for the MFMA convolution's channel tiling) as
+ * im2col + a 1x1 convolution on ossid_conv_nhwc_fwd: out [B][Ho][Wo][Kpad] channels-last, column (ky*k + kx)*Cin + ci =
+ * normalised img[b][ci][yo*stride - pad + ky][xo*stride - pad + kx] (0 outside the image and in the columns past
+ * k*k*Cin); img is NCHW as the caller holds it; mean / inv_std [Cin] (device, NULL = none) = normalizeImageRange
+ * (utils/__init__.py:33-39) applied to real pixels on the way. DenseNet conv0 (network.py:164): k 7, stride 2, pad 3,
+ * Kpad 160; SqueezeNet stem (:203-208): k 3, stride 2, pad 0, Kpad 48. The host re-lays the conv weight [Cout][Cin][k][k] to
+ * [Cout][Kpad] in the same column order. */
+int ossid_im2col_stem(const float* img_nchw, int B, int Cin, int H, int W, int k, int stride, int pad, int Kpad,
+                      const float* mean, const float* inv_std, float* out, void* stream);
+/* D4  relu(scale[c] * (x0 + conv2d_dw_group(x0, kernels)) + shift[c]) (network.py:178-181: the global-template modulation
+ * of the stem output, norm0 in eval mode, relu0), channels-last; kernels [B or 1][C][3][3], kernels_batch_stride = C*9 or
+ * 0 (one kernel set for the whole batch). */
+int ossid_stem_tail_nhwc(const float* x0, const float* kernels, int kernels_batch_stride, const float* scale, const float* shift,
+                         int B, int H, int W, int C, float* out, void* stream);
+/* D2-D4  nn.MaxPool2d(k, stride, padding, ceil_mode) channels-last (DenseNet pool0: 3, 2, 1; SqueezeNet: 3, 2, 0, ceil). */
+int ossid_maxpool_nhwc(const float* x, int B, int H, int W, int C, int k, int stride, int pad, int ceil_mode, float* out,
+                       void* stream);
 
 /* D12  torch.topk(scores, k) (network.py:555: the 1000 best of the ~570 k (template, anchor) object scores of a frame):
  * values [k] in decreasing order and their int64 indices; equal scores are ordered (and, at the cut, chosen) by increasing

@@ -105,6 +105,9 @@ _PROTOS = {
     "ossid_focal_smoothl1_loss_workspace_floats": (_sz, [_i, _i]),
     "ossid_focal_smoothl1_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_focal_smoothl1_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ossid_im2col_stem": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ossid_stem_tail_nhwc": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ossid_maxpool_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ossid_topk_workspace_bytes": (_sz, [_i, _i]),
     "ossid_topk": (_i, [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "ossid_nms_workspace_bytes": (_sz, [_i]),

@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
             for (int i = 0; i < 4; ++i) {
                 float u = acc[t][4 * q + i];
                 if (A.act == 1) u = u > 0.0f ? u : expm1f(u);
+                else if (A.act == 2) u = fmaxf(u, 0.0f);
                 v[i] = u * sc[i] + sh[i];
             }
             float* o = A.out + (size_t)opx[t] * A.out_cs + A.out_coff + co;
@@ -550,7 +551,7 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
     if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 16 || (Cout % 4) || B > 65535) return OSSID_EINVAL;
     if (d->taps != 1 && d->taps != 9 && d->taps != 4) return OSSID_EINVAL;
     if (B == 0) return OSSID_OK;
-    if (!d->x || !d->wpk || !d->out || (d->act != 0 && d->act != 1)) return OSSID_EINVAL;
+    if (!d->x || !d->wpk || !d->out || d->act < 0 || d->act > 2) return OSSID_EINVAL;
     ConvArgs a;
     a.x = d->x, a.wpk = (const float4*)d->wpk, a.bias = d->bias, a.bn_scale = d->post_scale, a.bn_shift = d->post_shift;
     a.pre_scale = d->pre_scale, a.pre_shift = d->pre_shift, a.pre_relu = d->pre_relu, a.out = d->out;

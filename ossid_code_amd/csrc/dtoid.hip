@@ -700,3 +700,147 @@ int ossid_topk(const float* scores, int n, int k, void* workspace, size_t worksp
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// D1-D4  the strided stems of the two backbones and the pooling around them, channels-last.
+//   im2col_stem   the 7x7 / stride 2 / pad 3 stem of DenseNet-121 (network.py:164-169, 3 -> 64) and the 3x3 / stride 2 /
+//                 no-pad stem of SqueezeNet-1.1 (:203-208, 4 -> 64) have 3 / 4 input channels: too few for the MFMA
+//                 convolution's channel tiling. Their receptive fields are gathered into rows [out pixel][k*k*Cin padded
+//                 to a multiple of 16] -- with normalizeImageRange ((x - mean) / std, utils/__init__.py:33-39) applied to
+//                 real pixels on the way, zero padding in NORMALISED space as the reference has it -- and the stem
+//                 becomes a 1x1 convolution on csrc/conv.hip (weights re-laid to match by the host).
+//   stem_tail     x0 + conv2d_dw_group(x0, k) (network.py:178-179, 186-192), eval BatchNorm affine, ReLU -- one pass.
+//   maxpool_nhwc  nn.MaxPool2d(k, stride, padding, ceil_mode) (DenseNet pool0: 3/2/1; SqueezeNet: 3/2/0 ceil).
+namespace {
+
+__global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restrict__ img, int Cin, int H, int W, int k, int stride,
+                                                          int pad, int Ho, int Wo, int Kpad, const float* __restrict__ mean,
+                                                          const float* __restrict__ inv_std, size_t total,
+                                                          float4* __restrict__ out) {
+    // one thread = 4 consecutive columns of one output row; column j = (ky * k + kx) * Cin + ci
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int K4 = Kpad / 4;
+    const int q = (int)(i % K4);
+    size_t r = i / K4;
+    const int xo = (int)(r % Wo);
+    r /= Wo;
+    const int yo = (int)(r % Ho), b = (int)(r / Ho);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = 4 * q + e;
+        float val = 0.0f;
+        if (j < k * k * Cin) {
+            const int ci = j % Cin, t = j / Cin, kx = t % k, ky = t / k;
+            const int y = yo * stride - pad + ky, x = xo * stride - pad + kx;
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                val = img[(((size_t)b * Cin + ci) * H + y) * W + x];                 // NCHW input, as the caller has it
+                if (mean) val = (val - mean[ci]) * inv_std[ci];
+            }
+        }
+        v[e] = val;
+    }
+    out[i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ __launch_bounds__(256) void stem_tail_kernel(const float4* __restrict__ x0, const float* __restrict__ kern,
+                                                        int kern_bs, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int H, int W, int C4, size_t total,
+                                                        float4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int xx = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H), b = (int)(r / H);
+    const float* kk = kern + (size_t)b * kern_bs + (size_t)c4 * 36;      // [C][3][3]: 4 channels x 9 taps
+    float4 acc = x0[i];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int y = yy + dy - 1;
+        if (y < 0 || y >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int x = xx + dx - 1;
+            if (x < 0 || x >= W) continue;
+            const float4 v = x0[(((size_t)b * H + y) * W + x) * C4 + c4];
+            const int t = dy * 3 + dx;
+            acc.x = fmaf(v.x, kk[t], acc.x), acc.y = fmaf(v.y, kk[9 + t], acc.y);
+            acc.z = fmaf(v.z, kk[18 + t], acc.z), acc.w = fmaf(v.w, kk[27 + t], acc.w);
+        }
+    }
+    const float4 sc = *(const float4*)(scale + 4 * c4), sh = *(const float4*)(shift + 4 * c4);
+    out[i] = make_float4(fmaxf(acc.x * sc.x + sh.x, 0.f), fmaxf(acc.y * sc.y + sh.y, 0.f), fmaxf(acc.z * sc.z + sh.z, 0.f),
+                         fmaxf(acc.w * sc.w + sh.w, 0.f));
+}
+
+__global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const float4* __restrict__ x, int H, int W, int C4, int k, int stride,
+                                                           int pad, int Ho, int Wo, size_t total, float4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int xo = (int)(r % Wo);
+    r /= Wo;
+    const int yo = (int)(r % Ho), b = (int)(r / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int dy = 0; dy < k; ++dy) {
+        const int y = yo * stride - pad + dy;
+        if (y < 0 || y >= H) continue;
+        for (int dx = 0; dx < k; ++dx) {
+            const int xx = xo * stride - pad + dx;
+            if (xx < 0 || xx >= W) continue;
+            const float4 v = x[(((size_t)b * H + y) * W + xx) * C4 + c4];
+            m.x = fmaxf(m.x, v.x), m.y = fmaxf(m.y, v.y), m.z = fmaxf(m.z, v.z), m.w = fmaxf(m.w, v.w);
+        }
+    }
+    out[i] = m;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ossid_im2col_stem(const float* img_nchw, int B, int Cin, int H, int W, int k, int stride, int pad, int Kpad,
+                      const float* mean, const float* inv_std, float* out, void* stream) {
+    if (!img_nchw || !out || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0 || pad < 0 || Kpad % 4 ||
+        Kpad < k * k * Cin || (!mean != !inv_std))
+        return OSSID_EINVAL;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return OSSID_EINVAL;
+    const size_t total = (size_t)B * Ho * Wo * (Kpad / 4);
+    hipLaunchKernelGGL(im2col_stem_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img_nchw, Cin,
+                       H, W, k, stride, pad, Ho, Wo, Kpad, mean, inv_std, total, (float4*)out);
+    return ossid_launch_status();
+}
+
+int ossid_stem_tail_nhwc(const float* x0, const float* kernels, int kernels_batch_stride, const float* scale, const float* shift,
+                         int B, int H, int W, int C, float* out, void* stream) {
+    if (!x0 || !kernels || !scale || !shift || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || kernels_batch_stride < 0)
+        return OSSID_EINVAL;
+    const size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(stem_tail_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x0, kernels, kernels_batch_stride, scale, shift, H, W, C / 4, total, (float4*)out);
+    return ossid_launch_status();
+}
+
+int ossid_maxpool_nhwc(const float* x, int B, int H, int W, int C, int k, int stride, int pad, int ceil_mode, float* out,
+                       void* stream) {
+    if (!x || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || k <= 0 || stride <= 0 || pad < 0 || 2 * pad > k)
+        return OSSID_EINVAL;
+    auto osz = [&](int n) {
+        int o = ceil_mode ? (n + 2 * pad - k + stride - 1) / stride + 1 : (n + 2 * pad - k) / stride + 1;
+        if (ceil_mode && (o - 1) * stride >= n + pad) --o;          // torch: the last window must start inside the input
+        return o;
+    };
+    const int Ho = osz(H), Wo = osz(W);
+    if (Ho <= 0 || Wo <= 0) return OSSID_EINVAL;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x, H, W, C / 4, k, stride, pad, Ho, Wo, total, (float4*)out);
+    return ossid_launch_status();
+}
+
+}  // extern "C"

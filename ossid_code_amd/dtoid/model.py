@@ -117,12 +117,14 @@ class DtoidNet(nn.Module):
     def forwardTestTime(self, input):
         image = input["img"]
         assert len(image) == 1, "test time handles one image and one object at a time (reference :64)"
-        image = normalizeImageRange(image)
+        raw = image.is_cuda                     # on the GPU normalizeImageRange is fused into the stem's gather (D1)
+        if not raw:
+            image = normalizeImageRange(image)
         obj_id = int(input["obj_id"][0])
         local, glob = self._template_features(input, obj_id, image.device)
         with torch.no_grad():
             scores, boxes, tids, seg, heat = self.model.forward_all_templates(image, local, glob, topk=self.TOP_K,
-                                                                               seg_sigmoid=True)   # reference :147
+                                                                               seg_sigmoid=True, raw_image=raw)   # :147
             if "template_z_values" in input and getattr(self.cfg, "filter_z", False):
                 z = input["template_z_values"].to(boxes.device)[0, tids[:, 0].long()]
                 size = torch.maximum(boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1])
@@ -145,10 +147,13 @@ class DtoidNet(nn.Module):
         batch of images `img [B,3,H,W]` that all look for the SAME object (`limg [1,n_t,3,h,w]`, `lmask`, `obj_id` as in
         forwardTestTime). The reference asserts B = 1 (models/dtoid/__init__.py:64) and would be called B times; here the
         image backbone runs once on the whole batch. Returns a list of B dicts with forwardTestTime's keys."""
-        image = normalizeImageRange(input["img"])
+        image = input["img"]
+        raw = image.is_cuda
+        if not raw:
+            image = normalizeImageRange(image)
         obj_id = int(input["obj_id"][0])
         local, glob = self._template_features(input, obj_id, image.device)
-        res = self.model.forward_all_templates_batch(image, local, glob, topk=self.TOP_K, seg_sigmoid=True)
+        res = self.model.forward_all_templates_batch(image, local, glob, topk=self.TOP_K, seg_sigmoid=True, raw_image=raw)
         outs = []
         for scores, boxes, tids, seg, heat in res:
             outs.append({"pred_bbox": boxes, "pred_scores": scores, "pred_template_ids": tids[:, 0],

@@ -204,6 +204,91 @@ class TemplateFeatExtract(nn.Module):
         return _squeezenet_features(self, img)
 
 
+class FusedTemplateEncoder:
+    """Test-time execution plan of a SqueezeNet-1.1 template encoder (TemplateFeatExtract / TemplateFeatExtractGlobal,
+    network.py:195-279) on this repo's kernels: the 4-channel stride-2 stem as im2col + 1x1 MFMA convolution, the
+    max-pools channels-last, every Fire module as three convolutions with the ReLU in their epilogues writing into
+    channel slices of one buffer (no torch.cat); the global branch's two valid 3x3 convolutions as padded convolutions
+    whose interior is kept (an interior output of a pad-1 conv never touches the padding: identical values). BatchNorm
+    (eval) on the two taps, the 30 -> 7 bilinear resize and the final concatenation are small torch ops."""
+
+    def __init__(self, mod):
+        P = ops.PackedConv
+        self.mod = mod
+        self.stem = P(ops._StemAsMatrix(mod.backbone_0[0], 48), act=2)
+        self.stages = []                                    # ("pool", module) | ("fire", (squeeze, e1, e3), e1_channels)
+        for part in (list(mod.backbone_1), list(mod.backbone_2)):
+            plan = []
+            for m in part:
+                if isinstance(m, nn.MaxPool2d):
+                    plan.append(("pool", m))
+                elif isinstance(m, nn.ReLU):
+                    continue                                # the stem's ReLU rides in its epilogue
+                else:
+                    plan.append(("fire", (P(m.squeeze, act=2), P(m.expand1x1, act=2), P(m.expand3x3, act=2))))
+            self.stages.append(plan)
+        self.final = None
+        if hasattr(mod, "final_conv_1"):
+            self.final = [P(_PadOne(mod.final_conv_1), mod.final_norm_1, act=1), P(_PadOne(mod.final_conv_2), mod.final_norm_2, act=1)]
+
+    def refresh(self):
+        self.stem.refresh()
+        for plan in self.stages:
+            for kind, item in plan:
+                if kind == "fire":
+                    for pk in item:
+                        pk.refresh()
+        for pk in self.final or []:
+            pk.refresh()
+
+    def _run(self, plan, x):
+        for kind, item in plan:
+            if kind == "pool":
+                k = item.kernel_size if isinstance(item.kernel_size, int) else item.kernel_size[0]
+                st = item.stride if isinstance(item.stride, int) else item.stride[0]
+                pd = item.padding if isinstance(item.padding, int) else item.padding[0]
+                x = ops.maxpool_nhwc(x, k, st, pd, item.ceil_mode)
+            else:
+                sq, e1, e3 = item
+                B, _, H, W = x.shape
+                s = sq(x)
+                out = torch.empty((B, e1.cout + e3.cout, H, W), dtype=torch.float32, device=x.device,
+                                  memory_format=torch.channels_last)
+                e1.run(s, B, H, W, out, out_cs=e1.cout + e3.cout, out_coff=0)
+                e3.run(s, B, H, W, out, out_cs=e1.cout + e3.cout, out_coff=e1.cout)
+                x = out
+        return x
+
+    def __call__(self, img):
+        mod = self.mod
+        x = self.stem(ops.im2col_stem(img, 3, 2, 0, 48))
+        x1 = self._run(self.stages[0], x)
+        x2 = self._run(self.stages[1], x1)
+        x1n, x2n = mod.norm_1(x1), mod.norm_2(x2)
+        xf = torch.cat([x2n, _bilinear_resize(x1n, x2.size(3))], dim=1)
+        if self.final is not None:
+            for pk in self.final:                          # valid 3x3: pad-1 convolution, keep the interior
+                xf = pk(xf)[:, :, 1:-1, 1:-1]
+        return xf.contiguous()
+
+
+class _PadOne:
+    """An nn.Conv2d(3x3, padding 0) presented to PackedConv as the pad-1 convolution whose interior it equals."""
+    padding, stride, groups = (1, 1), (1, 1), 1
+
+    def __init__(self, conv):
+        assert conv.kernel_size == (3, 3) and conv.padding == (0, 0) and conv.stride == (1, 1)
+        self.conv = conv
+
+    @property
+    def weight(self):
+        return self.conv.weight
+
+    @property
+    def bias(self):
+        return self.conv.bias
+
+
 class CorrelationModel(nn.Module):
     def __init__(self, img_size=(480, 480), input_dim=1024):
         super().__init__()
@@ -255,6 +340,8 @@ class FusedHead:
     def __init__(self, corr, cls, reg):
         P = ops.PackedConv3x3
         self.corr = corr
+        self.tc1 = P(_PadOne(corr.c1), corr.n1, act=True)      # the two VALID 3x3 convs on the 7x7 template features:
+        self.tc2 = P(_PadOne(corr.c2), corr.n2, act=True)      # pad-1 convolutions whose interior is kept
         self.dot = P(corr.corr_conv_dot, corr.norm_corr_dot, act=True)
         self.sub = P(corr.corr_conv_sub, corr.norm_corr_sub, act=True)
         self.sub_raw = P(corr.corr_conv_sub)                  # conv + bias only: the template-independent half of `sub`
@@ -269,7 +356,7 @@ class FusedHead:
         self.num_classes = cls.num_classes
 
     def refresh(self):
-        for pk in [self.dot, self.sub, self.sub_raw, self.dot3, self.cf, self.tail] + self.seg + self.cls + self.reg:
+        for pk in [self.tc1, self.tc2, self.dot, self.sub, self.sub_raw, self.dot3, self.cf, self.tail] + self.seg + self.cls + self.reg:
             pk.refresh()
         self._fill_derived()
 
@@ -334,7 +421,10 @@ class FusedHead:
         7x7 template features and the global average): constant across frames for an object, so the graphed path computes
         it once per (templates, weights) instead of once per frame."""
         corr = self.corr
-        t2 = corr._cab(corr.c2, corr.n2, corr._cab(corr.c1, corr.n1, template_feat)).contiguous()
+        if template_feat.is_cuda:
+            t2 = self.tc2(self.tc1(template_feat)[:, :, 1:-1, 1:-1])[:, :, 1:-1, 1:-1].contiguous()      # 7 -> 5 -> 3
+        else:
+            t2 = corr._cab(corr.c2, corr.n2, corr._cab(corr.c1, corr.n1, template_feat)).contiguous()
         avg = F.avg_pool2d(template_feat, 7)
         a2 = avg.reshape(avg.shape[0], avg.shape[1]).float().contiguous()
         csub = (a2 @ self.sub_wsum()).contiguous()            # [n_t, 9*256]: conv_sub's response to the constant image a_t
@@ -443,6 +533,11 @@ class FusedBackbone:
         self.ife = ife
         seq = list(ife.backdense_1) + list(ife.backdense_2)      # norm0 relu0 pool0 block1 | trans1 block2 ... norm5
         self.stem = seq[:3]
+        # stem on this repo's kernels: im2col (+ normalizeImageRange) -> 1x1 conv on the MFMA kernel -> template
+        # modulation + norm0 + ReLU in one pass -> max-pool, channels-last from the first kernel on
+        self.conv0 = P(ops._StemAsMatrix(ife.backdense_0[0], 160))
+        self.norm0 = self.stem[0]
+        self.norm0_affine = [t.clone() for t in ops._bn_affine(self.norm0)]
         self.stages = []
         for m in seq[3:]:
             if hasattr(m, "nlayers"):                            # DenseBlock
@@ -459,16 +554,30 @@ class FusedBackbone:
             for pk in ([p for pair in packed for p in pair] if kind == "block" else [packed]):
                 pk.refresh()
         self.final.refresh()
+        self.conv0.refresh()
+        for dst, src in zip(self.norm0_affine, ops._bn_affine(self.norm0)):
+            dst.copy_(src)
 
-    def __call__(self, image, template_feat):
+    use_fused_stem = os.environ.get("OSSID_FUSED_STEM", "1") != "0"
+
+    def __call__(self, image, template_feat, raw_image=False):
+        """raw_image: `image` is in [0, 1] and normalizeImageRange is applied inside the stem's gather (D1)."""
         ife = self.ife
-        x0 = ife.backdense_0(image)
-        if template_feat.shape[0] == 1 and x0.shape[0] > 1:        # a batch of images of ONE object (batched test time)
-            template_feat = template_feat.expand(x0.shape[0], -1, -1, -1)
-        x = x0 + ops.dw_xcorr(x0, template_feat)
-        for m in self.stem:
-            x = m(x)
-        x = x.contiguous(memory_format=torch.channels_last)
+        if self.use_fused_stem:
+            cols = ops.im2col_stem(image, 7, 2, 3, 160, normalize=raw_image)
+            x0 = self.conv0(cols)
+            x = ops.maxpool_nhwc(ops.stem_tail(x0, template_feat, *self.norm0_affine), 3, 2, 1)
+        else:
+            if raw_image:
+                from .model import normalizeImageRange
+                image = normalizeImageRange(image)
+            x0 = ife.backdense_0(image)
+            if template_feat.shape[0] == 1 and x0.shape[0] > 1:    # a batch of images of ONE object (batched test time)
+                template_feat = template_feat.expand(x0.shape[0], -1, -1, -1)
+            x = x0 + ops.dw_xcorr(x0, template_feat)
+            for m in self.stem:
+                x = m(x)
+            x = x.contiguous(memory_format=torch.channels_last)
         for kind, mod, packed in self.stages:
             B, C, H, W = x.shape
             if kind == "block":
@@ -556,11 +665,29 @@ class Network(nn.Module):
             if isinstance(layer, nn.BatchNorm2d):
                 layer.eval()
 
+    use_fused_templates = os.environ.get("OSSID_FUSED_TEMPLATES", "1") != "0"
+
+    def _fused_template_encoder(self, mod, slot):
+        key = FusedHead.version_key(mod)
+        cached = self.__dict__.get(slot)
+        if cached is None or cached[0][0] != key[0]:
+            cached = (key, FusedTemplateEncoder(mod))
+        elif cached[0] != key:
+            cached[1].refresh()
+            cached = (key, cached[1])
+        self.__dict__[slot] = cached
+        return cached[1]
+
+    def _encode_templates(self, mod, slot, img):
+        if self.use_fused_templates and img.is_cuda and not self.training and not torch.is_grad_enabled():
+            return self._fused_template_encoder(mod, slot)(img)
+        return mod(img)
+
     def compute_template_local(self, img):
-        return self.template_feature_extractor(img)
+        return self._encode_templates(self.template_feature_extractor, "_fused_tfe_local", img)
 
     def compute_template_global(self, img):
-        return self.template_feature_extractor_global(img)
+        return self._encode_templates(self.template_feature_extractor_global, "_fused_tfe_global", img)
 
     # finetune forward/backward on the hand-written kernels (train_ops.py); False = the nn.Module path (MIOpen)
     use_hip_training = os.environ.get("OSSID_TRAIN_IMPL", "hip") != "miopen"
@@ -694,10 +821,14 @@ class Network(nn.Module):
         classifications, _ = self.classification(xcors)
         return classifications, self.regression(xcors), anchors, heat_map, segmentation
 
-    def _features(self, image, template_global):
-        """D4: image feature map [B,640,h,w] (test time: DenseNet blocks on csrc/conv.hip)."""
+    def _features(self, image, template_global, raw_image=False):
+        """D4: image feature map [B,640,h,w] (test time: stem + DenseNet blocks on this repo's kernels). raw_image: the
+        image is in [0, 1] and still needs normalizeImageRange (fused into the stem's gather on the GPU path)."""
         if self.use_fused_backbone and image.is_cuda and not self.training:
-            return self._fused_backbone()(image, template_global)
+            return self._fused_backbone()(image, template_global, raw_image=raw_image)
+        if raw_image:
+            from .model import normalizeImageRange
+            image = normalizeImageRange(image)
         if template_global.shape[0] == 1 and image.shape[0] > 1:
             template_global = template_global.expand(image.shape[0], -1, -1, -1)
         return self.image_feature_extractor(image, template_global)
@@ -722,11 +853,11 @@ class Network(nn.Module):
         cat = lambda parts: parts[0] if len(parts) == 1 else torch.cat(parts, 0)   # noqa: E731  (one chunk: no copy)
         return (cat(cls_out), cat(reg_out), cat(seg_out), cat(heat_out), (xc.size(2), xc.size(3)))
 
-    def _dense_all_templates(self, image, template_features, template_global, sides=None):
+    def _dense_all_templates(self, image, template_features, template_global, sides=None, raw_image=False):
         """Backbone once + head per template chunk. No host syncs, no data-dependent shapes: capturable in a hipGraph."""
-        return self._dense_head(self._features(image, template_global), template_features, sides)
+        return self._dense_head(self._features(image, template_global, raw_image), template_features, sides)
 
-    def _graphed_dense(self, image, template_features, template_global, head_only=False):
+    def _graphed_dense(self, image, template_features, template_global, head_only=False, raw_image=False):
         """The dense part replayed from a captured hipGraph (the B=1 backbone alone is ~500 launches and otherwise
         host-bound). One graph per (input shape, chunk sizes, packed-head identity); inputs are copied into the
         graph's static buffers, outputs are read from them. head_only: `image` is already the feature map [1,640,h,w]
@@ -734,7 +865,7 @@ class Network(nn.Module):
         fused = self._fused_head() if self.use_fused_head else None
         fused_bb = self._fused_backbone() if (self.use_fused_backbone and not head_only) else None
         key = (tuple(image.shape), tuple(int(c.shape[0]) for c in template_features), id(fused), id(fused_bb),
-               str(image.device), bool(head_only))
+               str(image.device), bool(head_only), bool(raw_image))
         cache = self.__dict__.setdefault("_graph_cache", {})
         entry = cache.get(key)
         if entry is None:
@@ -748,7 +879,7 @@ class Network(nn.Module):
             # templates or the weights change (below)
             s_sides = [fused.template_side(c) for c in s_tf] if fused is not None else None
             run = (lambda: self._dense_head(s_img, s_tf, s_sides)) if head_only else \
-                (lambda: self._dense_all_templates(s_img, s_tf, s_g, s_sides))
+                (lambda: self._dense_all_templates(s_img, s_tf, s_g, s_sides, raw_image))
             with torch.cuda.stream(side):           # warm-up off the capture: MIOpen picks its kernels here
                 for _ in range(2):
                     run()
@@ -785,14 +916,15 @@ class Network(nn.Module):
         graph.replay()
         return outs
 
-    def forward_all_templates_batch(self, images, template_features, template_features_global, topk=1, seg_sigmoid=False):
+    def forward_all_templates_batch(self, images, template_features, template_features_global, topk=1, seg_sigmoid=False,
+                                    raw_image=False):
         """ADDITIVE API (the reference handles one image per call, models/dtoid/__init__.py:64): `forward_all_templates`
         semantics for a batch of images [B,3,H,W] of ONE object (BASELINE configs[2]: 32 images x 21 templates). The
         image backbone runs once on the whole batch (at batch 1 its 120 dependent launches are latency-bound; batched
         they are not), the head graph is replayed per image on that image's feature map, post-processing per image.
         Returns a list of B result lists, each exactly what forward_all_templates(images[i:i+1], ...) returns."""
         with torch.no_grad():
-            feats = self._features(images, template_features_global[0])
+            feats = self._features(images, template_features_global[0], raw_image)
             out = []
             hw = (images.shape[2], images.shape[3])
             for i in range(images.shape[0]):
@@ -804,16 +936,20 @@ class Network(nn.Module):
                 out.append(self.postprocess(*dense, hw, topk, seg_sigmoid))
             return out
 
-    def forward_all_templates(self, image, template_features, template_features_global, topk=1, seg_sigmoid=False):
+    def forward_all_templates(self, image, template_features, template_features_global, topk=1, seg_sigmoid=False,
+                              raw_image=False):
         """image [1,3,H,W]; template_features: list of [n_i,640,7,7] chunks; template_features_global: [[1,64,3,3]]
-        -> [max_score [k], anchors_pred [k,4], obj_indices [k,1], seg_pred [k,H,W], heatmap_pred [k,hh,hw]]"""
+        -> [max_score [k], anchors_pred [k,4], obj_indices [k,1], seg_pred [k,H,W], heatmap_pred [k,hh,hw]]
+        raw_image (additive): the image is in [0, 1] and normalizeImageRange happens inside the stem (D1 fused)."""
         with torch.no_grad():
             if self.use_graph and image.is_cuda and not self.training:
                 cls_all, reg_all, seg_all, heat_all, fmap = self._graphed_dense(image, template_features,
-                                                                                template_features_global[0])
+                                                                                template_features_global[0],
+                                                                                raw_image=raw_image)
             else:
                 cls_all, reg_all, seg_all, heat_all, fmap = self._dense_all_templates(image, template_features,
-                                                                                      template_features_global[0])
+                                                                                      template_features_global[0],
+                                                                                      raw_image=raw_image)
             return self.postprocess(cls_all, reg_all, seg_all, heat_all, fmap, (image.shape[2], image.shape[3]), topk,
                                     seg_sigmoid)
 

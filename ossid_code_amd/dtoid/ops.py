@@ -116,6 +116,80 @@ def topk_scores(scores, k):
     return vals, idx
 
 
+_IMNORM = {}
+
+
+def im2col_stem(img, k, stride, pad, kpad, normalize=False):
+    """ossid_im2col_stem: img [B,Cin,H,W] (NCHW) -> [B, kpad, Ho, Wo] logical tensor in channels_last memory (rows of
+    receptive fields, column (ky*k + kx)*Cin + ci), optionally with normalizeImageRange applied on the way."""
+    _lib.require_cuda(img)
+    img = img.float().contiguous()
+    B, Cin, H, W = img.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((B, Ho, Wo, kpad), dtype=torch.float32, device=img.device).permute(0, 3, 1, 2)
+    mean = inv = None
+    if normalize:
+        key = str(img.device)
+        if key not in _IMNORM:
+            _IMNORM[key] = (torch.tensor([0.485, 0.456, 0.406], device=img.device),
+                            1.0 / torch.tensor([0.229, 0.224, 0.225], device=img.device))
+        mean, inv = _IMNORM[key]
+    with torch.cuda.device(img.device):
+        rc = _lib.fn("ossid_im2col_stem")(img.data_ptr(), B, Cin, H, W, k, stride, pad, kpad, None if mean is None else
+                                          mean.data_ptr(), None if inv is None else inv.data_ptr(), out.data_ptr(), _lib.stream())
+    _lib.check(rc, "ossid_im2col_stem")
+    return out
+
+
+def stem_tail(x0, kernels, scale, shift):
+    """relu(scale * (x0 + dw_xcorr(x0, kernels)) + shift) on a channels-last x0 [B,C,H,W]; kernels [B or 1, C, 3, 3]."""
+    B, C, H, W = x0.shape
+    k = kernels.detach().float().contiguous()
+    out = torch.empty_like(x0)
+    with torch.cuda.device(x0.device):
+        rc = _lib.fn("ossid_stem_tail_nhwc")(x0.data_ptr(), k.data_ptr(), 0 if k.shape[0] == 1 else C * 9, scale.data_ptr(),
+                                             shift.data_ptr(), B, H, W, C, out.data_ptr(), _lib.stream())
+    _lib.check(rc, "ossid_stem_tail_nhwc")
+    return out
+
+
+def maxpool_nhwc(x, k, stride, pad=0, ceil_mode=False):
+    """nn.MaxPool2d(k, stride, pad, ceil_mode=ceil_mode) on a channels-last tensor."""
+    B, C, H, W = x.shape
+
+    def osz(n):
+        o = -(-(n + 2 * pad - k) // stride) + 1 if ceil_mode else (n + 2 * pad - k) // stride + 1
+        return o - 1 if ceil_mode and (o - 1) * stride >= n + pad else o
+    out = torch.empty((B, C, osz(H), osz(W)), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.fn("ossid_maxpool_nhwc")(x.data_ptr(), B, H, W, C, k, stride, pad, 1 if ceil_mode else 0, out.data_ptr(),
+                                           _lib.stream())
+    _lib.check(rc, "ossid_maxpool_nhwc")
+    return out
+
+
+class _StemAsMatrix:
+    """A k x k strided stem convolution presented to PackedConv as the 1x1 convolution that follows ossid_im2col_stem:
+    weight [Cout, Cin, k, k] re-laid to [Cout, kpad, 1, 1] in the im2col column order (ky*k + kx)*Cin + ci."""
+    padding, stride, groups = (0, 0), (1, 1), 1
+
+    def __init__(self, conv, kpad):
+        self.conv, self.kpad = conv, kpad
+
+    @property
+    def weight(self):
+        w = self.conv.weight.detach().float()
+        cout = w.shape[0]
+        flat = w.permute(0, 2, 3, 1).reshape(cout, -1)
+        out = torch.zeros((cout, self.kpad), dtype=torch.float32, device=w.device)
+        out[:, : flat.shape[1]] = flat
+        return out.view(cout, self.kpad, 1, 1)
+
+    @property
+    def bias(self):
+        return self.conv.bias
+
+
 def gather_rows(src, idx, sigmoid=False):
     """src [R, ...] float32, idx [k] int64 -> src[idx] (optionally through a sigmoid), one pass over the data."""
     _lib.require_cuda(src, idx)
@@ -174,7 +248,7 @@ class PackedConv:
         n = _lib.fn("ossid_conv_packed_floats")(self.cout, self.cin, self.taps)
         self.wpk = torch.empty(n, dtype=torch.float32, device=w.device)
         self.bias = None if conv.bias is None else torch.empty_like(conv.bias, dtype=torch.float32)
-        self.act = 1 if act else 0
+        self.act = int(act) if not isinstance(act, bool) else (1 if act else 0)       # 0 none, 1 ELU, 2 ReLU
         mk = lambda m: (None, None) if m is None else tuple(torch.empty_like(t) for t in _bn_affine(m))  # noqa: E731
         self.scale, self.shift = mk(bn)
         self.pre_scale, self.pre_shift = mk(pre_bn)

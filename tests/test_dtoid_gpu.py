@@ -771,3 +771,75 @@ def test_fused_detection_loss_matches_tensor_expressions(hiplib, case):
     for a, b, name in zip(res[True], res[False], ("loss_cls", "loss_reg", "dcls", "dreg")):
         scale = float(b.abs().max().clamp(min=1e-12))
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (case, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Cin,H,W,k,stride,pad,kpad", [(2, 3, 48, 64, 7, 2, 3, 160), (3, 4, 124, 124, 3, 2, 0, 48), (1, 3, 9, 11, 7, 2, 3, 160)])
+def test_strided_stem_as_im2col_plus_mfma_conv_matches_torch(hiplib, B, Cin, H, W, k, stride, pad, kpad):
+    """D1 + D4/D2: the 7x7/s2/p3 (DenseNet) and 3x3/s2/p0 (SqueezeNet) stems = ossid_im2col_stem (with
+    normalizeImageRange fused, zero padding in normalised space) + a 1x1 convolution on the MFMA kernel."""
+    torch.manual_seed(k + Cin)
+    conv = torch.nn.Conv2d(Cin, 64, k, stride=stride, padding=pad, bias=Cin == 4).cuda()
+    img = torch.rand(B, Cin, H, W, device="cuda")
+    normalize = Cin == 3
+    ref_in = dtoid.normalizeImageRange(img) if normalize else img
+    with torch.no_grad():
+        want = conv(ref_in)
+        pk = ops.PackedConv(ops._StemAsMatrix(conv, kpad))
+        got = pk(ops.im2col_stem(img, k, stride, pad, kpad, normalize=normalize))
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,stride,pad,ceil,H,W", [(3, 2, 1, False, 240, 320), (3, 2, 0, True, 61, 61), (3, 2, 0, True, 30, 30),
+                                                   (3, 2, 0, True, 15, 15), (3, 2, 0, True, 8, 10)])
+def test_maxpool_and_stem_tail_channels_last(hiplib, k, stride, pad, ceil, H, W):
+    x = torch.randn(2, 64, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    want = torch.nn.functional.max_pool2d(x, k, stride, pad, ceil_mode=ceil)
+    got = ops.maxpool_nhwc(x, k, stride, pad, ceil)
+    assert got.shape == want.shape and torch.equal(got, want)
+    for kb in (1, 2):
+        kern = torch.randn(kb, 64, 3, 3, device="cuda")
+        sc, sh = torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda")
+        ref = torch.relu((x + dtoid_oracle.dw_xcorr(x, kern.expand(2, -1, -1, -1))) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        assert float((ops.stem_tail(x, kern, sc, sh) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_template_encoders_and_stem_on_own_kernels_match_module_path(hiplib):
+    """D2/D3/D4 at the real sizes: [n_t,4,124,124] -> [n_t,640,7,7] (TemplateFeatExtract), [1,4,124,124] -> [1,64,3,3]
+    (TemplateFeatExtractGlobal, incl. the two valid 3x3 convs), and the image feature map [1,640,29,39] with the stem
+    (normalizeImageRange fused) on this repo's kernels -- against the nn.Module path (MIOpen), and weights changed by a
+    'finetune' are picked up."""
+    torch.manual_seed(31)
+    net = dtoid.Network(img_size=(480, 640), heatmap_size=(29, 39)).cuda().eval()
+    tm = torch.rand(5, 4, 124, 124, device="cuda")
+    img = torch.rand(1, 3, 480, 640, device="cuda")
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max().clamp(min=1e-9))
+    with torch.no_grad():
+        for trial in range(2):
+            if trial == 1:       # same storage, new values
+                net.template_feature_extractor.backbone_1[2].squeeze.weight.mul_(1.3)
+                net.template_feature_extractor_global.final_conv_2.bias.add_(0.05)
+                net.image_feature_extractor.backdense_0[0].weight.mul_(0.9)
+                net.image_feature_extractor.backdense_1[0].bias.add_(0.1)
+            loc, glob = net.compute_template_local(tm), net.compute_template_global(tm[:1])
+            feat = net._features(img, glob, raw_image=True)
+            net.use_fused_templates = False
+            loc_r, glob_r = net.compute_template_local(tm), net.compute_template_global(tm[:1])
+            net.use_fused_templates = True
+            fb = net._fused_backbone()
+            fb.use_fused_stem = False
+            feat_r = net._features(img, glob, raw_image=True)
+            fb.use_fused_stem = True
+            assert loc.shape == (5, 640, 7, 7) and glob.shape == (1, 64, 3, 3) and feat.shape == (1, 640, 29, 39)
+            assert rel(loc, loc_r) < 1e-4 and rel(glob, glob_r) < 1e-4 and rel(feat, feat_r) < 1e-4, trial
+    # and the whole test-time call goes through them (raw image in, template cache filled by the fused encoders)
+    m = dtoid.DtoidNet(dtoid.DtoidConfig()).cuda().eval()
+    test = {"img": img, "obj_id": torch.tensor([3]), "limg": torch.rand(1, 4, 3, 124, 124).cuda(),
+            "lmask": (torch.rand(1, 4, 1, 124, 124) > 0.5).float().cuda()}
+    out = m.forwardTestTime(test)
+    assert out["pred_bbox"].shape[1] == 4 and "_fused_tfe_local" in m.model.__dict__
