@@ -474,7 +474,8 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
 template <int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
 int launch_conv(ConvArgs a, int B, hipStream_t s) {
     constexpr int WN = 4 / (WM * WK), BPX = WN * NT * 32, F4 = KCH / 4;
-    if (a.Cin % KCH && !(WK > 1 && a.Cin % 8 == 0)) return OSSID_EINVAL;   // the split-K variants take a ragged last chunk
+    // a ragged last chunk (Cin no multiple of KCH) stages zeros past Cin and clamps the weight quads: any variant, Cin % 8 == 0
+    if (a.Cin % KCH && (a.Cin % 8 != 0 || KCH < 32)) return OSSID_EINVAL;
     int rows, PW, nblk;
     if (TAPS == 1) {
         rows = 1;
@@ -585,6 +586,11 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
     if (d->taps == 1) {   // no halo: the patch is just the pixel run
         // small: under one workgroup per CU, so LDS is no constraint and the launch is a chain of memory latencies, one
         // per chunk: 256-channel chunks (ragged last one: DenseNet's widths are multiples of 32), 64 channels per wave
+        // four channel tiles x 32 pixels with 64-channel chunks (a ragged last one for DenseNet's widths): with 16-channel
+        // chunks a 1x1 layer has only 8 MFMAs per wave between barriers. Measured on the batch-8 DenseNet layers
+        // (64..1024 -> 128..640 at 9 k..154 k pixels): forward 45 -> 56, data gradient 55 -> 59 TFLOP/s over the set
+        static const int exp1 = getenv("OSSID_CONV1_EXP") ? atoi(getenv("OSSID_CONV1_EXP")) : 0;   // A/B experiments only
+        if (tiles >= 4 && px >= 4096 && exp1 != 1) return launch_conv<4, 1, 1, false, 2, 1, 64>(a, B, s);
         if (plain_wgs < 160) return launch_conv<1, 4, 1, false, 8, 1, 256>(a, B, s);
         if (tiles >= 4)
             return px >= 128L * 512 ? launch_conv<4, 1, 4, false, 2, 1, 16>(a, B, s)

@@ -304,6 +304,7 @@ def test_graphed_finetune_step_matches_eager(hiplib):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 1024, 640, 29, 39), (1, 256, 128, 120, 160), (2, 64, 128, 30, 40),
+                                           (2, 96, 128, 60, 80), (1, 224, 128, 120, 160), (8, 992, 128, 29, 39),
                                              (1, 512, 256, 60, 80), (3, 32, 32, 7, 5), (1, 96, 24, 9, 11)])
 def test_conv1x1_with_pre_and_post_fusion(hiplib, B, Cin, Cout, H, W):
     """1x1 conv with BN+ReLU folded into the input staging and ELU+BN into the epilogue vs float64 torch."""
