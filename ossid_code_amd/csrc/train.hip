@@ -957,14 +957,16 @@ static int fill_wgrad_args(const ossid_wgrad_desc* d, const WgradPlan& p, WgradA
     return OSSID_OK;
 }
 
-// How many K-splits each problem of a GROUP gets: the group shares the chip, so the target is ~2.5 workgroups per CU
-// over the whole group, shared out in proportion to each problem's work (chunks x tiles).
+// How many K-splits each problem of a GROUP gets: the group shares the chip, so the target is just under two workgroups
+// per CU over the whole group (ONE round of resident workgroups: 640 measured 1 ms slower per step than 500, the second
+// round runs a quarter full), shared out in proportion to each problem's work (chunks x tiles).
 static void group_splits(WgradPlan* plans, int n) {
     double total = 0.0;
     for (int i = 0; i < n; ++i) total += (double)plans[i].n_chunks * plans[i].ntiles;
     for (int i = 0; i < n; ++i) {
         const double share = (double)plans[i].n_chunks * plans[i].ntiles / total;
-        long sp = (long)(640.0 * share / plans[i].ntiles + 0.5);
+        static const double target = getenv("OSSID_WGRAD_GROUP_BLOCKS") ? atof(getenv("OSSID_WGRAD_GROUP_BLOCKS")) : 500.0;
+        long sp = (long)(target * share / plans[i].ntiles + 0.5);
         if (sp < 1) sp = 1;
         if (sp > plans[i].n_chunks) sp = (long)plans[i].n_chunks;
         if (sp > 256) sp = 256;
