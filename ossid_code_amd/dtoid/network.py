@@ -349,7 +349,7 @@ class FusedHead:
         self._fill_derived()
         self.dot3 = P(corr.corr_conv_dot3x3, corr.norm_corr_dot3x3, act=True)
         self.cf = P(corr.cf, corr.nf, act=True)
-        self.seg = [P(getattr(corr, "s%d" % i), getattr(corr, "ns%d" % i), act=True) for i in (1, 2, 3, 4, 5)]
+        self.seg = [P(getattr(corr, "s%d" % i), getattr(corr, "ns%d" % i), act=True, phases=i in (2, 3, 4)) for i in (1, 2, 3, 4, 5)]
         self.tail = ops.SegTail(corr.s5, corr.ns5, corr.seg_final)
         self.cls = [P(getattr(cls, "conv%d" % i), act=True) for i in (1, 2, 3, 4)] + [P(cls.output)]
         self.reg = [P(getattr(reg, "conv%d" % i), act=True) for i in (1, 2, 3, 4)] + [P(reg.output)]

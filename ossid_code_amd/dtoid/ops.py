@@ -236,7 +236,7 @@ class PackedConv:
     neighbours: `pre_bn` (+ReLU) = eval-mode BatchNorm in FRONT of the conv (DenseNet's BN-ReLU-Conv), `act` = ELU and
     `bn` = eval-mode BatchNorm BEHIND it (the head's norm(F.elu(conv(x))))."""
 
-    def __init__(self, conv, bn=None, act=False, pre_bn=None, pre_relu=False):
+    def __init__(self, conv, bn=None, act=False, pre_bn=None, pre_relu=False, phases=False):
         w = conv.weight.detach().float().contiguous()
         _lib.require_cuda(w)
         self.cout, self.cin = int(w.shape[0]), int(w.shape[1])
@@ -257,7 +257,7 @@ class PackedConv:
         # 3x3 layers that may be called behind an exact 2x nearest up-sampling also keep the four PHASE weight sets
         # (2x2 kernels with merged rows / columns, csrc/conv.hip TAPS = 4): 4/9 of the multiply-adds
         self.wpk4 = None
-        if self.taps == 9 and pre_bn is None:
+        if self.taps == 9 and pre_bn is None and phases:      # only the decoder layers behind a 2x up-sampling ask for them
             n4 = _lib.fn("ossid_conv_packed_floats")(self.cout, self.cin, 4)
             self.wpk4 = torch.empty(4 * n4, dtype=torch.float32, device=w.device)
         self.refresh()

@@ -538,7 +538,7 @@ def test_phase_conv_equals_conv_of_2x_upsampled(hiplib, B, Cin, Cout, Hs, Ws):
         bn.running_mean.normal_(0, 0.2)
         bn.running_var.uniform_(0.5, 2.0)
     x = torch.randn(B, Cin, Hs, Ws, device="cuda")
-    pk = ops.PackedConv3x3(conv, bn, act=True)
+    pk = ops.PackedConv3x3(conv, bn, act=True, phases=True)
     assert pk.wpk4 is not None
     xl = x.contiguous(memory_format=torch.channels_last)
     out = torch.empty((B, Cout, 2 * Hs, 2 * Ws), device="cuda").contiguous(memory_format=torch.channels_last)
