@@ -265,10 +265,13 @@ int ossid_conv_pack_weights_dgrad(const float* w, int Cout, int Cin, int taps, f
 
 /* D16  one generic channels-last pass of the training step (rows = B*H*W pixels, `channels` % 4 == 0):
  *     m   = 1 (mask_mode 0) | [mask_scale[c] * x + mask_shift[c] > 0] (1: ReLU behind a folded BatchNorm)
- *           | (x > 0 ? 1 : x + 1) (2: ELU'(v) written in terms of x = ELU(v))
+ *           | (x > 0 ? 1 : x + 1) (2: ELU'(v) written in terms of x = ELU(v)) | [x > 0] (3: ReLU'(v) in terms of x = ReLU(v))
  *     r   = (alpha[c] * g + beta[c] * x + kappa[c]) * m              (NULL alpha/beta/kappa = 1 / 0 / 0)
  *     out = r, or out + r when accumulate != 0                        (out NULL: sums only)
- *     sums[0][c], sums[1][c] = sum over rows of (g*m, g*m*x) (sum_mode 1) or (r, r*x) (sum_mode 2); 0 = none
+ *     sums[0][c], sums[1][c] = sum over rows of (g*m, g*m*x) (sum_mode 1), (r, r*x) (sum_mode 2) or, for BatchNorm batch
+ *           statistics, (g - pivot[c], (g - pivot[c])^2) (sum_mode 3: sums about a per-channel pivot -- the tensor's first
+ *           row -- so that a channel whose spread is small against its mean loses nothing to E[x^2] - E[x]^2; the
+ *           pivot is copied to a third row sums[2][c]); 0 = none
  * Instances: BatchNorm batch statistics (g = x, sum_mode 1: sum x, sum x^2); backward of ELU + BatchNorm statistics
  * (alpha 1, beta/kappa from ossid_bn_fold_bwd, mask 2, sum_mode 2 -> the bias gradient); backward of a folded
  * BatchNorm+ReLU prologue (g = d out of the data gradient, mask 1, alpha = scale, sum_mode 1 -> d shift, d scale);
@@ -285,6 +288,7 @@ typedef struct ossid_chan_op_desc {
     const float* mask_shift;
     float* partials;
     float* sums;
+    const float* pivot;              /* sum_mode 3: [channels] floats the statistics are taken about (row 0 of the tensor) */
     int64_t n_rows;
     int32_t channels, g_stride, x_stride, out_stride, mask_mode, accumulate, sum_mode;
     int32_t sums_row_stride;         /* floats between sums[0][.] and sums[1][.] (0 = channels): lets a layer write the
@@ -298,14 +302,15 @@ int ossid_chan_op(const ossid_chan_op_desc* desc_host, void* stream);
 
 /* D16  training-mode BatchNorm2d (nn.BatchNorm2d in train(), online_learning.py:656) folded into the per-channel affine
  * the NEXT convolution applies while staging its input: from sums = (sum x, sum x^2) over n rows,
- *   (sums[c], sums[sums_row_stride + c]; 0 = C) mean, biased var -> scale = gamma * rstd, shift = beta - mean * scale; running statistics updated in place with
+ *   (sums[c], sums[sums_row_stride + c]; 0 = C; taken about pivot[c] when pivot != NULL: mean = pivot + S1/n,
+ *   var = S2/n - (S1/n)^2) mean, biased var -> scale = gamma * rstd, shift = beta - mean * scale; running statistics updated in place with
  *   `momentum` (unbiased variance), as torch does. Backward: (d scale, d shift) -> d gamma, d beta and the coefficients of
  *   the statistics' own gradient  dx += coef_x[c] * x + coef_1[c]  (= d mean / n + 2 (x - mean) d var / n), which the
  *   producer's ossid_chan_op pass applies (accumulate != 0: += onto coef_x / coef_1, several consumers of one tensor).
  *   n_partials > 0: the two sums (forward: sum x, sum x^2; backward: d shift, d scale) are read as the per-block partials a
  *   deferred ossid_chan_op left in `partials` and combined here, in the same fixed order. */
-int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, const float* partials, int n_partials, int C, double n,
-                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, const float* partials, int n_partials, const float* pivot, int C,
+                      double n, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                       float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, void* stream);
 int ossid_bn_fold_bwd(const float* dscale, const float* dshift, const float* partials, int n_partials, const float* gamma,
                       const float* mean, const float* rstd, int C, double n, float* dgamma, float* dbeta, float* coef_x,
@@ -369,6 +374,23 @@ int ossid_stem_tail_nhwc(const float* x0, const float* kernels, int kernels_batc
 /* D2-D4  nn.MaxPool2d(k, stride, padding, ceil_mode) channels-last (DenseNet pool0: 3, 2, 1; SqueezeNet: 3, 2, 0, ceil). */
 int ossid_maxpool_nhwc(const float* x, int B, int H, int W, int C, int k, int stride, int pad, int ceil_mode, float* out,
                        void* stream);
+
+/* D16  training-side companions of the stem kernels (finetune step, channels-last):
+ * ossid_dw_add_nhwc: out = x + conv2d_dw_group(x, kernels) (network.py:178-179), flip != 0: the taps rotated by 180 degrees
+ *   (= the gradient with respect to x of the same expression applied to the upstream gradient);
+ * ossid_dw_bwd_k_nhwc: dk[b][c][ky][kx] = sum_px g[b][px][c] * x[b][px + tap][c] (gradient with respect to the per-sample
+ *   kernels), per-row-chunk partials in `workspace` (ossid_dw_bwd_k_workspace_floats), summed in a fixed order;
+ * ossid_maxpool_idx_nhwc / ossid_maxpool_bwd_nhwc: nn.MaxPool2d forward that also stores the window position of the
+ *   maximum (uint8, first maximum in (ky, kx) order, as torch) and the backward as a gather over the windows containing
+ *   each input pixel -- no atomics. */
+int ossid_dw_add_nhwc(const float* x, const float* kernels, int kernels_batch_stride, int B, int H, int W, int C, int flip,
+                      float* out, void* stream);
+size_t ossid_dw_bwd_k_workspace_floats(int B, int H, int C);
+int ossid_dw_bwd_k_nhwc(const float* x, const float* g, int B, int H, int W, int C, float* workspace, float* dk, void* stream);
+int ossid_maxpool_idx_nhwc(const float* x, int B, int H, int W, int C, int k, int stride, int pad, int ceil_mode, float* out,
+                           uint8_t* argmax, void* stream);
+int ossid_maxpool_bwd_nhwc(const float* dout, const uint8_t* argmax, int B, int H, int W, int C, int k, int stride, int pad, int Ho,
+                           int Wo, float* dx, void* stream);
 
 /* D12  torch.topk(scores, k) (network.py:555: the 1000 best of the ~570 k (template, anchor) object scores of a frame):
  * values [k] in decreasing order and their int64 indices; equal scores are ordered (and, at the cut, chosen) by increasing

@@ -41,7 +41,7 @@ class WgradDesc(C.Structure):
 class ChanOpDesc(C.Structure):
     """struct ossid_chan_op_desc (include/ossid_hip.h)."""
     _fields_ = [(n, _vp) for n in ("g", "x", "out", "alpha", "beta", "kappa", "mask_scale", "mask_shift", "partials",
-                                   "sums")] + [("n_rows", C.c_int64)] + \
+                                   "sums", "pivot")] + [("n_rows", C.c_int64)] + \
                [(n, C.c_int32) for n in ("channels", "g_stride", "x_stride", "out_stride", "mask_mode", "accumulate",
                                          "sum_mode", "sums_row_stride", "defer_finalize")]
 
@@ -96,7 +96,7 @@ _PROTOS = {
     "ossid_conv_pack_weights_dgrad": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ossid_chan_op_partials": (_i, [C.c_longlong, _i]),
     "ossid_chan_op": (_i, [_vp, _vp]),
-    "ossid_bn_fold_fwd": (_i, [_vp, _i, _vp, _i, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ossid_bn_fold_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_bn_fold_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, C.c_double, _vp, _vp, _vp, _vp, _i, _vp]),
     "ossid_conv_pack_weights_table": (_i, [_vp, _i, C.c_longlong, _vp]),
     "ossid_colsum_finalize": (_i, [_vp, _i, _i, _vp, _i, _vp]),
@@ -108,6 +108,11 @@ _PROTOS = {
     "ossid_im2col_stem": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ossid_stem_tail_nhwc": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ossid_maxpool_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ossid_dw_add_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ossid_dw_bwd_k_workspace_floats": (_sz, [_i, _i, _i]),
+    "ossid_dw_bwd_k_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ossid_maxpool_idx_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ossid_maxpool_bwd_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ossid_topk_workspace_bytes": (_sz, [_i, _i]),
     "ossid_topk": (_i, [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "ossid_nms_workspace_bytes": (_sz, [_i]),

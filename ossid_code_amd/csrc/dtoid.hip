@@ -844,3 +844,204 @@ int ossid_maxpool_nhwc(const float* x, int B, int H, int W, int C, int k, int st
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Training-side companions of the stem kernels above (the finetune step, channels-last):
+//   dw_add_nhwc        y = x + conv2d_dw_group(x, k) with optional 180-degree-rotated taps (= the data gradient:
+//                      dx = g + conv2d_dw_group(g, rot180 k)), no affine, no ReLU
+//   dw_bwd_k_nhwc      dk[b][c][tap] = sum_px g[b][px][c] * x[b][px + tap][c]  (per-chunk partials + fixed-order finalize)
+//   maxpool with argmax index (uint8, position inside the window) and its backward as a gather over the <= ceil(k/s)^2
+//   windows that contain an input pixel (no atomics)
+namespace {
+
+__global__ __launch_bounds__(256) void dw_add_nhwc_kernel(const float4* __restrict__ x, const float* __restrict__ kern, int kern_bs,
+                                                          int H, int W, int C4, int flip, size_t total, float4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int xx = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H), b = (int)(r / H);
+    const float* kk = kern + (size_t)b * kern_bs + (size_t)c4 * 36;
+    float4 acc = x[i];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int y = yy + dy - 1;
+        if (y < 0 || y >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xq = xx + dx - 1;
+            if (xq < 0 || xq >= W) continue;
+            const float4 v = x[(((size_t)b * H + y) * W + xq) * C4 + c4];
+            const int t = flip ? 8 - (dy * 3 + dx) : dy * 3 + dx;
+            acc.x = fmaf(v.x, kk[t], acc.x), acc.y = fmaf(v.y, kk[9 + t], acc.y);
+            acc.z = fmaf(v.z, kk[18 + t], acc.z), acc.w = fmaf(v.w, kk[27 + t], acc.w);
+        }
+    }
+    out[i] = acc;
+}
+
+// grid (row chunks, C4, B); 256 threads stride over the pixels of the chunk; 36 partial sums per thread
+__global__ __launch_bounds__(256) void dw_bwd_k_nhwc_kernel(const float4* __restrict__ x, const float4* __restrict__ g, int H, int W,
+                                                            int C4, int rows_per_chunk, float* __restrict__ partials) {
+    __shared__ float red[4][36];
+    const int chunk = blockIdx.x, c4 = blockIdx.y, b = blockIdx.z;
+    const int y0 = chunk * rows_per_chunk, y1 = min(H, y0 + rows_per_chunk);
+    float s[36];
+#pragma unroll
+    for (int t = 0; t < 36; ++t) s[t] = 0.0f;
+    for (int p = y0 * W + threadIdx.x; p < y1 * W; p += 256) {
+        const int yy = p / W, xx = p - yy * W;
+        const float4 gv = g[(((size_t)b * H + yy) * W + xx) * C4 + c4];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int y = yy + dy - 1;
+            if (y < 0 || y >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xq = xx + dx - 1;
+                if (xq < 0 || xq >= W) continue;
+                const float4 v = x[(((size_t)b * H + y) * W + xq) * C4 + c4];
+                const int t = dy * 3 + dx;
+                s[t] = fmaf(gv.x, v.x, s[t]), s[9 + t] = fmaf(gv.y, v.y, s[9 + t]);
+                s[18 + t] = fmaf(gv.z, v.z, s[18 + t]), s[27 + t] = fmaf(gv.w, v.w, s[27 + t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 36; ++t)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s[t] += __shfl_xor(s[t], m);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int t = 0; t < 36; ++t) red[threadIdx.x >> 6][t] = s[t];
+    __syncthreads();
+    if (threadIdx.x < 36)
+        partials[(((size_t)chunk * gridDim.z + b) * C4 + c4) * 36 + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void dw_bwd_k_finalize_kernel(const float* __restrict__ partials, int chunks, int n,
+                                                                float* __restrict__ dk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;       // n = B * C4 * 36 = B * C * 9 in [b][c][tap] order already
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int c = 0; c < chunks; ++c) s += partials[(size_t)c * n + i];
+    dk[i] = s;
+}
+
+__global__ __launch_bounds__(256) void maxpool_idx_nhwc_kernel(const float4* __restrict__ x, int H, int W, int C4, int k, int stride,
+                                                               int pad, int Ho, int Wo, size_t total, float4* __restrict__ out,
+                                                               uchar4* __restrict__ idx) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int xo = (int)(r % Wo);
+    r /= Wo;
+    const int yo = (int)(r % Ho), b = (int)(r / Ho);
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    unsigned char a[4] = {255, 255, 255, 255};
+    for (int dy = 0; dy < k; ++dy) {
+        const int y = yo * stride - pad + dy;
+        if (y < 0 || y >= H) continue;
+        for (int dx = 0; dx < k; ++dx) {
+            const int xx = xo * stride - pad + dx;
+            if (xx < 0 || xx >= W) continue;
+            const float4 v4 = x[(((size_t)b * H + y) * W + xx) * C4 + c4];
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (v[e] > m[e] || a[e] == 255) m[e] = v[e], a[e] = (unsigned char)(dy * k + dx);   // first maximum wins
+        }
+    }
+    out[i] = make_float4(m[0], m[1], m[2], m[3]);
+    idx[i] = make_uchar4(a[0], a[1], a[2], a[3]);
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_nhwc_kernel(const float4* __restrict__ dout, const uchar4* __restrict__ idx, int H,
+                                                               int W, int C4, int k, int stride, int pad, int Ho, int Wo,
+                                                               size_t total, float4* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int X = (int)(r % W);
+    r /= W;
+    const int Y = (int)(r % H), b = (int)(r / H);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    // windows (yo, xo) that contain (Y, X): yo*stride - pad <= Y < yo*stride - pad + k
+    const int yo_hi = min(Ho - 1, (Y + pad) / stride), xo_hi = min(Wo - 1, (X + pad) / stride);
+    for (int yo = yo_hi; yo >= 0 && yo * stride - pad + k > Y; --yo)
+        for (int xo = xo_hi; xo >= 0 && xo * stride - pad + k > X; --xo) {
+            const unsigned char pos = (unsigned char)((Y - (yo * stride - pad)) * k + (X - (xo * stride - pad)));
+            const size_t o = (((size_t)b * Ho + yo) * Wo + xo) * C4 + c4;
+            const uchar4 a = idx[o];
+            const float4 g = dout[o];
+            if (a.x == pos) s[0] += g.x;
+            if (a.y == pos) s[1] += g.y;
+            if (a.z == pos) s[2] += g.z;
+            if (a.w == pos) s[3] += g.w;
+        }
+    dx[i] = make_float4(s[0], s[1], s[2], s[3]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ossid_dw_add_nhwc(const float* x, const float* kernels, int kernels_batch_stride, int B, int H, int W, int C, int flip,
+                      float* out, void* stream) {
+    if (!x || !kernels || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || kernels_batch_stride < 0) return OSSID_EINVAL;
+    const size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(dw_add_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x, kernels, kernels_batch_stride, H, W, C / 4, flip, total, (float4*)out);
+    return ossid_launch_status();
+}
+
+size_t ossid_dw_bwd_k_workspace_floats(int B, int H, int C) {
+    const int chunks = (H + 7) / 8;
+    return (size_t)chunks * B * C * 9;
+}
+
+int ossid_dw_bwd_k_nhwc(const float* x, const float* g, int B, int H, int W, int C, float* workspace, float* dk, void* stream) {
+    if (!x || !g || !workspace || !dk || B <= 0 || B > 65535 || H <= 0 || W <= 0 || C <= 0 || C % 4 || C / 4 > 65535) return OSSID_EINVAL;
+    const int rows = 8, chunks = (H + rows - 1) / rows;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(dw_bwd_k_nhwc_kernel, dim3(chunks, C / 4, B), dim3(256), 0, s, (const float4*)x, (const float4*)g, H, W, C / 4,
+                       rows, workspace);
+    const int n = B * C * 9;
+    hipLaunchKernelGGL(dw_bwd_k_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)workspace, chunks, n, dk);
+    return ossid_launch_status();
+}
+
+int ossid_maxpool_idx_nhwc(const float* x, int B, int H, int W, int C, int k, int stride, int pad, int ceil_mode, float* out,
+                           uint8_t* argmax, void* stream) {
+    if (!x || !out || !argmax || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || k <= 0 || k > 15 || stride <= 0 || pad < 0 ||
+        2 * pad > k)
+        return OSSID_EINVAL;
+    auto osz = [&](int n) {
+        int o = ceil_mode ? (n + 2 * pad - k + stride - 1) / stride + 1 : (n + 2 * pad - k) / stride + 1;
+        if (ceil_mode && (o - 1) * stride >= n + pad) --o;
+        return o;
+    };
+    const int Ho = osz(H), Wo = osz(W);
+    if (Ho <= 0 || Wo <= 0) return OSSID_EINVAL;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_idx_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x, H, W, C / 4, k, stride, pad, Ho, Wo, total, (float4*)out, (uchar4*)argmax);
+    return ossid_launch_status();
+}
+
+int ossid_maxpool_bwd_nhwc(const float* dout, const uint8_t* argmax, int B, int H, int W, int C, int k, int stride, int pad, int Ho,
+                           int Wo, float* dx, void* stream) {
+    if (!dout || !argmax || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || k <= 0 || stride <= 0 || Ho <= 0 || Wo <= 0)
+        return OSSID_EINVAL;
+    const size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dout, (const uchar4*)argmax, H, W, C / 4, k, stride, pad, Ho, Wo, total, (float4*)dx);
+    return ossid_launch_status();
+}
+
+}  // extern "C"

@@ -29,7 +29,7 @@ __device__ __forceinline__ v16f mfma(float a, float b, v16f c) {
 struct ChanOpArgs {
     const float *g, *x;
     float* out;
-    const float *alpha, *beta, *kappa, *ms, *mt;
+    const float *alpha, *beta, *kappa, *ms, *mt, *pivot;
     long long n_rows;
     int C, g_cs, x_cs, out_cs, mask_mode, accumulate, sum_mode, rows_per_block;
     float* partials;      // [gridDim.y][2][C]
@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void chan_op_kernel(const ChanOpArgs A) {
         return (p && valid) ? *(const float4*)(p + c0) : make_float4(dflt, dflt, dflt, dflt);
     };
     const float4 al = ld4(A.alpha, 1.f), be = ld4(A.beta, 0.f), ka = ld4(A.kappa, 0.f), ms = ld4(A.ms, 1.f),
-                 mt = ld4(A.mt, 0.f);
+                 mt = ld4(A.mt, 0.f), pv4 = ld4(A.pivot, 0.f);
+    const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const long long r0 = (long long)blockIdx.y * A.rows_per_block;
     const long long r1 = r0 + A.rows_per_block < A.n_rows ? r0 + A.rows_per_block : A.n_rows;
@@ -65,10 +66,15 @@ __global__ __launch_bounds__(256) void chan_op_kernel(const ChanOpArgs A) {
                 float m = 1.0f;
                 if (A.mask_mode == 1) m = (ms4[i] * x[i] + mt4[i] > 0.0f) ? 1.0f : 0.0f;
                 else if (A.mask_mode == 2) m = x[i] > 0.0f ? 1.0f : x[i] + 1.0f;
+                else if (A.mask_mode == 3) m = x[i] > 0.0f ? 1.0f : 0.0f;
                 const float gm = g[i] * m;
                 res[i] = (a4[i] * g[i] + b4[i] * x[i] + k4[i]) * m;
                 if (A.sum_mode == 1) s1[i] += gm, s2[i] += gm * x[i];
                 else if (A.sum_mode == 2) s1[i] += res[i], s2[i] += res[i] * x[i];
+                else if (A.sum_mode == 3) {      // statistics about a per-channel pivot: no E[x^2] - E[x]^2 cancellation
+                    const float dlt = g[i] - pv[i];
+                    s1[i] += dlt, s2[i] += dlt * dlt;
+                }
             }
             if (A.out) {
                 float* o = A.out + r * A.out_cs + c0;
@@ -100,7 +106,8 @@ __global__ __launch_bounds__(256) void chan_op_kernel(const ChanOpArgs A) {
 // sums[s][c] = sum over the P row-chunk partials, in a fixed order, accumulated in double. A block owns 64 columns; its
 // four waves each take a quarter of the partials (independent, unrolled loads), the quarters meet in LDS.
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int P, int C,
-                                                              float* __restrict__ sums, int row_stride) {
+                                                              float* __restrict__ sums, int row_stride,
+                                                              const float* __restrict__ pivot) {
     __shared__ double red[4][64];
     const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + col;
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     if (part == 0 && i < C2) {
         const double t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
         sums[i < C ? i : row_stride + (i - C)] = (float)t;
+        if (pivot && i < C) sums[2 * row_stride + i] = pivot[i];      // third row: the pivot the sums are about
     }
 }
 
@@ -166,7 +174,8 @@ __device__ __forceinline__ void column_sums(const float* sums, int row_stride, c
 
 template <int PARTS>
 __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restrict__ sums, int sums_row_stride,
-                                                          const float* __restrict__ partials, int P, int C, double n,
+                                                          const float* __restrict__ partials, int P,
+                                                          const float* __restrict__ pivot, int C, double n,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, float* __restrict__ scale,
@@ -178,8 +187,10 @@ __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restric
     double s0, s1;
     column_sums<PARTS>(sums, sums_row_stride, partials, P, C, c, part, red, s0, s1);
     if (part != 0 || c >= C) return;
-    const double mean = s0 / n;
-    double var = s1 / n - mean * mean;
+    // the sums are about pivot[c] (0 without one): mean = pivot + S1/n, var = S2/n - (S1/n)^2
+    const double dm = s0 / n;
+    const double mean = (pivot ? (double)pivot[c] : 0.0) + dm;
+    double var = s1 / n - dm * dm;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
     const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
@@ -780,13 +791,15 @@ int ossid_chan_op(const ossid_chan_op_desc* d, void* stream) {
     if (!d) return OSSID_EINVAL;
     if (d->n_rows < 0 || d->channels <= 0 || d->channels % 4) return OSSID_EINVAL;
     if (d->n_rows == 0) return OSSID_OK;
-    if (!d->g || (d->mask_mode != 0 && !d->x) || d->mask_mode < 0 || d->mask_mode > 2 || d->sum_mode < 0 || d->sum_mode > 2)
+    if (!d->g || (d->mask_mode != 0 && !d->x) || d->mask_mode < 0 || d->mask_mode > 3 || d->sum_mode < 0 || d->sum_mode > 3)
         return OSSID_EINVAL;
     if (d->sum_mode != 0 && (!d->partials || (!d->sums && !d->defer_finalize))) return OSSID_EINVAL;
     if (!d->out && d->sum_mode == 0) return OSSID_EINVAL;
     ChanOpArgs a;
     a.g = d->g, a.x = d->x, a.out = d->out, a.alpha = d->alpha, a.beta = d->beta, a.kappa = d->kappa;
     a.ms = d->mask_scale, a.mt = d->mask_shift, a.n_rows = d->n_rows, a.C = d->channels;
+    a.pivot = d->pivot;
+    if (d->sum_mode == 3 && !d->pivot) return OSSID_EINVAL;
     a.g_cs = d->g_stride > 0 ? d->g_stride : d->channels;
     a.x_cs = d->x_stride > 0 ? d->x_stride : d->channels;
     a.out_cs = d->out_stride > 0 ? d->out_stride : d->channels;
@@ -805,24 +818,25 @@ int ossid_chan_op(const ossid_chan_op_desc* d, void* stream) {
     if (rc != OSSID_OK || d->sum_mode == 0 || d->defer_finalize) return rc;
     const int C2 = 2 * d->channels;
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C2 + 63) / 64), dim3(256), 0, s, (const float*)d->partials, P,
-                       d->channels, d->sums, d->sums_row_stride > 0 ? d->sums_row_stride : d->channels);
+                       d->channels, d->sums, d->sums_row_stride > 0 ? d->sums_row_stride : d->channels,
+                       d->sum_mode == 3 ? d->pivot : nullptr);
     return ossid_launch_status();
 }
 
-int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, const float* partials, int n_partials, int C, double n,
-                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, const float* partials, int n_partials, const float* pivot, int C,
+                      double n, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                       float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, void* stream) {
     if ((!sums && n_partials <= 0) || (n_partials > 0 && !partials) || C <= 0 || n <= 0 || !scale || !shift || !mean_out ||
         !rstd_out || (!running_mean != !running_var))
         return OSSID_EINVAL;
     if (n_partials > 64)
         hipLaunchKernelGGL(bn_fold_fwd_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, sums,
-                           sums_row_stride > 0 ? sums_row_stride : C, partials, n_partials, C, n, gamma, beta, eps, momentum,
-                           running_mean, running_var, scale, shift, mean_out, rstd_out);
+                           sums_row_stride > 0 ? sums_row_stride : C, partials, n_partials, pivot, C, n, gamma, beta, eps,
+                           momentum, running_mean, running_var, scale, shift, mean_out, rstd_out);
     else
         hipLaunchKernelGGL(bn_fold_fwd_kernel<4>, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, sums,
-                           sums_row_stride > 0 ? sums_row_stride : C, partials, n_partials, C, n, gamma, beta, eps, momentum,
-                           running_mean, running_var, scale, shift, mean_out, rstd_out);
+                           sums_row_stride > 0 ? sums_row_stride : C, partials, n_partials, pivot, C, n, gamma, beta, eps,
+                           momentum, running_mean, running_var, scale, shift, mean_out, rstd_out);
     return ossid_launch_status();
 }
 

@@ -691,6 +691,47 @@ class Network(nn.Module):
 
     # finetune forward/backward on the hand-written kernels (train_ops.py); False = the nn.Module path (MIOpen)
     use_hip_training = os.environ.get("OSSID_TRAIN_IMPL", "hip") != "miopen"
+    # The 7x7 stem + norm0 + pool0 and the two SqueezeNet encoders ALSO have a training path on this repo's kernels
+    # (train_ops: im2col + 1x1 MFMA conv / wgrad, DwXcorrAdd, MaxPoolNHWC, bn_act_train; tested against the module path),
+    # but measured on one box (10 steps each, hipGraph replay) it is slower than torch / MIOpen on these few-channel,
+    # pass-dominated layers: 47.7 ms (both on torch) vs 48.3 (stem) / 48.0 (encoders) / 48.6 (both). Off by default.
+    use_hip_stem_training = os.environ.get("OSSID_TRAIN_STEM", "0") != "0"
+    use_hip_template_training = os.environ.get("OSSID_TRAIN_TEMPLATES", "0") != "0"
+
+    def _template_encoder_train_hip(self, mod, img):
+        """A SqueezeNet template encoder (TemplateFeatExtract / ...Global) in training mode on this repo's kernels,
+        channels-last: stem as im2col + 1x1 conv, Fire modules as FusedConv with ReLU epilogues, max-pools with argmax
+        indices, the training BatchNorms as column sums + fold + one generic pass, the valid 3x3 convs of the global
+        branch as padded convolutions whose interior is kept."""
+        from . import train_ops as T
+        stem = mod.backbone_0[0]
+        x = T.FusedConv.apply(ops.im2col_stem(img, 3, 2, 0, 48), T.relaid_stem_weight(stem, 48), stem.bias, None, None, False,
+                              2, None, False)
+
+        def run(part, x):
+            for m in part:
+                if isinstance(m, nn.MaxPool2d):
+                    x = T.MaxPoolNHWC.apply(x, m.kernel_size, m.stride, m.padding, m.ceil_mode)
+                elif isinstance(m, nn.ReLU):
+                    continue
+                else:
+                    sq = T.fused_conv(x, m.squeeze, act=2)
+                    x = torch.cat([T.fused_conv(sq, m.expand1x1, act=2), T.fused_conv(sq, m.expand3x3, act=2)], 1)
+            return x
+        x1 = run(mod.backbone_1, x)
+        x2 = run(mod.backbone_2, x1)
+        x1n, x2n = T.bn_act_train(x1, mod.norm_1), T.bn_act_train(x2, mod.norm_2)
+        xf = torch.cat([x2n, _bilinear_resize(x1n, x2.size(3))], dim=1)
+        if hasattr(mod, "final_conv_1"):
+            for conv, bn in ((mod.final_conv_1, mod.final_norm_1), (mod.final_conv_2, mod.final_norm_2)):
+                u = T.fused_conv(xf, conv, act=1)[:, :, 1:-1, 1:-1]          # valid 3x3 = interior of the padded conv
+                xf = T.bn_act_train(u, bn)
+        ts = mod.__dict__.get("_folded_bn_counters")
+        if ts is None:
+            ts = mod.__dict__["_folded_bn_counters"] = [b.num_batches_tracked for b in mod.modules()
+                                                        if isinstance(b, nn.BatchNorm2d)]
+        torch._foreach_add_(ts, 1)
+        return xf
 
     def _forward_train_hip(self, image, g, local):
         """Training-mode forward of everything behind the two template encoders on csrc/conv.hip + csrc/train.hip,
@@ -700,13 +741,21 @@ class Network(nn.Module):
         from .backbones import DenseBlock, Transition
         ife = self.image_feature_extractor
         self._train_pack_plan().run()                            # every conv weight -> MFMA layouts, one launch
-        x0 = ife.backdense_0(image)
-        x0 = x0 + ops.dw_xcorr(x0, g)
         seq = list(ife.backdense_1) + list(ife.backdense_2)      # norm0 relu0 pool0 block1 | trans1 block2 ... norm5
-        x = x0
-        for m in seq[:3]:                                        # stem: 64 channels at 240x320, on torch
-            x = m(x)
-        x = T.nhwc(x)
+        if self.use_hip_stem_training:
+            # stem on this repo's kernels, channels-last from the first one: im2col -> 1x1 MFMA conv (weight gradient
+            # by the same 1x1 wgrad kernel), template modulation, training BatchNorm + ReLU, max-pool
+            conv0 = ife.backdense_0[0]
+            x0 = T.FusedConv.apply(ops.im2col_stem(image, 7, 2, 3, 160), T.relaid_stem_weight(conv0, 160), conv0.bias, None,
+                                   None, False, 0, None, False)
+            x = T.MaxPoolNHWC.apply(T.bn_act_train(T.DwXcorrAdd.apply(x0, g), seq[0], relu=True), 3, 2, 1, False)
+        else:
+            x0 = ife.backdense_0(image)
+            x0 = x0 + ops.dw_xcorr(x0, g)
+            x = x0
+            for m in seq[:3]:                                    # stem: 64 channels at 240x320, on torch
+                x = m(x)
+            x = T.nhwc(x)
         norm5 = None
         for m in seq[3:]:
             if isinstance(m, DenseBlock):
@@ -725,7 +774,8 @@ class Network(nn.Module):
         # the folded BatchNorms update running_mean / running_var in their kernel; the counters in one launch
         ts = self.__dict__.get("_folded_bn_counters")
         if ts is None:
-            ts = [b.num_batches_tracked for m in seq[3:] + [ife.n1] for b in m.modules() if isinstance(b, nn.BatchNorm2d)]
+            folded = seq[3:] + [ife.n1] + ([seq[0]] if self.use_hip_stem_training else [])
+            ts = [b.num_batches_tracked for m in folded for b in m.modules() if isinstance(b, nn.BatchNorm2d)]
             self.__dict__["_folded_bn_counters"] = ts
         torch._foreach_add_(ts, 1)
         return out
@@ -804,9 +854,16 @@ class Network(nn.Module):
     def forward(self, image, template, template_mask, global_template, global_template_mask):
         """(B,3,H,W), (B,3,h,w), (B,1,h,w), (B,3,h,w), (B,1,h,w) ->
         classifications [B,A,2], regression [B,A,4], anchors [1,A,4], heat_map [B,1,hh,hw], segmentation [B,1,H,W]"""
-        g = self.template_feature_extractor_global(torch.cat([global_template, global_template_mask], dim=1))
-        local = self.template_feature_extractor(torch.cat([template, template_mask], dim=1))
-        if image.is_cuda and self.training and torch.is_grad_enabled() and self.use_hip_training:
+        hip_train = image.is_cuda and self.training and torch.is_grad_enabled() and self.use_hip_training
+        if hip_train and self.use_hip_template_training:
+            g = self._template_encoder_train_hip(self.template_feature_extractor_global,
+                                                 torch.cat([global_template, global_template_mask], dim=1))
+            local = self._template_encoder_train_hip(self.template_feature_extractor,
+                                                     torch.cat([template, template_mask], dim=1))
+        else:
+            g = self.template_feature_extractor_global(torch.cat([global_template, global_template_mask], dim=1))
+            local = self.template_feature_extractor(torch.cat([template, template_mask], dim=1))
+        if hip_train:
             return self._forward_train_hip(image, g, local)
         if image.is_cuda and not self.training and not torch.is_grad_enabled() and self.use_fused_head:
             # inference on (image, template) PAIRS (BASELINE configs[2] (ii)): backbone and head on csrc/conv.hip

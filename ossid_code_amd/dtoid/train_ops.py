@@ -65,7 +65,8 @@ def _scratch(name, nbytes, device):
 
 # ---- raw ops (no autograd) --------------------------------------------------------------------------------------------
 def chan_op(g, n_rows, C, x=None, out=None, g_cs=0, x_cs=0, out_cs=0, alpha=None, beta=None, kappa=None, mask_mode=0,
-            mask_scale=None, mask_shift=None, accumulate=False, sum_mode=0, sums=None, sums_row_stride=0, defer=False):
+            mask_scale=None, mask_shift=None, accumulate=False, sum_mode=0, sums=None, sums_row_stride=0, defer=False,
+            pivot=None):
     """include/ossid_hip.h ossid_chan_op on raw channels-last buffers (tensors only provide pointers; a tensor that is a
     channel slice of a wider buffer is passed as its first-element pointer + the buffer's channel count as stride).
     Returns `sums` ([2, C] float32, allocated when sum_mode != 0 and none was given). defer=True: the column sums stay
@@ -75,6 +76,7 @@ def chan_op(g, n_rows, C, x=None, out=None, g_cs=0, x_cs=0, out_cs=0, alpha=None
     dev = g.device
     d.g, d.x, d.out = g.data_ptr(), _p(x), _p(out)
     d.alpha, d.beta, d.kappa, d.mask_scale, d.mask_shift = _p(alpha), _p(beta), _p(kappa), _p(mask_scale), _p(mask_shift)
+    d.pivot = _p(pivot)
     d.n_rows, d.channels, d.g_stride, d.x_stride, d.out_stride = int(n_rows), int(C), int(g_cs), int(x_cs), int(out_cs)
     d.mask_mode, d.accumulate, d.sum_mode, d.sums_row_stride = int(mask_mode), 1 if accumulate else 0, int(sum_mode), int(sums_row_stride)
     if sum_mode:
@@ -85,12 +87,20 @@ def chan_op(g, n_rows, C, x=None, out=None, g_cs=0, x_cs=0, out_cs=0, alpha=None
             sums = (part, P)
         else:
             if sums is None:
-                sums = torch.empty((2, C), dtype=torch.float32, device=dev)
+                sums = torch.empty((3 if sum_mode == 3 else 2, C), dtype=torch.float32, device=dev)
             d.partials = _scratch("chan", P * 2 * C * 4, dev).data_ptr()
             d.sums = sums.data_ptr()
     with torch.cuda.device(dev):
         _lib.check(_lib.fn("ossid_chan_op")(_byref(d), _lib.stream()), "ossid_chan_op")
     return sums
+
+
+def batch_stats(x_flat, n_rows, C, cs=0, sums=None, sums_row_stride=0, defer=False):
+    """Column sums of a channels-last tensor (or channel slice: pointer to its first element + channel stride) for a
+    training BatchNorm, taken about the tensor's FIRST ROW as pivot (sum_mode 3): [3, C] = (sum (x - p), sum (x - p)^2, p).
+    defer=True: (partials, P, pivot pointer tensor) for bn_fold_fwd to finish."""
+    res = chan_op(x_flat, n_rows, C, g_cs=cs, sum_mode=3, pivot=x_flat, sums=sums, sums_row_stride=sums_row_stride, defer=defer)
+    return res + (x_flat,) if defer else res
 
 
 class _Packed:
@@ -264,15 +274,22 @@ def wgrad_group(items):
         _lib.check(_lib.fn("ossid_conv_wgrad_group")(arr, n, ws.data_ptr(), nbytes, _lib.stream()), "ossid_conv_wgrad_group")
 
 
-def bn_fold_fwd(sums, C, n, gamma, beta, eps, momentum, running_mean, running_var, sums_row_stride=0):
-    """sums: a [2, C] tensor (or a pointer into a wider table, with sums_row_stride), or the (scratch, P) pair of a deferred
-    chan_op. Returns [4, C] = scale, shift, mean, rstd."""
-    part, P = (sums if isinstance(sums, tuple) else (None, 0))
-    dev = part.device if part is not None else sums.device
+def bn_fold_fwd(sums, C, n, gamma, beta, eps, momentum, running_mean, running_var, sums_row_stride=0, pivot=None):
+    """sums: a [2 or 3, C] tensor (third row = pivot) or a pointer into a wider table (sums_row_stride; pivot given
+    separately), or the (scratch, P, pivot) triple of a deferred batch_stats. Returns [4, C] = scale, shift, mean, rstd."""
+    part, P = None, 0
+    if isinstance(sums, tuple):
+        part, P = sums[0], sums[1]
+        pivot = sums[2] if len(sums) > 2 else pivot
+        dev = part.device
+    else:
+        dev = sums.device
+        if pivot is None and sums.dim() == 2 and sums.shape[0] == 3:
+            pivot = sums[2]
     out = torch.empty((4, C), dtype=torch.float32, device=dev)          # scale, shift, mean, rstd
     with torch.cuda.device(dev):
         rc = _lib.fn("ossid_bn_fold_fwd")(None if part is not None else sums.data_ptr(), int(sums_row_stride), _p(part), int(P),
-                                          C, float(n), _p(gamma), _p(beta), float(eps),
+                                          _p(pivot), C, float(n), _p(gamma), _p(beta), float(eps),
                                           float(momentum), _p(running_mean), _p(running_var), out[0].data_ptr(),
                                           out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _lib.stream())
     _lib.check(rc, "ossid_bn_fold_fwd")
@@ -322,15 +339,17 @@ def upsample_bwd(dup, B, Hs, Ws, H, W, C):
 
 # ---- autograd Functions -----------------------------------------------------------------------------------------------
 class ColStats(torch.autograd.Function):
-    """x [B,C,H,W] channels-last -> sums [2,C] = (sum x, sum x^2) over B*H*W. The gradient arriving on `sums` is, by the
-    private convention shared with BNFold, g[0] = d/d(sum x), g[1] = 2 * d/d(sum x^2), so dx = g[0][c] + g[1][c] * x."""
+    """x [B,C,H,W] channels-last -> stats [3,C] = (sum (x - p), sum (x - p)^2, p) over B*H*W with p = x's first row (the
+    pivot: a channel whose spread is small against its mean loses nothing to E[x^2] - E[x]^2). The gradient arriving on
+    `stats` is, by the private convention shared with BNFold, g[0] = d/d(mean) / n-form constant term, g[1] = the
+    coefficient of x: dx = g[0][c] + g[1][c] * x (g[2] is ignored: mean and variance do not depend on the pivot)."""
 
     @staticmethod
     def forward(ctx, x):
         x = nhwc(x)
         B, C, H, W = x.shape
         ctx.save_for_backward(x)
-        return chan_op(x, B * H * W, C, x=x, sum_mode=1)
+        return batch_stats(flat(x), B * H * W, C)
 
     @staticmethod
     def backward(ctx, g):
@@ -338,8 +357,8 @@ class ColStats(torch.autograd.Function):
         B, C, H, W = x.shape
         g = g.contiguous()
         dx = torch.empty_like(x)
-        ones_zero = torch.zeros(C, dtype=torch.float32, device=x.device)
-        chan_op(x, B * H * W, C, x=x, out=dx, alpha=ones_zero, beta=g[1], kappa=g[0])
+        zero = torch.zeros(C, dtype=torch.float32, device=x.device)
+        chan_op(x, B * H * W, C, x=x, out=dx, alpha=zero, beta=g[1], kappa=g[0])
         return dx
 
 
@@ -365,7 +384,7 @@ class BNFold(torch.autograd.Function):
         g = g.contiguous()
         res = torch.empty((4, C), dtype=torch.float32, device=out.device)      # dgamma, dbeta, coef_x, coef_1
         bn_fold_bwd(g[0], g[1], gamma, out[2], out[3], C, ctx.n, res[0], res[1], res[2], res[3])
-        dsums = torch.stack([res[3], res[2]])      # ColStats convention: [d/d sum x, 2 d/d sum x^2]
+        dsums = torch.stack([res[3], res[2], torch.zeros_like(res[2])])      # ColStats convention: [constant, x coefficient, -]
         return dsums, res[0], res[1], None, None
 
 
@@ -390,12 +409,13 @@ class FusedConv(torch.autograd.Function):
         H, W = (Hs, Ws) if size is None else (int(size[0]), int(size[1]))
         pre = None if pre_scale is None else (pre_scale.contiguous(), pre_shift.contiguous())
         u = empty_nhwc(B, Cout, H, W, x.device)
+        act = int(act_elu)                       # 0 none, 1 ELU, 2 ReLU (True = ELU: the head's `F.elu(conv(x))`)
         conv_raw(x, _pack(w, "fwd"), B, H, W, Cin, Cout, taps, u, bias=None if bias is None else bias.detach(), pre=pre,
-                 pre_relu=pre_relu, act=1 if act_elu else 0, src_hw=(Hs, Ws) if size is not None else (0, 0))
-        sums = chan_op(u, B * H * W, Cout, x=u, sum_mode=1) if want_stats else None
-        ctx.save_for_backward(x, w, u if (act_elu or want_stats) else None, None if pre is None else pre[0],
+                 pre_relu=pre_relu, act=act, src_hw=(Hs, Ws) if size is not None else (0, 0))
+        sums = batch_stats(flat(u), B * H * W, Cout) if want_stats else None
+        ctx.save_for_backward(x, w, u if (act or want_stats) else None, None if pre is None else pre[0],
                               None if pre is None else pre[1])
-        ctx.cfg = (pre_relu, act_elu, (H, W), want_stats, bias is not None)
+        ctx.cfg = (pre_relu, act, (H, W), want_stats, bias is not None)
         if want_stats:
             return u, sums
         return u
@@ -417,7 +437,7 @@ class FusedConv(torch.autograd.Function):
             dv = torch.empty_like(du) if (act_elu or use_stats) else None
             sums = chan_op(du, N, Cout, x=u if (act_elu or use_stats) else None, out=dv,
                            beta=dsums[1].contiguous() if use_stats else None,
-                           kappa=dsums[0].contiguous() if use_stats else None, mask_mode=2 if act_elu else 0,
+                           kappa=dsums[0].contiguous() if use_stats else None, mask_mode=(0, 2, 3)[act_elu],
                            sum_mode=2 if (has_bias and need[2]) else 0)
             if dv is None:
                 dv = du
@@ -449,10 +469,12 @@ class FusedConv(torch.autograd.Function):
         return dx, dw, db, dps, dpt, None, None, None, None
 
 
-def fused_conv(x, conv, pre=None, pre_relu=False, act_elu=False, size=None, want_stats=False):
-    """Apply an nn.Conv2d (3x3 / pad 1 or 1x1, stride 1) through FusedConv. pre = (scale, shift) or None."""
+def fused_conv(x, conv, pre=None, pre_relu=False, act_elu=False, size=None, want_stats=False, act=None):
+    """Apply an nn.Conv2d (3x3 / pad 1 or 1x1, stride 1) through FusedConv. pre = (scale, shift) or None; act: 0 none,
+    1 ELU, 2 ReLU (act_elu=True is act=1)."""
     ps, pt = (None, None) if pre is None else pre
-    return FusedConv.apply(x, conv.weight, conv.bias, ps, pt, bool(pre_relu), bool(act_elu), size, bool(want_stats))
+    a = int(act) if act is not None else (1 if act_elu else 0)
+    return FusedConv.apply(x, conv.weight, conv.bias, ps, pt, bool(pre_relu), a, size, bool(want_stats))
 
 
 class AvgPool2(torch.autograd.Function):
@@ -502,31 +524,31 @@ class DenseBlockTrain(torch.autograd.Function):
         N = B * H * W
         buf = empty_nhwc(B, Ct, H, W, dev)
         buf[:, :C0] = x
-        table = torch.empty((2, Ct), dtype=torch.float32, device=dev)
-        chan_op(buf, N, C0, x=buf, g_cs=Ct, x_cs=Ct, sum_mode=1, sums=table, sums_row_stride=Ct)
+        table = torch.empty((3, Ct), dtype=torch.float32, device=dev)      # (sum (x-p), sum (x-p)^2, p) per channel
+        batch_stats(flat(buf), N, C0, cs=Ct, sums=table, sums_row_stride=Ct)
         layers = list(block.values())
         saved = []
         c = C0
         for li, layer in enumerate(layers):
             g1, b1, w1, g2, b2, w2 = params[6 * li:6 * li + 6]
             f1 = bn_fold_fwd(table, c, N, g1, b1, layer.norm1.eps, _mom(layer.norm1), layer.norm1.running_mean,
-                             layer.norm1.running_var, sums_row_stride=Ct)
+                             layer.norm1.running_var, sums_row_stride=Ct, pivot=table[2])
             mid = int(w1.shape[0])
             y1 = empty_nhwc(B, mid, H, W, dev)
             # 1x1 with the batch statistics of its output summed in the epilogue; 3x3 likewise for the 32 new channels
             s2 = conv_raw(buf, _pack(w1, "fwd"), B, H, W, c, mid, 1, y1, pre=(f1[0], f1[1]), pre_relu=True, in_cs=Ct,
                           epi=dict(sum_mode=2) if FUSE_STATS else None)
             if not FUSE_STATS:
-                s2 = chan_op(y1, N, mid, x=y1, sum_mode=1, defer=True)
+                s2 = batch_stats(flat(y1), N, mid, defer=True)
             f2 = bn_fold_fwd(s2, mid, N, g2, b2, layer.norm2.eps, _mom(layer.norm2), layer.norm2.running_mean,
                              layer.norm2.running_var)
             s3 = conv_raw(y1, _pack(w2, "fwd"), B, H, W, mid, growth, 9, buf, pre=(f2[0], f2[1]), pre_relu=True, out_cs=Ct,
                           out_coff=c, epi=dict(sum_mode=2) if FUSE_STATS else None)
-            if FUSE_STATS:
+            if FUSE_STATS:     # (the epilogue sums are about 0: the opt-in fused path keeps the plain E[x^2] - E[x]^2 form)
                 colsum_finalize(s3, growth, table.view(-1)[c:], sums_row_stride=Ct)
+                table[2, c:c + growth].zero_()
             else:
-                new = flat(buf, c)
-                chan_op(new, N, growth, x=new, g_cs=Ct, x_cs=Ct, sum_mode=1, sums=table.view(-1)[c:], sums_row_stride=Ct)
+                batch_stats(flat(buf, c), N, growth, cs=Ct, sums=table.view(-1)[c:], sums_row_stride=Ct)
             saved.append((f1, y1, f2))
             c += growth
         ctx.block, ctx.saved, ctx.buf, ctx.params, ctx.C0 = block, saved, buf, params, C0
@@ -596,6 +618,117 @@ class DenseBlockTrain(torch.autograd.Function):
         dx = G[:, :C0].contiguous(memory_format=torch.channels_last)
         ctx.saved = ctx.buf = None
         return (dx, None) + tuple(grads)
+
+
+class DwXcorrAdd(torch.autograd.Function):
+    """y = x + conv2d_dw_group(x, k) (network.py:178-179) on a channels-last x [B,C,H,W], k [B,C,3,3]."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        x = nhwc(x)
+        B, C, H, W = x.shape
+        k = k.float().contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.fn("ossid_dw_add_nhwc")(x.data_ptr(), k.data_ptr(), C * 9 if k.shape[0] > 1 else 0, B, H, W, C, 0,
+                                                    out.data_ptr(), _lib.stream()), "ossid_dw_add_nhwc")
+        ctx.save_for_backward(x, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, k = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = nhwc(g)
+        dx = dk = None
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _lib.check(_lib.fn("ossid_dw_add_nhwc")(g.data_ptr(), k.data_ptr(), C * 9 if k.shape[0] > 1 else 0, B, H, W, C, 1,
+                                                        dx.data_ptr(), _lib.stream()), "ossid_dw_add_nhwc")
+            if ctx.needs_input_grad[1]:
+                ws = _scratch("dwk", _lib.fn("ossid_dw_bwd_k_workspace_floats")(B, H, C) * 4, x.device)
+                dkb = torch.empty((B, C, 3, 3), dtype=torch.float32, device=x.device)
+                _lib.check(_lib.fn("ossid_dw_bwd_k_nhwc")(x.data_ptr(), g.data_ptr(), B, H, W, C, ws.data_ptr(), dkb.data_ptr(),
+                                                          _lib.stream()), "ossid_dw_bwd_k_nhwc")
+                dk = dkb if k.shape[0] > 1 else dkb.sum(0, keepdim=True)
+        return dx, dk
+
+
+class MaxPoolNHWC(torch.autograd.Function):
+    """nn.MaxPool2d(k, stride, pad, ceil_mode) on a channels-last tensor; the argmax window position is kept as uint8."""
+
+    @staticmethod
+    def forward(ctx, x, k, stride, pad, ceil_mode):
+        x = nhwc(x)
+        B, C, H, W = x.shape
+
+        def osz(n):
+            o = -(-(n + 2 * pad - k) // stride) + 1 if ceil_mode else (n + 2 * pad - k) // stride + 1
+            return o - 1 if ceil_mode and (o - 1) * stride >= n + pad else o
+        Ho, Wo = osz(H), osz(W)
+        out = empty_nhwc(B, C, Ho, Wo, x.device)
+        idx = torch.empty(B * Ho * Wo * C, dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.fn("ossid_maxpool_idx_nhwc")(x.data_ptr(), B, H, W, C, k, stride, pad, 1 if ceil_mode else 0,
+                                                         out.data_ptr(), idx.data_ptr(), _lib.stream()), "ossid_maxpool_idx_nhwc")
+        ctx.save_for_backward(idx)
+        ctx.cfg = (B, C, H, W, k, stride, pad, Ho, Wo)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, C, H, W, k, stride, pad, Ho, Wo = ctx.cfg
+        g = nhwc(g)
+        dx = empty_nhwc(B, C, H, W, g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.fn("ossid_maxpool_bwd_nhwc")(g.data_ptr(), idx.data_ptr(), B, H, W, C, k, stride, pad, Ho, Wo,
+                                                         dx.data_ptr(), _lib.stream()), "ossid_maxpool_bwd_nhwc")
+        return dx, None, None, None, None
+
+
+class AffineAct(torch.autograd.Function):
+    """y = relu?(x * scale[c] + shift[c]) materialised (a training BatchNorm whose consumer is not a convolution: in front
+    of a max-pool, a bilinear resize, a concatenation). One generic pass forward, one backward (with the (d shift, d scale)
+    sums)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, relu):
+        x = nhwc(x)
+        B, C, H, W = x.shape
+        scale, shift = scale.contiguous(), shift.contiguous()
+        y = torch.empty_like(x)
+        chan_op(x, B * H * W, C, x=x, out=y, alpha=scale, kappa=shift, mask_mode=1 if relu else 0, mask_scale=scale,
+                mask_shift=shift)
+        ctx.save_for_backward(x, scale, shift)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, scale, shift = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = nhwc(g)
+        dx = torch.empty_like(x)
+        s = chan_op(g, B * H * W, C, x=x, out=dx, alpha=scale, mask_mode=1 if ctx.relu else 0, mask_scale=scale,
+                    mask_shift=shift, sum_mode=1)
+        return dx, s[1], s[0], None
+
+
+def bn_act_train(x, bn, relu=False):
+    """Training-mode BatchNorm (+ReLU) with a materialised output, on this repo's passes: column sums -> fold -> apply."""
+    B, C, H, W = x.shape
+    scale, shift = bn_fold(ColStats.apply(x), B * H * W, bn)
+    return AffineAct.apply(x, scale, shift, bool(relu))
+
+
+def relaid_stem_weight(conv, kpad):
+    """[Cout, Cin, k, k] -> [Cout, kpad, 1, 1] in ossid_im2col_stem's column order (differentiable torch ops)."""
+    w = conv.weight
+    cout = w.shape[0]
+    flat = w.permute(0, 2, 3, 1).reshape(cout, -1)
+    return torch.nn.functional.pad(flat, (0, kpad - flat.shape[1])).reshape(cout, kpad, 1, 1).contiguous()
 
 
 def dense_block_train(x, block):

@@ -844,3 +844,21 @@ def test_template_encoders_and_stem_on_own_kernels_match_module_path(hiplib):
             "lmask": (torch.rand(1, 4, 1, 124, 124) > 0.5).float().cuda()}
     out = m.forwardTestTime(test)
     assert out["pred_bbox"].shape[1] == 4 and "_fused_tfe_local" in m.model.__dict__
+
+
+@pytest.mark.gpu
+def test_finetune_step_with_stem_and_template_encoders_on_own_kernels(hiplib):
+    """The opt-in all-own-kernels training path (stem + both SqueezeNet encoders too): same loss as the default path on
+    the first step, finite and decreasing afterwards."""
+    cfg = dtoid.DtoidConfig()
+    losses = {}
+    for own in (False, True):
+        torch.manual_seed(4)
+        m = dtoid.DtoidNet(cfg).cuda().train()
+        m.model.use_hip_stem_training = m.model.use_hip_template_training = own
+        flat = finetune.FlatParams(m)
+        opt = finetune.FusedAMSGrad(flat, lr=1e-4, weight_decay=1e-6)
+        batch = _batch(cfg, 2, "cuda", seed=3)
+        losses[own] = [float(finetune.finetune_step(m, batch, opt)) for _ in range(3)]
+    assert abs(losses[True][0] - losses[False][0]) <= 2e-4 * abs(losses[False][0])
+    assert all(np.isfinite(losses[True])) and losses[True][-1] < losses[True][0]

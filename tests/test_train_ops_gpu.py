@@ -71,6 +71,13 @@ def test_chan_op_sums_only_and_strided_sum_table(hiplib):
     (1, 32, 16, 48, 64, 9, 0, 0, True, (23, 31)),      # ... behind a non-integer one
     (3, 512, 640, 7, 9, 1, 0, 0, True, None),
     (1, 768, 512, 29, 39, 9, 0, 0, False, None),
+    (8, 128, 32, 15, 15, 1, 0, 0, False, None),        # SqueezeNet Fire squeeze convs (pixel count no multiple of 32)
+    (8, 256, 48, 7, 7, 1, 0, 0, False, None),
+    (8, 64, 16, 30, 30, 1, 0, 0, False, None),
+    (8, 32, 128, 15, 15, 9, 0, 0, False, None),        # ... and expand convs (few input channels)
+    (8, 16, 64, 30, 30, 9, 0, 0, False, None),
+    (8, 48, 192, 7, 7, 1, 0, 0, False, None),
+    (2, 160, 64, 24, 32, 1, 0, 0, False, None),        # the 7x7 stem as a 1x1 conv on im2col rows
 ])
 def test_wgrad_matches_torch(hiplib, B, Cin, Cout, H, W, taps, in_extra, dy_extra, pre, up):
     g = torch.Generator().manual_seed(Cin + Cout + H)
@@ -224,3 +231,127 @@ def test_dense_block_training_path_matches_module_path(hiplib, L, C0, B, H, W, f
     for (n, b), q in zip(blk.named_buffers(), ref.buffers()):
         if b.dtype.is_floating_point:
             assert rel(b, q) < 1e-4, n
+
+
+def test_stem_training_pieces_match_torch_autograd(hiplib):
+    """x + conv2d_dw_group(x, k) (both gradients), channels-last max-pool with argmax indices (3/2/1 and 3/2/0 ceil) and
+    the materialised training BatchNorm+ReLU against torch autograd."""
+    from oracle import dtoid_oracle
+    torch.manual_seed(5)
+    x = torch.randn(2, 16, 21, 27, device="cuda")
+    k = torch.randn(2, 16, 3, 3, device="cuda") * 0.3
+    go = torch.randn(2, 16, 21, 27, device="cuda")
+    xr, kr = x.clone().requires_grad_(True), k.clone().requires_grad_(True)
+    (xr + dtoid_oracle.dw_xcorr(xr, kr)).backward(go)
+    xm, km = x.clone().requires_grad_(True), k.clone().requires_grad_(True)
+    y = T.DwXcorrAdd.apply(xm, km)
+    y.backward(go)
+    assert rel(y, x + dtoid_oracle.dw_xcorr(x, k)) < 1e-5 and rel(xm.grad, xr.grad) < 1e-5 and rel(km.grad, kr.grad) < 1e-4
+    for kk, st, pd, ceil in ((3, 2, 1, False), (3, 2, 0, True)):
+        xr = x.clone().requires_grad_(True)
+        yr = F.max_pool2d(xr, kk, st, pd, ceil_mode=ceil)
+        g2 = torch.randn_like(yr)
+        yr.backward(g2)
+        xm = x.clone().requires_grad_(True)
+        ym = T.MaxPoolNHWC.apply(xm, kk, st, pd, ceil)
+        ym.backward(g2)
+        assert torch.equal(ym, yr) and rel(xm.grad, xr.grad) < 1e-6
+    bn = torch.nn.BatchNorm2d(16).cuda().train()
+    with torch.no_grad():
+        bn.weight.normal_(1, 0.3)
+        bn.bias.normal_(0, 0.3)
+    import copy
+    rbn = copy.deepcopy(bn)
+    xr = x.clone().requires_grad_(True)
+    F.relu(rbn(xr)).backward(go)
+    xm = x.clone().requires_grad_(True)
+    T.bn_act_train(xm, bn, relu=True).backward(go)
+    assert rel(xm.grad, xr.grad) < 2e-4 and rel(bn.weight.grad, rbn.weight.grad) < 2e-4 and rel(bn.bias.grad, rbn.bias.grad) < 2e-4
+    assert rel(bn.running_var, rbn.running_var) < 1e-5
+
+
+def test_template_encoder_training_path_matches_module_path(hiplib):
+    """Both SqueezeNet template encoders in training mode on this repo's kernels (8 templates of 124 x 124, as in a
+    finetune batch), against a float64 run of the module on the CPU; this path must be as close to it as the nn.Module
+    GPU path (MIOpen, Winograd 3x3) is, within a factor. The 7 x 7 squeeze layers hold only 8 x 48 x 49 pre-activations
+    and a single one within float32 rounding of zero flips its ReLU decision, which moves one bias gradient by several
+    per cent (measured: seed 9, features.10.squeeze, 1 element of 18816, every other value equal to 4e-7) -- in either
+    float32 path. A kernel fault is systematic, a flipped kink is not: three seeds, at most one may show such a flip."""
+    import copy
+    from ossid_code_amd import dtoid
+    flipped = []
+    for seed in (9, 10, 11):
+        torch.manual_seed(seed)
+        net = dtoid.Network(img_size=(480, 640), heatmap_size=(29, 39)).cuda().train()
+        ref = copy.deepcopy(net)
+        tm = torch.rand(8, 4, 124, 124, device="cuda")
+        bad = []
+        for name in ("template_feature_extractor", "template_feature_extractor_global"):
+            mod, rmod = getattr(net, name), getattr(ref, name)
+            r64 = copy.deepcopy(rmod).double().cpu()
+            out64 = r64(tm.double().cpu())
+            go = torch.randn_like(out64)
+            out64.backward(go)
+            out = net._template_encoder_train_hip(mod, tm)
+            outr = rmod(tm)
+            out.backward(go.float().cuda())
+            outr.backward(go.float().cuda())
+            assert out.shape == outr.shape and rel(out, out64) < max(2e-4, 3 * rel(outr, out64)), (seed, name)
+            for (n, p), q, q64 in zip(mod.named_parameters(), rmod.parameters(), r64.parameters()):
+                if q64.grad is None:
+                    assert p.grad is None, n
+                else:
+                    mine, theirs = rel(p.grad, q64.grad), rel(q.grad, q64.grad)
+                    if not mine < max(1e-3, 3 * theirs):
+                        bad.append((name, n, mine, theirs))
+            for (n, b), q in zip(mod.named_buffers(), r64.buffers()):
+                assert (rel(b, q) < 1e-4) if b.dtype.is_floating_point else torch.equal(b.cpu(), q), (seed, name, n)
+        if bad:
+            flipped.append((seed, bad))
+    assert len(flipped) <= 1, flipped
+
+
+@pytest.mark.parametrize("cin,sq,e,hw", [(64, 16, 64, 30), (128, 16, 64, 30), (128, 32, 128, 15), (256, 32, 128, 15), (256, 48, 192, 7),
+                                         (384, 48, 192, 7), (384, 64, 256, 7), (512, 64, 256, 7)])
+def test_fire_module_on_fused_convs_matches_torch_autograd(hiplib, cin, sq, e, hw):
+    """One SqueezeNet Fire module (squeeze 1x1 -> ReLU -> expand 1x1 | 3x3 -> ReLU -> cat) at every configuration the
+    template encoders use, through FusedConv with ReLU epilogues: output, input gradient, all six parameter gradients."""
+    import copy
+    torch.manual_seed(cin + sq)
+    fire = backbones.Fire(cin, sq, e, e).cuda()
+    ref = copy.deepcopy(fire)
+    x = torch.randn(8, cin, hw, hw, device="cuda")
+    go = torch.randn(8, 2 * e, hw, hw, device="cuda")
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(go)
+    xm = x.clone().requires_grad_(True)
+    s = T.fused_conv(xm, fire.squeeze, act=2)
+    y = torch.cat([T.fused_conv(s, fire.expand1x1, act=2), T.fused_conv(s, fire.expand3x3, act=2)], 1)
+    y.backward(go)
+    assert rel(y, yr) < 2e-5 and rel(xm.grad, xr.grad) < 2e-4
+    for (n, p), q in zip(fire.named_parameters(), ref.parameters()):
+        assert rel(p.grad, q.grad) < 5e-4, (n, rel(p.grad, q.grad))
+
+
+def test_batch_statistics_survive_a_large_mean_with_a_small_spread(hiplib):
+    """A channel at 100 +- 0.01 (or 0.5 +- 1e-3, a nearly dead ReLU channel): E[x^2] - E[x]^2 in float32 would lose the
+    variance entirely; the pivoted sums of ossid_chan_op (sum_mode 3) + ossid_bn_fold_fwd keep it. Forward output and the
+    input gradient of a training BatchNorm against float64."""
+    import copy
+    torch.manual_seed(3)
+    x = torch.randn(4, 8, 30, 40, device="cuda")
+    x[:, 0] = 100.0 + 0.01 * x[:, 0]
+    x[:, 1] = 0.5 + 1e-3 * x[:, 1]
+    x[:, 2] = -3000.0 + x[:, 2]
+    bn = torch.nn.BatchNorm2d(8).cuda().train()
+    r64 = copy.deepcopy(bn).double().cpu()
+    a = x.clone().requires_grad_(True)
+    y = T.bn_act_train(a, bn)
+    c = x.double().cpu().requires_grad_(True)
+    y64 = r64(c)
+    go = torch.randn_like(y64)
+    y.backward(go.float().cuda())
+    y64.backward(go)
+    assert rel(y, y64) < 2e-3 and rel(bn.running_var, r64.running_var) < 1e-3      # (the inputs themselves carry ~1e-7 * 100 / 0.01)
+    assert rel(bn.weight.grad, r64.weight.grad) < 5e-3
