@@ -38,7 +38,8 @@ def build_lib(force=False, verbose=False):
     """Compile every HIP source into ossid_code_amd/libossid_hip.so; returns its path."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [_hipcc()] + FLAGS + ["-o", LIB_PATH + ".tmp"] + sources()
+    extra = os.environ.get("OSSID_HIPCC_EXTRA", "").split()       # A/B builds of ablation switches (-DOSSID_...)
+    cmd = [_hipcc()] + FLAGS + extra + ["-o", LIB_PATH + ".tmp"] + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

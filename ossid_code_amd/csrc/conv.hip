@@ -35,6 +35,17 @@ __device__ __forceinline__ v16f mfma(float a, float b, v16f c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+#ifndef OSSID_WPF
+#define OSSID_WPF 1
+#endif
+// Optional float4 of padding per patch position (a wave's ds_read_b128 takes the same channel quad of 32 consecutive
+// positions: a lane stride of KCH*4 bytes). A/B on the GPU (round 2): 0 and 1 time the same within noise on every layer
+// of tools/train_layers_bench.py and on both DTOID legs -- the loop is not LDS-bound -- so the default stays 0.
+// Likewise OSSID_WPF (weight prefetch distance in groups): 1, 2 and 3 time the same; the main loop's MFMA pipe is
+// 74-89 % busy at the clock the part actually holds under this load (1.95-2.03 GHz, tools/conv_timeline.py).
+#ifndef OSSID_LDS_PAD
+#define OSSID_LDS_PAD 0
+#endif
 #ifndef OSSID_MEDIUM_WGS
 #define OSSID_MEDIUM_WGS 600
 #endif
@@ -71,14 +82,36 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     constexpr int WN = 4 / (WM * WK);
     constexpr int BPX = WN * NT * 32;
     constexpr int F4 = KCH / 4;                 // float4 per patch position
+    constexpr int F4P = F4 + OSSID_LDS_PAD;     // ... and its stride in LDS
     constexpr int NKB = KCH / 8 / WK;           // 8-channel blocks of a chunk handled by one wave
     constexpr int KY = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1);   // prefetch groups per channel block (one kernel row each)
     constexpr int GQ = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : (NKB >= 2 ? 2 : 1));   // weight quads per prefetch group
     constexpr int GPC = TAPS == 9 ? NKB * 3 : (TAPS == 4 ? NKB * 2 : NKB / GQ);   // groups per chunk per wave
     static_assert(WM * WK * WN == 4 && KCH % (8 * WK) == 0 && 256 % F4 == 0, "bad tiling");
-    extern __shared__ __attribute__((aligned(16))) float4 patch[];   // [2][buf_pos][F4]
+    extern __shared__ __attribute__((aligned(16))) float4 patch[];   // [2][buf_pos][F4P]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
     const int wm = wave % WM, wk = (wave / WM) % WK, wn = wave / (WM * WK);
+#ifdef OSSID_TIMING   // diagnostic build only (tools/conv_timeline.py): per-wave s_memrealtime stamps (100 MHz, one clock for the whole chip) + HW_ID go to e_partials
+    auto tnow = []() {
+        unsigned long long t;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+        return t;
+    };
+    auto cnow = []() {                                   // shader-clock counter (per XCD origin: differences only)
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+        return t;
+    };
+    unsigned long long tstamp[4] = {tnow(), 0, 0, 0}, cstamp[2] = {0, 0};
+    auto tdump = [&]() {
+        if (lane == 0 && A.e_partials) {
+            unsigned long long* o = (unsigned long long*)A.e_partials + ((size_t)blockIdx.x * 4 + wave) * 6;
+            o[0] = tstamp[0], o[1] = tstamp[1], o[2] = tstamp[2], o[3] = tstamp[3];
+            o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+            o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) | ((cstamp[1] - cstamp[0]) << 8);   // XCC_ID | loop cycles
+        }
+    };
+#endif
     // ---- logical block (bx, by, b) from the 1-D launch id, XCD-aware ------------------------------------------------
     // Workgroup ids go round-robin over the 8 XCDs, each with a private 4 MB L2. The packed weights of ONE channel-tile
     // group (WM x 32 output channels x Cin x taps: 2.9 MB for 640->256, 3.5 MB for 768->512) fit there, those of the
@@ -161,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
             const int sx = (A.Ws == W) ? xx : min((int)floorf((float)xx * A.scale_w), A.Ws - 1);
             goff[e] = ok ? ((sy * A.Ws + sx) * A.in_cs + 4 * j) : -1;
         }
-        lidx[e] = pos < npos ? idx : -1;
+        lidx[e] = pos < npos ? pos * F4P + j : -1;
     }
 
     // this lane's pixel in each of its NT tiles: patch position of tap (0,0), output pixel index (or -1)
@@ -236,7 +269,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     auto stage_write = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < NLD; ++e)
-            if (lidx[e] >= 0) patch[(size_t)buf * A.buf_pos * F4 + lidx[e]] = st[e];
+            if (lidx[e] >= 0) patch[(size_t)buf * A.buf_pos * F4P + lidx[e]] = st[e];
     };
 
     // weight quads of prefetch group gi (a per-wave linear counter over (chunk, channel block, kernel row))
@@ -258,10 +291,19 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     const int nchunks = (A.Cin + KCH - 1) / KCH;
     stage_load(0);
     stage_write(0);
-    float4 cur[GQ], nxt[GQ];
+    // weight quads ride PF prefetch groups ahead of their MFMAs in a register ring (loads return in issue order, so
+    // a wait on a weight quad also waits for every staging load issued before it: PF groups of MFMAs cover both)
+    constexpr int PF = OSSID_WPF;
+    float4 wq[PF + 1][GQ];
 #pragma unroll
-    for (int i = 0; i < GQ; ++i) cur[i] = W4[(size_t)quad_of(0, i) * 64];
+    for (int d = 0; d < PF; ++d)
+#pragma unroll
+        for (int i = 0; i < GQ; ++i) wq[d][i] = W4[(size_t)quad_of(d, i) * 64];
     __syncthreads();
+#ifdef OSSID_TIMING
+    tstamp[1] = tnow();
+    cstamp[0] = cnow();
+#endif
 
     int gi = 0;
 #pragma unroll 1
@@ -269,16 +311,18 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
 #ifndef OSSID_ABL_NOSTAGE
         if (ch + 1 < nchunks) stage_load((ch + 1) * KCH);     // in flight under this chunk's MFMAs
 #endif
-        const float4* pb = patch + (size_t)(ch & 1) * A.buf_pos * F4 + h;
+        const float4* pb = patch + (size_t)(ch & 1) * A.buf_pos * F4P + h;
 #pragma unroll
         for (int g = 0; g < GPC; ++g) {
 #pragma unroll
 #ifndef OSSID_ABL_NOW
-            for (int i = 0; i < GQ; ++i) nxt[i] = W4[(size_t)quad_of(gi + 1, i) * 64];
+            for (int i = 0; i < GQ; ++i) wq[PF][i] = W4[(size_t)quad_of(gi + PF, i) * 64];
 #else
-            for (int i = 0; i < GQ; ++i) nxt[i] = cur[i];
+            for (int i = 0; i < GQ; ++i) wq[PF][i] = wq[0][i];
 #endif
+#ifndef OSSID_ABL_NOFENCE
             __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int i = 0; i < GQ; ++i) {
                 // (a workgroup's spare waves -- channel tiles past the last -- run the same MFMAs on tile 0's weights and
@@ -286,11 +330,11 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
                 // matrix-pipe drain around every group)
                 const int kb = wk * NKB + (TAPS == 9 ? g / 3 : (TAPS == 4 ? g / 2 : g * GQ + i));   // 8-channel block inside the chunk
                 const int toff = TAPS == 9 ? (g % 3) * PW + i : (TAPS == 4 ? (ph_a + g % 2) * PW + ph_b + i : 0);
-                const float4 a = cur[i];
+                const float4 a = wq[0][i];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
 #ifndef OSSID_ABL_NOB
-                    const float4 bq = pb[(size_t)(pos0[t] + toff) * F4 + 2 * kb];
+                    const float4 bq = pb[(size_t)(pos0[t] + toff) * F4P + 2 * kb];
 #else
                     const float4 bq = make_float4(a.y, a.x, a.w, a.z);
 #endif
@@ -300,15 +344,23 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
                     acc[t] = mfma(a.w, bq.w, acc[t]);
                 }
             }
+#ifndef OSSID_ABL_NOFENCE
             __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
-            for (int i = 0; i < GQ; ++i) cur[i] = nxt[i];
+            for (int d = 0; d < PF; ++d)
+#pragma unroll
+                for (int i = 0; i < GQ; ++i) wq[d][i] = wq[d + 1][i];
             ++gi;
         }
         if (ch + 1 < nchunks) stage_write((ch + 1) & 1);
         __syncthreads();
     }
     (void)KY;
+#ifdef OSSID_TIMING
+    cstamp[1] = cnow();
+    tstamp[2] = tnow();
+#endif
 
     // ---- split-K: the WK partial tiles meet in LDS (fixed summation order), each wave then finishes 4/WK register quads
     if (WK > 1) {
@@ -331,6 +383,9 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
             }
     }
 
+#ifdef OSSID_TIMING
+    if (!active) { tstamp[3] = tnow(); tdump(); return; }
+#endif
     if (!active) return;
     // ---- epilogue: (ELU) -> (per-channel affine) -> [training extras] -> 16-byte stores --------------------------------
     // Training extras (one pass less over the output each): v = the value so far, a = aux[pixel][channel]
@@ -420,6 +475,11 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
             }
         }
     }
+#ifdef OSSID_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    tstamp[3] = tnow();
+    tdump();
+#endif
     if (EPI && A.e_sum) {
         // Sum over the 32 pixels (lanes) of each half-wave as a butterfly REDUCE-SCATTER: at each of four steps a lane
         // hands half of its remaining values to its partner and adds the partner's to the half it keeps (8+4+2+1
@@ -497,7 +557,7 @@ int launch_conv(ConvArgs a, int B, hipStream_t s) {
     }
     a.buf_pos = rows * PW;
     if (a.buf_pos * F4 > NLD * 256) return OSSID_EINVAL;
-    size_t lds = (size_t)2 * a.buf_pos * KCH * 4;
+    size_t lds = (size_t)2 * a.buf_pos * (F4 + OSSID_LDS_PAD) * 16;
     const size_t red = WK > 1 ? (size_t)WK * (WM * WN) * NT * 16 * 64 * 4 : 0;
     if (red > lds) lds = red;
     const bool epi = (a.e_mask | a.e_acc | a.e_sum) != 0;

@@ -220,6 +220,8 @@ def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_rel
             rows = B * (H + 4) * ((W + 31) // 32) + 8      # upper bound over every tiling the dispatcher may pick
             part = _scratch("conv_partials", rows * 2 * cout * 4, out.device)
             d.epi_partials, d.epi_partials_rows = part.data_ptr(), rows
+        if epi.get("timing_buf") is not None:           # -DOSSID_TIMING diagnostic builds only (tools/conv_timeline.py)
+            d.epi_partials, d.epi_partials_rows = epi["timing_buf"].data_ptr(), 1 << 30
     with torch.cuda.device(out.device):
         _lib.check(_lib.fn("ossid_conv_nhwc_fwd")(_byref(d), _lib.stream()), "ossid_conv_nhwc_fwd")
         if part is not None:
