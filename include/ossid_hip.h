@@ -204,6 +204,17 @@ size_t ossid_conv_packed_floats(int Cout, int Cin, int taps);
 int ossid_conv_pack_weights(const float* w, int Cout, int Cin, int taps, float* wpk, void* stream);
 int ossid_conv_nhwc_fwd(const ossid_conv_desc* desc_host, void* stream);
 
+/* D6-D8 / D16  the same 3x3 convolution (stride 1, pad 1; ossid_conv_desc with taps = 9, no fused up-sampling, no
+ * training extras) as Winograd F(2x2, 3x3): 16 multiplies per 2x2 output tile and channel pair instead of 36, f32
+ * throughout (csrc/wino.hip; results differ from ossid_conv_nhwc_fwd by rounding only). Stands behind the same nn.Conv2d
+ * layers (network.py:102-110, :135-143, :288-326) and their data gradients in the finetune step. desc->wpk must be the
+ * layout of ossid_conv_pack_weights_wino: U = G g G^T of w [Cout][Cin][3][3]; dgrad != 0 packs the data gradient's layer
+ * (Cin output channels, Cout reduction channels, filter rotated by 180 degrees; the desc then carries cin = Cout,
+ * cout = Cin). The reduction channel count must be a multiple of 16. */
+size_t ossid_conv_wino_packed_floats(int Cout, int Cin);
+int ossid_conv_pack_weights_wino(const float* w, int Cout, int Cin, int dgrad, float* wpk, void* stream);
+int ossid_conv3x3_wino_fwd(const ossid_conv_desc* desc_host, void* stream);
+
 /* D6 (tail)  the last two layers of the segmentation decoder in one launch (network.py:357-362):
  *   out[b][y][x] = b2 + conv3x3_{16->1}( post( ELU( b1 + conv3x3_{32->16}( nearest_upsample(x -> [H][W]) ) ) ) )
  * x [B][src_height][src_width][in_channel_stride] channels-last (the first 32 channels are read); w1p =
@@ -322,7 +333,7 @@ int ossid_colsum_finalize(const float* partials, int n_partials, int C, float* s
 
 /* D16  all convolution weights of a training step re-packed in ONE launch (they change every optimizer step): a device
  * table with one row per (layer, layout): kind 0 = the forward layout of ossid_conv_pack_weights, 1 = the data-gradient
- * layout of ossid_conv_pack_weights_dgrad; first_block = prefix sum of ceil(packed float4 / 256) over the rows before. */
+ * layout of ossid_conv_pack_weights_dgrad, 2 / 3 = ossid_conv_pack_weights_wino with dgrad = 0 / 1 (taps = 9); first_block = prefix sum of ceil(packed float4 / 256) over the rows before. */
 typedef struct ossid_pack_row {
     const float* w;
     float* wpk;

@@ -94,6 +94,9 @@ _PROTOS = {
     "ossid_conv_wgrad_group_workspace_bytes": (_sz, [_vp, _i]),
     "ossid_conv_wgrad_group": (_i, [_vp, _i, _vp, _sz, _vp]),
     "ossid_conv_pack_weights_dgrad": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "ossid_conv_wino_packed_floats": (C.c_size_t, [_i, _i]),
+    "ossid_conv_pack_weights_wino": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "ossid_conv3x3_wino_fwd": (_i, [_vp, _vp]),
     "ossid_chan_op_partials": (_i, [C.c_longlong, _i]),
     "ossid_chan_op": (_i, [_vp, _vp]),
     "ossid_bn_fold_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -38,6 +38,36 @@ static inline int ossid_ensure_dyn_lds(const void* fn, size_t bytes, OssidLdsAtt
         if (rc_ != OSSID_OK) return rc_;                                          \
     } while (0)
 
+// Winograd F(2x2, 3x3) filter transform U = G g G^T (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]) for the packed layout of
+// csrc/wino.hip, [ceil(M/32)][K/8][16 xi][64 lanes][4]: element i -> lane (c,h) of (mt, kb, xi) holds
+// U_xi[32mt+c][8kb+4h+0..3]. w is the forward weight [Cout][Cin][3][3]; dgrad != 0 packs the data gradient's layer
+// (M = Cin output channels, K = Cout reduction channels, filter rotated by 180 degrees).
+__device__ __forceinline__ float4 ossid_wino_pack_quad(const float* __restrict__ w, int Cout, int Cin, int dgrad, size_t i) {
+    const int lane = (int)(i & 63);
+    size_t r = i >> 6;
+    const int xi = (int)(r & 15);
+    r >>= 4;
+    const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout, KB = K / 8;
+    const int kb = (int)(r % KB), mt = (int)(r / KB);
+    const int m = mt * 32 + (lane & 31), k0 = kb * 8 + 4 * (lane >> 5);
+    const int ti = xi >> 2, tj = xi & 3;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = 0.0f;
+        if (m >= M) continue;
+        const float* g = dgrad ? w + ((size_t)(k0 + e) * Cin + m) * 9 : w + ((size_t)m * Cin + k0 + e) * 9;
+        float t[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const float g0 = dgrad ? g[8 - b] : g[b], g1 = dgrad ? g[5 - b] : g[3 + b], g2 = dgrad ? g[2 - b] : g[6 + b];
+            t[b] = ti == 0 ? g0 : (ti == 1 ? 0.5f * (g0 + g1 + g2) : (ti == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+        }
+        v[e] = tj == 0 ? t[0] : (tj == 1 ? 0.5f * (t[0] + t[1] + t[2]) : (tj == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2]));
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // 64-lane wave reductions (xor butterfly; every lane ends with the result)
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll

@@ -348,7 +348,7 @@ struct PackRow {
     const float* w;
     float4* wpk;
     long long first_block;      // prefix sum of blocks (256 float4 each)
-    int Cout, Cin, taps, kind;  // kind 0: forward layout, 1: data-gradient layout
+    int Cout, Cin, taps, kind;  // kind 0: forward layout, 1: data-gradient layout, 2 / 3: their Winograd forms
 };
 
 __global__ __launch_bounds__(256) void pack_all_kernel(const PackRow* __restrict__ table, int n_rows) {
@@ -360,6 +360,11 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackRow* __restrict
     }
     const PackRow R = table[lo];
     const size_t i = (size_t)(b - R.first_block) * 256 + threadIdx.x;
+    if (R.kind >= 2) {      // Winograd layouts (csrc/wino.hip): 16 transform positions per (channel tile, 8-channel block)
+        const int K8 = (R.kind == 2 ? R.Cin : R.Cout) / 8, M32 = ((R.kind == 2 ? R.Cout : R.Cin) + 31) / 32;
+        if (i < (size_t)M32 * K8 * 16 * 64) R.wpk[i] = ossid_wino_pack_quad(R.w, R.Cout, R.Cin, R.kind == 3, i);
+        return;
+    }
     const int KB = (R.kind == 0 ? R.Cin : R.Cout) / 8;
     const int MT = ((R.kind == 0 ? R.Cout : R.Cin) + 31) / 32;
     const size_t total = (size_t)MT * KB * R.taps * 64;

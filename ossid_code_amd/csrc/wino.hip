@@ -1,0 +1,339 @@
+// 3x3 (stride 1, pad 1) convolutions as Winograd F(2x2, 3x3) on the f32 matrix cores (gfx950), channels-last.
+//
+// Same layers and the same fused prologue / epilogue as csrc/conv.hip (the dense 3x3 nn.Conv2d layers of DTOID's head,
+// /root/reference/python/ossid/models/dtoid/network.py:102-110, :135-143, :288-326, and their data gradients in the
+// finetune step, scripts/online_learning.py:650-679), at 16 multiplies per 2x2 output tile and channel pair instead of
+// 36: the direct kernel's main loop runs the MFMA pipe 74-89 % busy at the 1.95-2.03 GHz the part holds under this load
+// (tools/conv_timeline.py), so the remaining lever on these layers is the multiply count, not the schedule.
+//
+//   Y = A^T [ sum_ci (G g G^T) o (B^T d B) ] A      d = 4x4 input patch, g = 3x3 filter, Y = 2x2 outputs
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// GEMM view: for each of the 16 transform positions xi = (i, j):  M_xi[co][tile] = sum_ci U_xi[co][ci] * V_xi[ci][tile],
+// v_mfma_f32_32x32x2_f32 with output channels on M, 32 tiles on N (lane & 31). All arithmetic f32 (the transforms only
+// add, subtract and halve); results differ from the direct kernel by rounding only (tests: <= 2e-5 of the output scale).
+//   - U = G g G^T is computed when the weights are packed (ossid_conv_pack_weights_wino; layout
+//     [ceil(Cout/32)][Cin/8][16 xi][64 lanes][4]: lane (c,h) holds U_xi[32mt+c][8kb+4h+0..3]), streamed from L2 with a
+//     two-deep register pipeline as in conv.hip
+//   - V = B^T d B: a workgroup owns 32 tiles (a run of the flattened (image, tile row, tile column) index) x 64 output
+//     channels. Each thread loads the three patch rows its half of the transform needs for one (tile, channel quad) of a
+//     16-channel chunk (12 x 16-byte loads, fused input affine (+ReLU) applied to real pixels), transforms in registers
+//     and writes 8 float4 to LDS [16 xi][32 tiles][4 quads], double buffered; next chunk's loads fly under the MFMAs
+//   - waves: 2 channel tiles x 2 halves of xi (rows i in {0,1} / {2,3}): 8 accumulators of 16 registers per wave. The
+//     halves of A^T M A meet in LDS after the loop: each wave keeps one output row of its tiles, gives the other away
+//   - epilogue as conv.hip: bias -> ELU / ReLU -> per-channel affine -> 16-byte stores
+// Cin must be a multiple of 16; odd H / W: the last tile row / column computes outputs that are not stored.
+#include <stddef.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ v16f mfma(float a, float b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+struct WinoArgs {
+    const float* x;
+    const float4* wpk;
+    const float *bias, *bn_scale, *bn_shift, *pre_scale, *pre_shift;
+    float* out;
+    int H, W, Cin, Cout, n_cotiles, act, in_cs, out_cs, out_coff, pre_relu, pre_bs;
+    long long in_bs;
+    int TH, TW, T;     // tiles per image (rows, columns), tiles in the batch
+    int gx, gy;        // groups of 32 tiles, groups of 2 channel tiles
+};
+
+constexpr int KCH = 16, F4 = 4, VBUF = 16 * 32 * F4;      // float4 per LDS buffer
+
+__global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float4 vb[];   // [2][16 xi][32 tiles][4 quads]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int wm = wave & 1, wx = wave >> 1;
+    // ---- logical block (bx = tile group, by = channel group) from the 1-D launch id, XCD-aware as in conv.hip: every
+    // XCD streams the transformed weights of ONE channel group (64 x Cin x 16 floats: 2.6 MB at Cin = 640) through its L2
+    int bx, by;
+    {
+        const int L = blockIdx.x, P = A.gx;
+        int pt;
+        if (A.gy <= 8 && (8 % A.gy) == 0) {
+            const int k = L & 7, R = 8 / A.gy, per = (P + R - 1) / R;
+            by = k % A.gy;
+            pt = (L >> 3) < per ? (k / A.gy) * per + (L >> 3) : P;
+        } else if ((A.gy & 7) == 0) {
+            const int j = L >> 3;
+            by = (L & 7) + 8 * (j / P);
+            pt = j % P;
+        } else {
+            by = L % A.gy;
+            pt = L / A.gy;
+        }
+        if (pt >= P) return;
+        bx = pt;
+    }
+    const int H = A.H, W = A.W, TPI = A.TH * A.TW;
+
+    // ---- staging role: (tile tl, channel quad j, transform half ih) -> 3 patch rows x 4 columns ------------------
+    const int j = tid & 3, tl = (tid >> 2) & 31, ih = tid >> 7;
+    int gbase = 0;              // float offset of patch element (row ih, column 0), possibly outside the image
+    unsigned gmask = 0;         // bit r*4+cc: that element is a real pixel
+    const float* xb = A.x;
+    const float *psb = A.pre_scale, *ptb = A.pre_shift;
+    {
+        const int gt = bx * 32 + tl;
+        const bool tv = gt < A.T;
+        const int b = tv ? gt / TPI : 0, rem = tv ? gt - b * TPI : 0, ty = rem / A.TW, tx = rem - ty * A.TW;
+        xb += (size_t)b * A.in_bs;
+        if (psb) psb += (size_t)b * A.pre_bs, ptb += (size_t)b * A.pre_bs;
+        gbase = ((2 * ty - 1 + ih) * W + 2 * tx - 1) * A.in_cs + 4 * j;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int yy = 2 * ty - 1 + ih + r, xx = 2 * tx - 1 + cc;
+                if (tv && yy >= 0 && yy < H && xx >= 0 && xx < W) gmask |= 1u << (r * 4 + cc);
+            }
+    }
+    const int rstride = W * A.in_cs;
+    float4 st[3][4];
+    auto stage_load = [&](int ci0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+                st[r][cc] = (gmask >> (r * 4 + cc)) & 1 ? *(const float4*)(xb + (ptrdiff_t)(gbase + r * rstride + cc * A.in_cs + ci0))
+                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (psb) {      // affine (+ReLU) of the INPUT on real pixels only: the zero padding stays zero
+            const float4 ps = *(const float4*)(psb + ci0 + 4 * j), pt = *(const float4*)(ptb + ci0 + 4 * j);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    if (!((gmask >> (r * 4 + cc)) & 1)) continue;
+                    float4 v = st[r][cc];
+                    v.x = v.x * ps.x + pt.x, v.y = v.y * ps.y + pt.y, v.z = v.z * ps.z + pt.z, v.w = v.w * ps.w + pt.w;
+                    if (A.pre_relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                    st[r][cc] = v;
+                }
+        }
+    };
+    // rows of B^T d for this half (loaded patch rows p, q, s = rows ih, ih+1, ih+2 of d), then the column transform
+    auto transform_write = [&](int buf) {
+        float4* o = vb + (size_t)buf * VBUF + (size_t)tl * F4 + j;
+#ifdef OSSID_WABL_NOTRANSFORM
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[(size_t)(8 * ih + k) * 32 * F4] = st[k % 3][k & 3];
+        return;
+#endif
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float4 R[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const float4 p = st[0][cc], q = st[1][cc], s = st[2][cc];
+                if (ih == 0) R[cc] = k == 0 ? f4sub(p, s) : f4add(q, s);     // i = 0: d0 - d2;  i = 1: d1 + d2
+                else R[cc] = k == 0 ? f4sub(q, p) : f4sub(p, s);             // i = 2: d2 - d1;  i = 3: d1 - d3
+            }
+            const int i = 2 * ih + k;
+            o[(size_t)(i * 4 + 0) * 32 * F4] = f4sub(R[0], R[2]);
+            o[(size_t)(i * 4 + 1) * 32 * F4] = f4add(R[1], R[2]);
+            o[(size_t)(i * 4 + 2) * 32 * F4] = f4sub(R[2], R[1]);
+            o[(size_t)(i * 4 + 3) * 32 * F4] = f4sub(R[1], R[3]);
+        }
+    };
+
+    // ---- MFMA role: channel tile wm of the group, transform rows i in {2wx, 2wx+1}, the group's 32 tiles -----------
+    const int co_tile = by * 2 + wm;
+    const bool active = co_tile < A.n_cotiles;
+    const int nq = (A.Cin / 8) * 16;                              // weight quads per channel tile
+    const float4* W4 = A.wpk + (size_t)(active ? co_tile : 0) * nq * 64 + lane;
+    // prefetch group gi = (chunk, 8-channel block kb, half xh of the wave's 8 positions): 4 quads, 16 MFMAs
+    auto quad_of = [&](int gi, int i) {
+        const int q = ((gi >> 1) * 16) + 8 * wx + 4 * (gi & 1) + i;
+        return q < nq ? q : nq - 1;
+    };
+    v16f acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[e][r] = 0.0f;
+
+    const int nchunks = A.Cin / KCH;
+    stage_load(0);
+    transform_write(0);
+    float4 cur[4], nxt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur[i] = W4[(size_t)quad_of(0, i) * 64];
+    __syncthreads();
+
+    int gi = 0;
+#pragma unroll 1
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch + 1 < nchunks) stage_load((ch + 1) * KCH);         // in flight under this chunk's MFMAs
+        const float4* pb = vb + (size_t)(ch & 1) * VBUF + (size_t)(8 * wx * 32 + c) * F4 + h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int kb = g >> 1, xh = g & 1;
+#pragma unroll
+#ifndef OSSID_WABL_NOW
+            for (int i = 0; i < 4; ++i) nxt[i] = W4[(size_t)quad_of(gi + 1, i) * 64];
+#else
+            for (int i = 0; i < 4; ++i) nxt[i] = cur[i];
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * xh + i;
+                const float4 a = cur[i];
+                const float4 bq = pb[(size_t)e * 32 * F4 + 2 * kb];
+                acc[e] = mfma(a.x, bq.x, acc[e]);
+                acc[e] = mfma(a.y, bq.y, acc[e]);
+                acc[e] = mfma(a.z, bq.z, acc[e]);
+                acc[e] = mfma(a.w, bq.w, acc[e]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+            ++gi;
+        }
+        if (ch + 1 < nchunks) transform_write((ch + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- output transform. M[i][j] = acc[(i - 2wx) * 4 + j]. S = this half's share of A^T M (rows a = 0, 1), then
+    // P[a][b] = (S A)[a][b]; the wave keeps row a = wx and hands row 1 - wx to its partner through LDS (V is dead).
+    v16f keep[2], give[2];
+    {
+        v16f S0[4], S1[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (wx == 0) S0[jj] = acc[jj] + acc[4 + jj], S1[jj] = acc[4 + jj];           // rows 0, 1: (M0 + M1, M1)
+            else S0[jj] = acc[jj], S1[jj] = -acc[jj] - acc[4 + jj];                     // rows 2, 3: (M2, -M2 - M3)
+        }
+        const v16f P00 = S0[0] + S0[1] + S0[2], P01 = S0[1] - S0[2] - S0[3];
+        const v16f P10 = S1[0] + S1[1] + S1[2], P11 = S1[1] - S1[2] - S1[3];
+        if (wx == 0) keep[0] = P00, keep[1] = P01, give[0] = P10, give[1] = P11;
+        else keep[0] = P10, keep[1] = P11, give[0] = P00, give[1] = P01;
+    }
+    float* ex = (float*)vb;                                        // [wm][wx][b][16][64]
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ex[((size_t)((wm * 2 + wx) * 2 + b2) * 16 + r) * 64 + lane] = give[b2][r];
+    __syncthreads();
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep[b2][r] += ex[((size_t)((wm * 2 + (1 - wx)) * 2 + b2) * 16 + r) * 64 + lane];
+
+    if (!active) return;
+    // ---- epilogue: bias -> (ELU / ReLU) -> per-channel affine -> 16-byte stores of output row 2 ty + wx --------------
+    const int gt = bx * 32 + c;
+    if (gt >= A.T) return;
+    const int b = gt / TPI, rem = gt - b * TPI, ty = rem / A.TW, tx = rem - ty * A.TW;
+    const int oy = 2 * ty + wx;
+    if (oy >= H) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int co = co_tile * 32 + 8 * q + 4 * h;
+        float bi[4], sc[4], sh[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = co + i < A.Cout;
+            bi[i] = (A.bias && in) ? A.bias[co + i] : 0.0f;
+            sc[i] = (A.bn_scale && in) ? A.bn_scale[co + i] : 1.0f;
+            sh[i] = (A.bn_shift && in) ? A.bn_shift[co + i] : 0.0f;
+        }
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+            const int ox = 2 * tx + b2;
+            if (ox >= W) continue;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float u = keep[b2][4 * q + i] + bi[i];
+                if (A.act == 1) u = u > 0.0f ? u : expm1f(u);
+                else if (A.act == 2) u = fmaxf(u, 0.0f);
+                v[i] = u * sc[i] + sh[i];
+            }
+            float* o = A.out + ((size_t)b * H * W + (size_t)oy * W + ox) * A.out_cs + A.out_coff + co;
+            if (co + 3 < A.Cout) {
+                *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (co + i < A.Cout) o[i] = v[i];
+            }
+        }
+    }
+}
+
+// U = G g G^T packed as the kernel streams it. dgrad != 0: the weights of the data gradient (the transposed layer:
+// output channels = the forward's inputs, filter rotated by 180 degrees), w stays the forward [Cout][Cin][3][3].
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int dgrad,
+                                                        float4* __restrict__ wpk, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    wpk[i] = ossid_wino_pack_quad(w, Cout, Cin, dgrad, i);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ossid_conv_wino_packed_floats(int Cout, int Cin) {
+    return (size_t)((Cout + 31) / 32) * (Cin / 8) * 16 * 64 * 4;
+}
+
+int ossid_conv_pack_weights_wino(const float* w, int Cout, int Cin, int dgrad, float* wpk, void* stream) {
+    if (!w || !wpk || Cout <= 0 || Cin <= 0 || (dgrad ? Cout : Cin) % 16) return OSSID_EINVAL;
+    const size_t total = (dgrad ? ossid_conv_wino_packed_floats(Cin, Cout) : ossid_conv_wino_packed_floats(Cout, Cin)) / 4;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout,
+                       Cin, dgrad, (float4*)wpk, total);
+    return ossid_launch_status();
+}
+
+int ossid_conv3x3_wino_fwd(const ossid_conv_desc* d, void* stream) {
+    if (!d || !d->x || !d->wpk || !d->out) return OSSID_EINVAL;
+    const int B = d->batch, H = d->height, W = d->width, Cin = d->cin, Cout = d->cout;
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 16 || d->taps != 9 || d->act < 0 || d->act > 2)
+        return OSSID_EINVAL;
+    if ((d->src_height > 0 && d->src_height != H) || (d->src_width > 0 && d->src_width != W)) return OSSID_EINVAL;   // no fused up-sampling
+    if (d->epi_aux || d->epi_alpha || d->epi_mask_scale || d->epi_mask_shift || d->epi_mask_mode || d->epi_accumulate || d->epi_sum_mode)
+        return OSSID_EINVAL;                                                                                          // no training extras
+    WinoArgs a;
+    a.x = d->x, a.wpk = (const float4*)d->wpk, a.bias = d->bias, a.bn_scale = d->post_scale, a.bn_shift = d->post_shift;
+    a.pre_scale = d->pre_scale, a.pre_shift = d->pre_shift, a.out = d->out, a.pre_relu = d->pre_relu;
+    a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout, a.n_cotiles = (Cout + 31) / 32, a.act = d->act;
+    a.in_cs = d->in_channel_stride > 0 ? d->in_channel_stride : Cin;
+    a.in_bs = d->in_batch_stride >= 0 ? d->in_batch_stride : (long long)H * W * a.in_cs;
+    a.pre_bs = d->pre_batch_stride;
+    a.out_cs = d->out_channel_stride > 0 ? d->out_channel_stride : Cout;
+    a.out_coff = d->out_channel_offset;
+    if (a.in_cs < Cin || a.out_cs < a.out_coff + Cout || (a.in_cs % 4) || (a.out_cs % 4) || (a.out_coff % 4) ||
+        (a.pre_scale && !a.pre_shift) || (a.in_bs % 4) || a.pre_bs < 0 || (a.pre_bs % 4) || (long long)H * W * a.in_cs > 0x7fffffffLL)
+        return OSSID_EINVAL;
+    a.TH = (H + 1) / 2, a.TW = (W + 1) / 2;
+    const long long T = (long long)B * a.TH * a.TW;
+    if (T > 0x7fffffffLL) return OSSID_EINVAL;
+    a.T = (int)T;
+    a.gx = (int)((T + 31) / 32), a.gy = (a.n_cotiles + 1) / 2;
+    const size_t lds = (size_t)2 * VBUF * 16;
+    OSSID_ENSURE_LDS(wino_conv_kernel, lds);
+    const long P = a.gx;
+    long nwg;
+    if (a.gy <= 8 && 8 % a.gy == 0)
+        nwg = 8 * ((P + 8 / a.gy - 1) / (8 / a.gy));
+    else
+        nwg = P * a.gy;
+    if (nwg > 0x7fffffffL) return OSSID_EINVAL;
+    hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)nwg), dim3(256), lds, (hipStream_t)stream, a);
+    return ossid_launch_status();
+}
+
+}  // extern "C"

@@ -231,12 +231,16 @@ def _bn_affine(bn):
 USE_PHASE_CONV = os.environ.get("OSSID_PHASE_CONV", "1") != "0"
 
 
+USE_WINO = os.environ.get("OSSID_WINO", "1") != "0"
+WINO_MIN_WGS = int(os.environ.get("OSSID_WINO_MIN_WGS", "256"))
+
+
 class PackedConv:
     """One nn.Conv2d (3x3 / stride 1 / padding 1, or 1x1) in the MFMA operand layout of csrc/conv.hip with its fused
     neighbours: `pre_bn` (+ReLU) = eval-mode BatchNorm in FRONT of the conv (DenseNet's BN-ReLU-Conv), `act` = ELU and
     `bn` = eval-mode BatchNorm BEHIND it (the head's norm(F.elu(conv(x))))."""
 
-    def __init__(self, conv, bn=None, act=False, pre_bn=None, pre_relu=False, phases=False):
+    def __init__(self, conv, bn=None, act=False, pre_bn=None, pre_relu=False, phases=False, wino=True):
         w = conv.weight.detach().float().contiguous()
         _lib.require_cuda(w)
         self.cout, self.cin = int(w.shape[0]), int(w.shape[1])
@@ -260,6 +264,12 @@ class PackedConv:
         if self.taps == 9 and pre_bn is None and phases:      # only the decoder layers behind a 2x up-sampling ask for them
             n4 = _lib.fn("ossid_conv_packed_floats")(self.cout, self.cin, 4)
             self.wpk4 = torch.empty(4 * n4, dtype=torch.float32, device=w.device)
+        # 3x3 layers with at least one full pair of channel tiles also keep U = G g G^T for the Winograd F(2x2,3x3) kernel
+        # (csrc/wino.hip: 16 instead of 36 multiplies per 2x2 outputs); run() takes it when the launch fills the chip
+        self.wpk_wino = None
+        if self.taps == 9 and self.cout >= 64 and USE_WINO and wino:
+            self.wpk_wino = torch.empty(_lib.fn("ossid_conv_wino_packed_floats")(self.cout, self.cin), dtype=torch.float32,
+                                        device=w.device)
         self.refresh()
 
     def refresh(self):
@@ -270,6 +280,10 @@ class PackedConv:
         with torch.cuda.device(w.device):
             _lib.check(_lib.fn("ossid_conv_pack_weights")(w.data_ptr(), self.cout, self.cin, self.taps,
                                                           self.wpk.data_ptr(), _lib.stream()), "ossid_conv_pack_weights")
+        if self.wpk_wino is not None:
+            with torch.cuda.device(w.device):
+                _lib.check(_lib.fn("ossid_conv_pack_weights_wino")(w.data_ptr(), self.cout, self.cin, 0, self.wpk_wino.data_ptr(),
+                                                                   _lib.stream()), "ossid_conv_pack_weights_wino")
         if self.wpk4 is not None:
             n4 = self.wpk4.numel() // 4
             rows = ((w[:, :, 0], w[:, :, 1] + w[:, :, 2]), (w[:, :, 0] + w[:, :, 1], w[:, :, 2]))       # phase a: [Cout,Cin,3] x2
@@ -305,8 +319,14 @@ class PackedConv:
         d.act, d.pre_relu = self.act, self.pre_relu
         d.src_height, d.src_width = int(src_hw[0]), int(src_hw[1])
         d.in_channel_stride, d.out_channel_stride, d.out_channel_offset = in_cs, out_cs, out_coff
+        name = "ossid_conv_nhwc_fwd"
+        if self.wpk_wino is not None and d.src_height in (0, H) and d.src_width in (0, W):
+            # workgroups of the Winograd launch (32 tiles of 2x2 outputs x 64 channels each): under one per CU the direct
+            # kernel's split-reduction variants are the better fit
+            if ((B * ((H + 1) // 2) * ((W + 1) // 2) + 31) // 32) * ((self.cout + 63) // 64) >= WINO_MIN_WGS:
+                name, d.wpk = "ossid_conv3x3_wino_fwd", self.wpk_wino.data_ptr()
         with torch.cuda.device(out_nhwc.device):
-            _lib.check(_lib.fn("ossid_conv_nhwc_fwd")(C_byref(d), _lib.stream()), "ossid_conv_nhwc_fwd")
+            _lib.check(_lib.fn(name)(C_byref(d), _lib.stream()), name)
         return out_nhwc
 
     def __call__(self, x, size=None):

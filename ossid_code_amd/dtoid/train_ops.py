@@ -115,8 +115,11 @@ class _Packed:
         if ent is None:
             cout, cin = int(w.shape[0]), int(w.shape[1])
             taps = int(w.shape[2] * w.shape[3])
-            n = _lib.fn("ossid_conv_packed_floats")(cout, cin, taps) if kind == "fwd" else \
-                _lib.fn("ossid_conv_packed_floats")(cin, cout, taps)
+            if kind in ("wino_fwd", "wino_dgrad"):
+                n = _lib.fn("ossid_conv_wino_packed_floats")(*((cout, cin) if kind == "wino_fwd" else (cin, cout)))
+            else:
+                n = _lib.fn("ossid_conv_packed_floats")(cout, cin, taps) if kind == "fwd" else \
+                    _lib.fn("ossid_conv_packed_floats")(cin, cout, taps)
             if len(cls._cache) > 4096:
                 cls._cache.clear()
             ent = cls._cache[key] = torch.empty(n, dtype=torch.float32, device=w.device)
@@ -137,9 +140,13 @@ def _pack(w, kind):
     plan = _ACTIVE_PLAN() if _ACTIVE_PLAN is not None else None
     if plan is not None and plan.fresh.get((w.data_ptr(), tuple(w.shape), kind)) == w._version:
         return buf
-    name = "ossid_conv_pack_weights" if kind == "fwd" else "ossid_conv_pack_weights_dgrad"
     with torch.cuda.device(w.device):
-        _lib.check(_lib.fn(name)(w.data_ptr(), cout, cin, taps, buf.data_ptr(), _lib.stream()), name)
+        if kind in ("wino_fwd", "wino_dgrad"):
+            name = "ossid_conv_pack_weights_wino"
+            _lib.check(_lib.fn(name)(w.data_ptr(), cout, cin, 1 if kind == "wino_dgrad" else 0, buf.data_ptr(), _lib.stream()), name)
+        else:
+            name = "ossid_conv_pack_weights" if kind == "fwd" else "ossid_conv_pack_weights_dgrad"
+            _lib.check(_lib.fn(name)(w.data_ptr(), cout, cin, taps, buf.data_ptr(), _lib.stream()), name)
     return buf
 
 
@@ -194,7 +201,7 @@ def end_step():
 
 
 def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_relu=False, act=0, in_cs=0, out_cs=0,
-             out_coff=0, src_hw=(0, 0), epi=None):
+             out_coff=0, src_hw=(0, 0), epi=None, wino=False, post=None):
     """ossid_conv_nhwc_fwd on raw channels-last buffers. epi (training extras, include/ossid_hip.h "epilogue extras"):
     dict(aux=, aux_cs=, alpha=, mask=(scale, shift), accumulate=, sum_mode=) -- with sum_mode the per-wave partial rows
     land in a scratch buffer and (scratch, rows) is returned for bn_fold_fwd / bn_fold_bwd / colsum_finalize (valid until
@@ -222,8 +229,11 @@ def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_rel
             d.epi_partials, d.epi_partials_rows = part.data_ptr(), rows
         if epi.get("timing_buf") is not None:           # -DOSSID_TIMING diagnostic builds only (tools/conv_timeline.py)
             d.epi_partials, d.epi_partials_rows = epi["timing_buf"].data_ptr(), 1 << 30
+    if post is not None:
+        d.post_scale, d.post_shift = post[0].data_ptr(), post[1].data_ptr()
+    name = "ossid_conv3x3_wino_fwd" if wino else "ossid_conv_nhwc_fwd"       # wino: wpk is the Winograd layout
     with torch.cuda.device(out.device):
-        _lib.check(_lib.fn("ossid_conv_nhwc_fwd")(_byref(d), _lib.stream()), "ossid_conv_nhwc_fwd")
+        _lib.check(_lib.fn(name)(_byref(d), _lib.stream()), name)
         if part is not None:
             return part, int(_lib.fn("ossid_conv_last_partial_rows")())
     return out

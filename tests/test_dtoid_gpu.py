@@ -271,7 +271,7 @@ def test_conv3x3_fused_nearest_upsample(hiplib, Hs, Ws, H, W, Cin, Cout):
     x = torch.randn(2, Cin, Hs, Ws, generator=g).cuda()
     with torch.no_grad():
         up = torch.nn.functional.interpolate(x, size=(H, W), mode="nearest")
-        want = ops.PackedConv3x3(conv)(up)                       # the same kernel on the materialised tensor
+        want = ops.PackedConv3x3(conv, wino=False)(up)           # the same (direct) kernel on the materialised tensor
         pk = ops.PackedConv3x3(conv)
         xl = x.contiguous(memory_format=torch.channels_last)
         got = pk.run(xl, 2, H, W, torch.empty_like(want), src_hw=(Hs, Ws))     # the 9-tap kernel with the fused index map

@@ -1,0 +1,89 @@
+"""Winograd F(2x2,3x3) convolution (csrc/wino.hip) against torch's conv2d in float64 and against the direct kernel:
+the layers it stands behind are the 3x3 convolutions of DTOID's head (network.py:102-110, :135-143, :288-326)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from ossid_code_amd.dtoid import train_ops
+    return train_ops
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+def nhwc(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 16, 32, 4, 4), (3, 64, 48, 7, 9), (1, 32, 64, 2, 2), (2, 48, 100, 1, 5),
+                                            (8, 128, 32, 30, 40), (4, 640, 256, 29, 39), (2, 256, 96, 29, 39), (1, 32, 16, 61, 33)])
+def test_wino_forward_matches_conv2d(T, B, cin, cout, H, W):
+    g = torch.Generator().manual_seed(B * 1000 + cin + H)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    xd, wd = nhwc(x.cuda()), w.cuda()
+    out = T.empty_nhwc(B, cout, H, W, "cuda")
+    T.conv_raw(xd, T._pack(wd, "wino_fwd"), B, H, W, cin, cout, 9, out, bias=bias.cuda(), wino=True)
+    assert rel(out, ref) < 2e-5
+    direct = T.empty_nhwc(B, cout, H, W, "cuda")
+    T.conv_raw(xd, T._pack(wd, "fwd"), B, H, W, cin, cout, 9, direct, bias=bias.cuda())
+    assert rel(out, direct) < 2e-5 and rel(direct, ref) < 2e-5
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_wino_prologue_epilogue_strides(T, act):
+    """Input affine + ReLU on real pixels only, bias -> activation -> output affine, channel strides and an output
+    offset (a dense block's resident buffer), as ossid_conv_nhwc_fwd."""
+    g = torch.Generator().manual_seed(5 + act)
+    B, cin, cout, H, W, cs_in, cs_out, off = 3, 32, 40, 9, 11, 48, 64, 8
+    xfull = torch.randn(B, cs_in, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    bias, ps, pt = torch.randn(cout, generator=g), torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    qs, qt = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    xin = torch.relu(xfull[:, :cin].double() * ps.double().view(1, -1, 1, 1) + pt.double().view(1, -1, 1, 1))
+    y = F.conv2d(xin, w.double(), bias.double(), padding=1)
+    y = F.elu(y) if act == 1 else (torch.relu(y) if act == 2 else y)
+    ref = y * qs.double().view(1, -1, 1, 1) + qt.double().view(1, -1, 1, 1)
+    out = torch.full((B, cs_out, H, W), 7.0).cuda().contiguous(memory_format=torch.channels_last)
+    T.conv_raw(nhwc(xfull.cuda()), T._pack(w.cuda(), "wino_fwd"), B, H, W, cin, cout, 9, out, bias=bias.cuda(),
+               pre=(ps.cuda(), pt.cuda()), pre_relu=True, act=act, in_cs=cs_in, out_cs=cs_out, out_coff=off, wino=True,
+               post=(qs.cuda(), qt.cuda()))
+    assert rel(out[:, off:off + cout], ref) < 2e-5
+    assert float((out[:, :off] - 7).abs().max()) == 0 and float((out[:, off + cout:] - 7).abs().max()) == 0
+
+
+def test_wino_data_gradient_layout(T):
+    """The data gradient = the same kernel on ossid_conv_pack_weights_wino(dgrad = 1)."""
+    g = torch.Generator().manual_seed(11)
+    B, cin, cout, H, W = 4, 48, 64, 13, 10
+    x = torch.randn(B, cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    dy = torch.randn(B, cout, H, W, generator=g)
+    F.conv2d(x, w.double(), padding=1).backward(dy.double())
+    dx = T.empty_nhwc(B, cin, H, W, "cuda")
+    T.conv_raw(nhwc(dy.cuda()), T._pack(w.cuda(), "wino_dgrad"), B, H, W, cout, cin, 9, dx, wino=True)
+    assert rel(dx, x.grad) < 2e-5
+
+
+def test_wino_rejects_what_it_does_not_do(T):
+    from ossid_code_amd import _lib
+    x = torch.zeros(1, 24, 4, 4).cuda().contiguous(memory_format=torch.channels_last)
+    out = T.empty_nhwc(1, 32, 4, 4, "cuda")
+    wpk = torch.zeros(1 << 16, device="cuda")
+    with pytest.raises(Exception):
+        T.conv_raw(x, wpk, 1, 4, 4, 24, 32, 9, out, wino=True)           # Cin % 16
+    with pytest.raises(Exception):
+        T.conv_raw(x, wpk, 1, 4, 4, 16, 32, 1, out, wino=True)           # not a 3x3
+    with pytest.raises(Exception):
+        T.conv_raw(x, wpk, 1, 4, 4, 16, 32, 9, out, wino=True, src_hw=(2, 2))   # fused up-sampling

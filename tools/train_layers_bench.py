@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="")
     ap.add_argument("--json", default="")
+    ap.add_argument("--wino", action="store_true", help="3x3 layers (no fused up-sampling): forward and data gradient on csrc/wino.hip")
     a = ap.parse_args()
     B = a.batch
     what = a.what.split(",")
@@ -73,15 +74,16 @@ def main():
         ps, pt = torch.rand(cin).cuda() + 0.5, torch.randn(cin).cuda() * 0.1
         flops = 2.0 * B * H * W * cin * cout * taps
         res = {}
+        wino = a.wino and taps == 9 and src is None
         if "fwd" in what:
-            wpk = T._pack(w, "fwd")
+            wpk = T._pack(w, "wino_fwd" if wino else "fwd")
             out = T.empty_nhwc(B, cout, H, W, "cuda")
             res["fwd"] = timed(lambda: T.conv_raw(x, wpk, B, H, W, cin, cout, taps, out, pre=(ps, pt), pre_relu=True,
-                                                  in_cs=cin + extra, src_hw=(Hs, Ws) if src else (0, 0)), a.reps)
+                                                  in_cs=cin + extra, src_hw=(Hs, Ws) if src else (0, 0), wino=wino), a.reps)
         if "dgrad" in what and src is None and cout % 16 == 0:
-            wpk = T._pack(w, "dgrad")
+            wpk = T._pack(w, "wino_dgrad" if wino else "dgrad")
             dx = T.empty_nhwc(B, cin, H, W, "cuda")
-            res["dgrad"] = timed(lambda: T.conv_raw(dy, wpk, B, H, W, cout, cin, taps, dx), a.reps)
+            res["dgrad"] = timed(lambda: T.conv_raw(dy, wpk, B, H, W, cout, cin, taps, dx, wino=wino), a.reps)
         elif "dgrad" in what and cout % 16 == 0:
             wpk = T._pack(w, "dgrad")
             dx = T.empty_nhwc(B, cin, H, W, "cuda")
