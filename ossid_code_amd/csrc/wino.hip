@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs A) {
     const int H = A.H, W = A.W, TPI = A.TH * A.TW;
 
     // ---- staging role: (tile tl, channel quad j, transform half ih) -> 3 patch rows x 4 columns ------------------
-    const int j = tid & 3, tl = (tid >> 2) & 31, ih = tid >> 7;
+    const int j = tid & 3, tl = (tid >> 2) & 31, ih = __builtin_amdgcn_readfirstlane(tid >> 7);   // (wave-uniform)
     int gbase = 0;              // float offset of patch element (row ih, column 0), possibly outside the image
     unsigned gmask = 0;         // bit r*4+cc: that element is a real pixel
     const float* xb = A.x;
@@ -166,7 +166,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs A) {
     const int nchunks = A.Cin / KCH;
     stage_load(0);
     transform_write(0);
-    float4 cur[4], nxt[4];
+    // weight quads: ONE register set, refilled in place -- the load of the quad four steps ahead (the next group's) is
+    // issued right behind the four MFMAs that consumed this one, so every quad still has 16 MFMAs of cover
+    float4 cur[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) cur[i] = W4[(size_t)quad_of(0, i) * 64];
     __syncthreads();
@@ -176,29 +178,27 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs A) {
     for (int ch = 0; ch < nchunks; ++ch) {
         if (ch + 1 < nchunks) stage_load((ch + 1) * KCH);         // in flight under this chunk's MFMAs
         const float4* pb = vb + (size_t)(ch & 1) * VBUF + (size_t)(8 * wx * 32 + c) * F4 + h;
+        float4 bq = pb[0];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int kb = g >> 1, xh = g & 1;
 #pragma unroll
-#ifndef OSSID_WABL_NOW
-            for (int i = 0; i < 4; ++i) nxt[i] = W4[(size_t)quad_of(gi + 1, i) * 64];
-#else
-            for (int i = 0; i < 4; ++i) nxt[i] = cur[i];
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int e = 4 * xh + i;
-                const float4 a = cur[i];
-                const float4 bq = pb[(size_t)e * 32 * F4 + 2 * kb];
-                acc[e] = mfma(a.x, bq.x, acc[e]);
-                acc[e] = mfma(a.y, bq.y, acc[e]);
-                acc[e] = mfma(a.z, bq.z, acc[e]);
-                acc[e] = mfma(a.w, bq.w, acc[e]);
+                const float4 a = cur[i], b4 = bq;
+                // the operand quad of the NEXT step is read while this step's MFMAs run (the last step of a chunk reads
+                // its own position again: harmless)
+                const int en = (i < 3) ? e + 1 : (g < 3 ? 4 * ((g + 1) & 1) : e), kbn = (i < 3) ? kb : (g < 3 ? (g + 1) >> 1 : kb);
+                bq = pb[(size_t)en * 32 * F4 + 2 * kbn];
+                acc[e] = mfma(a.x, b4.x, acc[e]);
+                acc[e] = mfma(a.y, b4.y, acc[e]);
+                acc[e] = mfma(a.z, b4.z, acc[e]);
+                acc[e] = mfma(a.w, b4.w, acc[e]);
+#ifndef OSSID_WABL_NOW
+                cur[i] = W4[(size_t)quad_of(gi + 1, i) * 64];
+#endif
+                __builtin_amdgcn_sched_barrier(0);      // keep this order: the compiler would sink the load to its use
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
             ++gi;
         }
         if (ch + 1 < nchunks) transform_write((ch + 1) & 1);

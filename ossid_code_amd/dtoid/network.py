@@ -430,9 +430,10 @@ class FusedHead:
         csub = (a2 @ self.sub_wsum()).contiguous()            # [n_t, 9*256]: conv_sub's response to the constant image a_t
         return [t2, avg, a2, csub]
 
-    def correlation(self, image_feat, template_feat, side=None, frame=None):
+    def correlation(self, image_feat, template_feat, side=None, frame=None, decoder=True):
         """frame: a dict shared by the template chunks of ONE image (the template-independent tensors -- channels-last image,
-        G of the dot reassociation, S of the sub one -- are then computed once per frame, not once per chunk)."""
+        G of the dot reassociation, S of the sub one -- are then computed once per frame, not once per chunk).
+        decoder=False: seg is None, the caller runs self.decoder(x2) itself (beside the two detection trunks)."""
         corr = self.corr
         frame = {} if frame is None else frame
         t2, avg, a2, csub = self.template_side(template_feat) if side is None else side
@@ -489,7 +490,12 @@ class FusedHead:
             x = torch.cat([self.dot(image_feat * avg), self.sub(image_feat - avg), self.dot3(dot3x3)], dim=1)
         x2 = self.cf(x)
         heat_map = torch.sigmoid(corr.corr_conv_heatmap(x2))
-        # decoder: each F.interpolate(mode="nearest") is folded into the NEXT conv's patch staging, so the up-sampled
+        return x2, heat_map, (self.decoder(x2) if decoder else None)
+
+    def decoder(self, x2):
+        """Segmentation decoder (network.py:350-362) on the fused feature map."""
+        corr = self.corr
+        # each F.interpolate(mode="nearest") is folded into the NEXT conv's patch staging, so the up-sampled
         # tensors (up to 21 x 32 x 480 x 640 floats) are never written or re-read
         s = self.seg[0](x2)
         for i in (1, 2, 3):
@@ -497,7 +503,7 @@ class FusedHead:
         seg = self.tail(s, size=corr.img_size)        # up-sample + s5/ELU/ns5 + seg_final in one launch
         if seg is None:
             seg = corr.seg_final(self.seg[4](s, size=corr.img_size))
-        return x2, heat_map, seg
+        return seg
 
     def _const(self, like):
         key = (tuple(like.shape), str(like.device))
@@ -890,6 +896,17 @@ class Network(nn.Module):
             template_global = template_global.expand(image.shape[0], -1, -1, -1)
         return self.image_feature_extractor(image, template_global)
 
+    # measured (round 2, 21 templates, graph replay): 9.02 ms with the three branches on three streams vs 8.53 ms on one --
+    # the captured graph does not run the branches side by side to any profit; kept as an opt-in for eager experiments
+    use_branch_streams = os.environ.get("OSSID_HEAD_STREAMS", "0") != "0"
+
+    def _branch_streams(self, device):
+        key = str(device)
+        c = self.__dict__.setdefault("_branch_stream_cache", {})
+        if key not in c:
+            c[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        return c[key]
+
     def _dense_head(self, features, template_features, sides=None):
         """Head of ONE image (features [1,640,h,w]) per template chunk -> dense (cls [n_t,A,2], reg [n_t,A,4],
         seg [n_t,1,H,W], heat [n_t,1,hh,hw], feature-map shape)."""
@@ -897,7 +914,23 @@ class Network(nn.Module):
         cls_out, reg_out, seg_out, heat_out = [], [], [], []
         frame = {}
         for ci, chunk in enumerate(template_features):
-            if fused is not None:
+            if fused is not None and self.use_branch_streams:
+                # the two detection trunks and the segmentation decoder only share their input: three HIP streams (three
+                # branches of the captured graph), so the ragged last round of workgroups of one branch's launches is
+                # filled by another's instead of leaving CUs idle
+                xc, heat, _ = fused.correlation(features, chunk, None if sides is None else sides[ci], frame, decoder=False)
+                cur = torch.cuda.current_stream(features.device)
+                sa, sb = self._branch_streams(features.device)
+                sa.wait_stream(cur)
+                sb.wait_stream(cur)
+                with torch.cuda.stream(sa):
+                    cls_out.append(fused.classification(xc))
+                with torch.cuda.stream(sb):
+                    reg_out.append(fused.regression(xc))
+                seg = fused.decoder(xc)
+                cur.wait_stream(sa)
+                cur.wait_stream(sb)
+            elif fused is not None:
                 xc, heat, seg = fused.correlation(features, chunk, None if sides is None else sides[ci], frame)
                 cls_out.append(fused.classification(xc))
                 reg_out.append(fused.regression(xc))

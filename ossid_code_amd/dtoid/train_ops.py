@@ -160,13 +160,19 @@ class PackPlan:
         for conv in convs:
             w = conv.weight.detach()
             cout, cin, taps = int(w.shape[0]), int(w.shape[1]), int(w.shape[2] * w.shape[3])
-            for kind in ("fwd", "dgrad"):
+            for kind in ("fwd", "dgrad", "wino_fwd", "wino_dgrad"):
                 if kind == "dgrad" and cout % 16:
                     continue
                 if kind == "fwd" and (cin % 16 or cout % 4):
                     continue
+                # the Winograd layouts of the layers wino_fits() can say yes to (its batch-independent conditions)
+                if kind == "wino_fwd" and not (USE_WINO and taps == 9 and cin % 16 == 0 and cout >= 64):
+                    continue
+                if kind == "wino_dgrad" and not (USE_WINO and taps == 9 and cout % 16 == 0 and cin >= 64):
+                    continue
                 buf = _Packed.get(w, kind)
-                rows.append((w.data_ptr(), buf.data_ptr(), first, cout, cin, taps, 0 if kind == "fwd" else 1))
+                rows.append((w.data_ptr(), buf.data_ptr(), first, cout, cin, taps,
+                             {"fwd": 0, "dgrad": 1, "wino_fwd": 2, "wino_dgrad": 3}[kind]))
                 keys.append((w.data_ptr(), tuple(w.shape), kind))
                 first += (buf.numel() // 4 + 255) // 256
         arr = (_lib.PackRow * len(rows))()
@@ -406,6 +412,19 @@ def bn_fold(sums, n, bn):
     return st[0], st[1]
 
 
+USE_WINO = os.environ.get("OSSID_TRAIN_WINO", "1") != "0"
+WINO_MIN_WGS = int(os.environ.get("OSSID_TRAIN_WINO_MIN_WGS", "128"))
+
+
+def wino_fits(B, H, W, cin, cout, taps, plain=True):
+    """Should this 3x3 convolution (cin -> cout on [B][H][W], no fused up-sampling) run on csrc/wino.hip? Needs the
+    reduction channels in 16s, at least a pair of channel tiles and enough workgroups (32 tiles of 2x2 outputs x 64
+    channels each) to occupy the chip; measured per layer in profiles/r02_train_layers_wino.txt."""
+    if not (USE_WINO and plain and taps == 9 and cin % 16 == 0 and cout >= 64):
+        return False
+    return ((B * ((H + 1) // 2) * ((W + 1) // 2) + 31) // 32) * ((cout + 63) // 64) >= WINO_MIN_WGS
+
+
 class FusedConv(torch.autograd.Function):
     """u = ELU?( conv( relu?( x * pre_scale + pre_shift ) [nearest-up-sampled to `size`], w ) + bias ), optionally with
     the column sums of u as a second output (for the BatchNorm that follows). 3x3 / pad 1 / stride 1 or 1x1.
@@ -422,8 +441,10 @@ class FusedConv(torch.autograd.Function):
         pre = None if pre_scale is None else (pre_scale.contiguous(), pre_shift.contiguous())
         u = empty_nhwc(B, Cout, H, W, x.device)
         act = int(act_elu)                       # 0 none, 1 ELU, 2 ReLU (True = ELU: the head's `F.elu(conv(x))`)
-        conv_raw(x, _pack(w, "fwd"), B, H, W, Cin, Cout, taps, u, bias=None if bias is None else bias.detach(), pre=pre,
-                 pre_relu=pre_relu, act=act, src_hw=(Hs, Ws) if size is not None else (0, 0))
+        wino = wino_fits(B, H, W, Cin, Cout, taps, plain=(H, W) == (Hs, Ws))
+        conv_raw(x, _pack(w, "wino_fwd" if wino else "fwd"), B, H, W, Cin, Cout, taps, u,
+                 bias=None if bias is None else bias.detach(), pre=pre, pre_relu=pre_relu, act=act,
+                 src_hw=(Hs, Ws) if size is not None else (0, 0), wino=wino)
         sums = batch_stats(flat(u), B * H * W, Cout) if want_stats else None
         ctx.save_for_backward(x, w, u if (act or want_stats) else None, None if pre is None else pre[0],
                               None if pre is None else pre[1])
@@ -468,7 +489,8 @@ class FusedConv(torch.autograd.Function):
         dx = dps = dpt = None
         if need[0] or (pre is not None and (need[3] or need[4])):
             dxu = empty_nhwc(B, Cin, H, W, dev)
-            conv_raw(dv, _pack(w, "dgrad"), B, H, W, Cout, Cin, taps, dxu)
+            wino = wino_fits(B, H, W, Cout, Cin, taps)
+            conv_raw(dv, _pack(w, "wino_dgrad" if wino else "dgrad"), B, H, W, Cout, Cin, taps, dxu, wino=wino)
             if (H, W) != (Hs, Ws):
                 dxu = upsample_bwd(dxu, B, Hs, Ws, H, W, Cin)
             if pre is not None:
@@ -600,7 +622,8 @@ class DenseBlockTrain(torch.autograd.Function):
                 s = conv_raw(gs, _pack(w2, "dgrad"), B, H, W, growth, mid, 9, db, in_cs=Ct,
                              epi=dict(aux=y1, alpha=f2[0], mask=(f2[0], f2[1]), sum_mode=1))
             else:
-                conv_raw(gs, _pack(w2, "dgrad"), B, H, W, growth, mid, 9, db, in_cs=Ct)
+                wino = wino_fits(B, H, W, growth, mid, 9)
+                conv_raw(gs, _pack(w2, "wino_dgrad" if wino else "dgrad"), B, H, W, growth, mid, 9, db, in_cs=Ct, wino=wino)
                 s = chan_op(db, N, mid, x=y1, out=db, alpha=f2[0], mask_mode=1, mask_scale=f2[0], mask_shift=f2[1],
                             sum_mode=1, defer=True)
             r2 = torch.empty((4, mid), dtype=torch.float32, device=dev)
