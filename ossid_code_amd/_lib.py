@@ -174,7 +174,29 @@ def ptr(t):
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current HIP stream on the current device (the private fast path: ~0.3 us instead of ~4 us
+    through torch.cuda.current_stream() -- the eager finetune step makes ~2000 launches)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
+def on_device(dev):
+    """`with on_device(t.device):` -- torch.cuda.device(dev), or nothing at all when dev is already current (one process
+    per GPU: always, after start-up)."""
+    idx = dev.index if isinstance(dev, torch.device) else dev
+    if idx is None or torch._C._cuda_getDevice() == idx:
+        return _NULL_CTX
+    return torch.cuda.device(dev)
 
 
 def require_cuda(*tensors):

@@ -203,6 +203,9 @@ class GradSync:
             self._next -= 1
 
     def _flush(self, b):
+        if self.flat.grad.is_cuda:
+            from . import train_ops
+            train_ops.join_wgrad_stream()      # weight gradients still in flight on the side stream (train_ops.WGRAD_SIDE)
         dst, src = [], []
         for (p, off, cnt), v in zip(b["params"], b["views"]):
             if p.grad is None:

@@ -739,7 +739,40 @@ class Network(nn.Module):
         torch._foreach_add_(ts, 1)
         return xf
 
-    def _forward_train_hip(self, image, g, local):
+    # Independent branches of the training step on side HIP streams (eager execution only -- under a graph capture the
+    # branches run in line): the local template encoder beside the image backbone, the three correlation convolutions
+    # side by side, the two detection trunks beside the segmentation decoder. At batch 8 each of these launches fills
+    # 60-75 % of the chip's workgroup slots; two or three of them in flight fill the rest. autograd runs every node's
+    # backward on the stream of its forward, so the backward pass is concurrent in the same way. Tensors that cross
+    # streams are record_stream()ed for the caching allocator.
+    use_train_streams = os.environ.get("OSSID_TRAIN_STREAMS", "1") != "0"
+
+    def _branches_on(self, device):
+        return (self.use_train_streams and device.type == "cuda" and not torch.cuda.is_current_stream_capturing())
+
+    def _fork(self, k, inputs, fn):
+        """Run fn() on side stream k behind everything queued on the current stream; returns (outputs, stream)."""
+        dev = inputs[0].device
+        pool = self.__dict__.setdefault("_train_stream_pool", {})
+        key = (str(dev), k)
+        if key not in pool:
+            pool[key] = torch.cuda.Stream(device=dev)
+        side = pool[key]
+        side.wait_stream(torch.cuda.current_stream(dev))
+        for t in inputs:
+            t.record_stream(side)
+        with torch.cuda.stream(side):
+            out = fn()
+        return out, side
+
+    @staticmethod
+    def _join(side, outputs):
+        main = torch.cuda.current_stream(outputs[0].device)
+        main.wait_stream(side)
+        for t in outputs:
+            t.record_stream(main)
+
+    def _forward_train_hip(self, image, g, local, join_local=None):
         """Training-mode forward of everything behind the two template encoders on csrc/conv.hip + csrc/train.hip,
         channels-last end to end (same arithmetic as the module path below; BatchNorm batch statistics folded into the
         next convolution's input staging). Returns (classifications, regression, anchors, heat_map, segmentation)."""
@@ -776,6 +809,8 @@ class Network(nn.Module):
         u, sums = T.bn_relu_conv(x, norm5, ife.c1, relu=False, act_elu=True, want_stats=True)
         s, t = T.bn_fold(sums, n_px, ife.n1)
         feat = u * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)                 # n1(elu(c1(norm5(.)))), [B,640,29,39]
+        if join_local is not None:
+            self._join(join_local, [local])
         out = self._head_train_hip(feat, local)
         # the folded BatchNorms update running_mean / running_var in their kernel; the counters in one launch
         ts = self.__dict__.get("_folded_bn_counters")
@@ -824,12 +859,30 @@ class Network(nn.Module):
         t2 = corr._cab(corr.c2, corr.n2, corr._cab(corr.c1, corr.n1, local))      # 7x7 -> 5x5 -> 3x3 (tiny: torch)
         dot3x3 = ops.dw_xcorr(feat, t2)
         avg = F.avg_pool2d(local, 7)
-        parts = [cab(feat * avg, corr.corr_conv_dot, corr.norm_corr_dot),
-                 cab(feat - avg, corr.corr_conv_sub, corr.norm_corr_sub),
-                 cab(dot3x3, corr.corr_conv_dot3x3, corr.norm_corr_dot3x3)]
+        par = self._branches_on(feat.device)
+        if par:
+            (p1, s_a) = self._fork(0, [feat, avg], lambda: cab(feat - avg, corr.corr_conv_sub, corr.norm_corr_sub))
+            (p2, s_b) = self._fork(1, [dot3x3], lambda: cab(dot3x3, corr.corr_conv_dot3x3, corr.norm_corr_dot3x3))
+            p0 = cab(feat * avg, corr.corr_conv_dot, corr.norm_corr_dot)
+            self._join(s_a, list(p1))
+            self._join(s_b, list(p2))
+            parts = [p0, p1, p2]
+        else:
+            parts = [cab(feat * avg, corr.corr_conv_dot, corr.norm_corr_dot),
+                     cab(feat - avg, corr.corr_conv_sub, corr.norm_corr_sub),
+                     cab(dot3x3, corr.corr_conv_dot3x3, corr.norm_corr_dot3x3)]
         ucat = torch.cat([p[0] for p in parts], 1)
         pre = (torch.cat([p[1] for p in parts]), torch.cat([p[2] for p in parts]))
         u2, s2, t2_ = cab(ucat, corr.cf, corr.nf, pre=pre)
+
+        def trunk(mod):
+            h = T.fused_conv(u2, mod.conv1, pre=(s2, t2_), act_elu=True)
+            for i in (2, 3, 4):
+                h = T.fused_conv(h, getattr(mod, "conv%d" % i), act_elu=True)
+            return T.fused_conv(h, mod.output)
+        if par:      # the two detection trunks beside the heat map + segmentation decoder
+            (cls_raw, s_a) = self._fork(0, [u2, s2, t2_], lambda: trunk(self.classification))
+            (reg_raw, s_b) = self._fork(1, [u2, s2, t2_], lambda: trunk(self.regression))
         x2 = u2 * s2.view(1, -1, 1, 1) + t2_.view(1, -1, 1, 1)              # materialised once, for the 1-channel heat conv
         heat_map = torch.sigmoid(corr.corr_conv_heatmap(x2))
         u, sc, sh = cab(u2, corr.s1, corr.ns1, pre=(s2, t2_))
@@ -838,15 +891,14 @@ class Network(nn.Module):
                             size=(2 * u.shape[2], 2 * u.shape[3]))
         u, sc, sh = cab(u, corr.s5, corr.ns5, pre=(sc, sh), size=corr.img_size)
         segmentation = corr.seg_final(u * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
-
-        def trunk(mod):
-            h = T.fused_conv(u2, mod.conv1, pre=(s2, t2_), act_elu=True)
-            for i in (2, 3, 4):
-                h = T.fused_conv(h, getattr(mod, "conv%d" % i), act_elu=True)
-            return T.fused_conv(h, mod.output)
-        cls = torch.sigmoid(trunk(self.classification))
+        if par:
+            self._join(s_a, [cls_raw])
+            self._join(s_b, [reg_raw])
+        else:
+            cls_raw, reg_raw = trunk(self.classification), trunk(self.regression)
+        cls = torch.sigmoid(cls_raw)
         classifications = cls.permute(0, 2, 3, 1).reshape(B, -1, self.classification.num_classes)
-        regression = trunk(self.regression).permute(0, 2, 3, 1).reshape(B, -1, 4)
+        regression = reg_raw.permute(0, 2, 3, 1).reshape(B, -1, 4)
         anchors = self.anchors([[u2.size(2), u2.size(3)]], device=u2.device)
         ts = self.__dict__.get("_folded_bn_counters_head")
         if ts is None:
@@ -868,6 +920,12 @@ class Network(nn.Module):
                                                      torch.cat([template, template_mask], dim=1))
         else:
             g = self.template_feature_extractor_global(torch.cat([global_template, global_template_mask], dim=1))
+            if hip_train and self._branches_on(image.device):
+                # the local encoder's output is first read by the head: it runs beside the image backbone
+                (local, s_loc) = self._fork(2, [template, template_mask],
+                                            lambda: self.template_feature_extractor(torch.cat([template, template_mask], dim=1)))
+                out = self._forward_train_hip(image, g, local, join_local=s_loc)
+                return out
             local = self.template_feature_extractor(torch.cat([template, template_mask], dim=1))
         if hip_train:
             return self._forward_train_hip(image, g, local)

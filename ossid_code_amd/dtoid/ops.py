@@ -18,7 +18,7 @@ class _DwXcorr(torch.autograd.Function):
         x = x.contiguous().float()          # [B,C,H,W], or [1,C,H,W] shared by all B kernels
         k = k.contiguous().float()
         out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.fn("ossid_dw_xcorr_fwd")(x.data_ptr(), x.shape[0] * C, k.data_ptr(), B * C, H, W,
                                                      out.data_ptr(), _lib.stream()), "ossid_dw_xcorr_fwd")
         if x.shape[0] != B:
@@ -33,7 +33,7 @@ class _DwXcorr(torch.autograd.Function):
         B, C, H, W = x.shape
         dout = dout.contiguous()
         dx = dk = None
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 _lib.check(_lib.fn("ossid_dw_xcorr_bwd_x")(dout.data_ptr(), k.data_ptr(), B * C, H, W, dx.data_ptr(),
@@ -69,7 +69,7 @@ def dw_xcorr_nhwc_bcast(x, kernel):
     x = x.float().contiguous(memory_format=torch.channels_last)
     k = kernel.detach().float().contiguous()
     out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(_lib.fn("ossid_dw_xcorr_nhwc_bcast")(x.data_ptr(), k.data_ptr(), B, C, H, W, out.data_ptr(),
                                                         _lib.stream()), "ossid_dw_xcorr_nhwc_bcast")
     return out
@@ -91,7 +91,7 @@ def nms(boxes, scores, iou_threshold, sorted_desc=False):
     nkeep = torch.empty(1, dtype=torch.int32, device=boxes.device)
     nbytes = _lib.fn("ossid_nms_workspace_bytes")(n)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=boxes.device)
-    with torch.cuda.device(boxes.device):
+    with _lib.on_device(boxes.device):
         _lib.check(_lib.fn("ossid_nms")(sb.data_ptr(), n, float(iou_threshold), ws.data_ptr(), nbytes, keep.data_ptr(),
                                         nkeep.data_ptr(), _lib.stream()), "ossid_nms")
     kept = keep[: int(nkeep.item())].long()
@@ -110,7 +110,7 @@ def topk_scores(scores, k):
     idx = torch.empty(k, dtype=torch.int64, device=s.device)
     nbytes = _lib.fn("ossid_topk_workspace_bytes")(n, k)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=s.device)
-    with torch.cuda.device(s.device):
+    with _lib.on_device(s.device):
         _lib.check(_lib.fn("ossid_topk")(s.data_ptr(), n, k, ws.data_ptr(), nbytes, vals.data_ptr(), idx.data_ptr(),
                                          _lib.stream()), "ossid_topk")
     return vals, idx
@@ -134,7 +134,7 @@ def im2col_stem(img, k, stride, pad, kpad, normalize=False):
             _IMNORM[key] = (torch.tensor([0.485, 0.456, 0.406], device=img.device),
                             1.0 / torch.tensor([0.229, 0.224, 0.225], device=img.device))
         mean, inv = _IMNORM[key]
-    with torch.cuda.device(img.device):
+    with _lib.on_device(img.device):
         rc = _lib.fn("ossid_im2col_stem")(img.data_ptr(), B, Cin, H, W, k, stride, pad, kpad, None if mean is None else
                                           mean.data_ptr(), None if inv is None else inv.data_ptr(), out.data_ptr(), _lib.stream())
     _lib.check(rc, "ossid_im2col_stem")
@@ -146,7 +146,7 @@ def stem_tail(x0, kernels, scale, shift):
     B, C, H, W = x0.shape
     k = kernels.detach().float().contiguous()
     out = torch.empty_like(x0)
-    with torch.cuda.device(x0.device):
+    with _lib.on_device(x0.device):
         rc = _lib.fn("ossid_stem_tail_nhwc")(x0.data_ptr(), k.data_ptr(), 0 if k.shape[0] == 1 else C * 9, scale.data_ptr(),
                                              shift.data_ptr(), B, H, W, C, out.data_ptr(), _lib.stream())
     _lib.check(rc, "ossid_stem_tail_nhwc")
@@ -161,7 +161,7 @@ def maxpool_nhwc(x, k, stride, pad=0, ceil_mode=False):
         o = -(-(n + 2 * pad - k) // stride) + 1 if ceil_mode else (n + 2 * pad - k) // stride + 1
         return o - 1 if ceil_mode and (o - 1) * stride >= n + pad else o
     out = torch.empty((B, C, osz(H), osz(W)), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = _lib.fn("ossid_maxpool_nhwc")(x.data_ptr(), B, H, W, C, k, stride, pad, 1 if ceil_mode else 0, out.data_ptr(),
                                            _lib.stream())
     _lib.check(rc, "ossid_maxpool_nhwc")
@@ -202,7 +202,7 @@ def gather_rows(src, idx, sigmoid=False):
     if row % 4:
         g = src[idx]
         return torch.sigmoid(g) if sigmoid else g
-    with torch.cuda.device(src.device):
+    with _lib.on_device(src.device):
         _lib.check(_lib.fn("ossid_gather_rows")(src.data_ptr(), int(src.shape[0]), row, idx.data_ptr(), k,
                                                 1 if sigmoid else 0, out.data_ptr(), _lib.stream()), "ossid_gather_rows")
     return out
@@ -215,7 +215,7 @@ def decode_clip_boxes(anchors, deltas, img_w, img_h):
     d = deltas.detach().float().contiguous()
     R, A = d.shape[0], d.shape[1]
     out = torch.empty_like(d)
-    with torch.cuda.device(d.device):
+    with _lib.on_device(d.device):
         _lib.check(_lib.fn("ossid_decode_clip_boxes")(a.data_ptr(), d.data_ptr(), R, A, float(img_w), float(img_h),
                                                       out.data_ptr(), _lib.stream()), "ossid_decode_clip_boxes")
     return out
@@ -277,11 +277,11 @@ class PackedConv:
         valid across parameter updates (the online loop finetunes the detector every few frames)."""
         conv, bn, pre_bn = self._src
         w = conv.weight.detach().float().contiguous()
-        with torch.cuda.device(w.device):
+        with _lib.on_device(w.device):
             _lib.check(_lib.fn("ossid_conv_pack_weights")(w.data_ptr(), self.cout, self.cin, self.taps,
                                                           self.wpk.data_ptr(), _lib.stream()), "ossid_conv_pack_weights")
         if self.wpk_wino is not None:
-            with torch.cuda.device(w.device):
+            with _lib.on_device(w.device):
                 _lib.check(_lib.fn("ossid_conv_pack_weights_wino")(w.data_ptr(), self.cout, self.cin, 0, self.wpk_wino.data_ptr(),
                                                                    _lib.stream()), "ossid_conv_pack_weights_wino")
         if self.wpk4 is not None:
@@ -293,7 +293,7 @@ class PackedConv:
                     cols = (lambda r: (r[:, :, 0], r[:, :, 1] + r[:, :, 2])) if b == 0 else \
                         (lambda r: (r[:, :, 0] + r[:, :, 1], r[:, :, 2]))
                     w4 = torch.stack([torch.stack(cols(r0), -1), torch.stack(cols(r1), -1)], -2).contiguous()   # [Cout,Cin,2,2]
-                    with torch.cuda.device(w.device):
+                    with _lib.on_device(w.device):
                         _lib.check(_lib.fn("ossid_conv_pack_weights")(
                             w4.data_ptr(), self.cout, self.cin, 4, self.wpk4[(a * 2 + b) * n4:].data_ptr(), _lib.stream()),
                             "ossid_conv_pack_weights")
@@ -325,7 +325,7 @@ class PackedConv:
             # kernel's split-reduction variants are the better fit
             if ((B * ((H + 1) // 2) * ((W + 1) // 2) + 31) // 32) * ((self.cout + 63) // 64) >= WINO_MIN_WGS:
                 name, d.wpk = "ossid_conv3x3_wino_fwd", self.wpk_wino.data_ptr()
-        with torch.cuda.device(out_nhwc.device):
+        with _lib.on_device(out_nhwc.device):
             _lib.check(_lib.fn(name)(C_byref(d), _lib.stream()), name)
         return out_nhwc
 
@@ -354,7 +354,7 @@ class PackedConv:
         d.post_scale, d.post_shift = p(self.scale), p(self.shift)
         d.batch, d.height, d.width, d.cin, d.cout, d.taps, d.act = B, Hs, Ws, self.cin, self.cout, 4, self.act
         d.in_batch_stride = -1
-        with torch.cuda.device(out_nhwc.device):
+        with _lib.on_device(out_nhwc.device):
             rc = _lib.fn("ossid_conv_nhwc_fwd")(C_byref(d), _lib.stream())
         if rc == -22:
             return False
@@ -385,7 +385,7 @@ class SegTail:
         """Re-read the three source modules into the same device buffers (see PackedConv.refresh)."""
         conv1, bn1, conv2 = self._src
         w1 = conv1.weight.detach().float().contiguous()
-        with torch.cuda.device(w1.device):
+        with _lib.on_device(w1.device):
             _lib.check(_lib.fn("ossid_seg_tail_pack_weights")(w1.data_ptr(), self.w1p.data_ptr(), _lib.stream()),
                        "ossid_seg_tail_pack_weights")
         if conv1.bias is not None:
@@ -407,7 +407,7 @@ class SegTail:
             return None
         x = x.float().contiguous(memory_format=torch.channels_last)
         out = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             rc = _lib.fn("ossid_seg_tail_fwd")(x.data_ptr(), B, Hs, Ws, 32, H, W, self.w1p.data_ptr(),
                                                self.b1.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
                                                self.w2.data_ptr(), self.b2.data_ptr(), out.data_ptr(), _lib.stream())

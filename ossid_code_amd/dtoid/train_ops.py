@@ -55,7 +55,7 @@ _SCRATCH = {}
 
 
 def _scratch(name, nbytes, device):
-    key = (name, str(device), torch.cuda.current_stream(device).cuda_stream)
+    key = (name, str(device), _lib.stream())
     t = _SCRATCH.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -90,7 +90,7 @@ def chan_op(g, n_rows, C, x=None, out=None, g_cs=0, x_cs=0, out_cs=0, alpha=None
                 sums = torch.empty((3 if sum_mode == 3 else 2, C), dtype=torch.float32, device=dev)
             d.partials = _scratch("chan", P * 2 * C * 4, dev).data_ptr()
             d.sums = sums.data_ptr()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.fn("ossid_chan_op")(_byref(d), _lib.stream()), "ossid_chan_op")
     return sums
 
@@ -140,7 +140,7 @@ def _pack(w, kind):
     plan = _ACTIVE_PLAN() if _ACTIVE_PLAN is not None else None
     if plan is not None and plan.fresh.get((w.data_ptr(), tuple(w.shape), kind)) == w._version:
         return buf
-    with torch.cuda.device(w.device):
+    with _lib.on_device(w.device):
         if kind in ("wino_fwd", "wino_dgrad"):
             name = "ossid_conv_pack_weights_wino"
             _lib.check(_lib.fn(name)(w.data_ptr(), cout, cin, 1 if kind == "wino_dgrad" else 0, buf.data_ptr(), _lib.stream()), name)
@@ -190,7 +190,7 @@ class PackPlan:
         return len(convs) == len(self.sig) and all(c.weight.data_ptr() == p for c, p in zip(convs, self.sig))
 
     def run(self):
-        with torch.cuda.device(self.device):
+        with _lib.on_device(self.device):
             rc = _lib.fn("ossid_conv_pack_weights_table")(self.table.data_ptr(), self.n_rows, self.total_blocks, _lib.stream())
         _lib.check(rc, "ossid_conv_pack_weights_table")
         global _ACTIVE_PLAN
@@ -238,7 +238,7 @@ def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_rel
     if post is not None:
         d.post_scale, d.post_shift = post[0].data_ptr(), post[1].data_ptr()
     name = "ossid_conv3x3_wino_fwd" if wino else "ossid_conv_nhwc_fwd"       # wino: wpk is the Winograd layout
-    with torch.cuda.device(out.device):
+    with _lib.on_device(out.device):
         _lib.check(_lib.fn(name)(_byref(d), _lib.stream()), name)
         if part is not None:
             return part, int(_lib.fn("ossid_conv_last_partial_rows")())
@@ -247,7 +247,7 @@ def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_rel
 
 def colsum_finalize(partials, C, sums, sums_row_stride=0):
     part, P = partials
-    with torch.cuda.device(part.device):
+    with _lib.on_device(part.device):
         _lib.check(_lib.fn("ossid_colsum_finalize")(part.data_ptr(), int(P), int(C), sums.data_ptr(), int(sums_row_stride),
                                                     _lib.stream()), "ossid_colsum_finalize")
 
@@ -265,7 +265,7 @@ def wgrad_raw(x, dy, B, H, W, cin, cout, taps, dw, pre=None, pre_relu=False, in_
     d.pre_relu, d.accumulate = 1 if pre_relu else 0, 1 if accumulate else 0
     d.in_channel_stride, d.dy_channel_stride = int(in_cs), int(dy_cs)
     d.src_height, d.src_width = int(src_hw[0]), int(src_hw[1])
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.fn("ossid_conv_wgrad")(_byref(d), _lib.stream()), "ossid_conv_wgrad")
     return dw
 
@@ -288,7 +288,7 @@ def wgrad_group(items):
     if nbytes == 0:
         raise RuntimeError("ossid_conv_wgrad_group_workspace_bytes rejected the group")
     ws = _scratch("wgrad_group", nbytes, dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.fn("ossid_conv_wgrad_group")(arr, n, ws.data_ptr(), nbytes, _lib.stream()), "ossid_conv_wgrad_group")
 
 
@@ -305,7 +305,7 @@ def bn_fold_fwd(sums, C, n, gamma, beta, eps, momentum, running_mean, running_va
         if pivot is None and sums.dim() == 2 and sums.shape[0] == 3:
             pivot = sums[2]
     out = torch.empty((4, C), dtype=torch.float32, device=dev)          # scale, shift, mean, rstd
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.fn("ossid_bn_fold_fwd")(None if part is not None else sums.data_ptr(), int(sums_row_stride), _p(part), int(P),
                                           _p(pivot), C, float(n), _p(gamma), _p(beta), float(eps),
                                           float(momentum), _p(running_mean), _p(running_var), out[0].data_ptr(),
@@ -317,7 +317,7 @@ def bn_fold_fwd(sums, C, n, gamma, beta, eps, momentum, running_mean, running_va
 def bn_fold_bwd(dscale, dshift, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate=False, partials=None):
     """partials = (scratch, P) of a deferred chan_op (row 0 = d shift, row 1 = d scale) instead of dscale / dshift."""
     part, P = partials if partials is not None else (None, 0)
-    with torch.cuda.device(coef_x.device):
+    with _lib.on_device(coef_x.device):
         rc = _lib.fn("ossid_bn_fold_bwd")(_p(dscale), _p(dshift), _p(part), int(P), _p(gamma), mean.data_ptr(), rstd.data_ptr(),
                                           C, float(n), _p(dgamma), _p(dbeta), coef_x.data_ptr(), coef_1.data_ptr(),
                                           1 if accumulate else 0, _lib.stream())
@@ -348,7 +348,7 @@ def _upsample_tables(Hs, Ws, H, W, device):
 def upsample_bwd(dup, B, Hs, Ws, H, W, C):
     rs, cs = _upsample_tables(Hs, Ws, H, W, dup.device)
     out = empty_nhwc(B, C, Hs, Ws, dup.device)
-    with torch.cuda.device(dup.device):
+    with _lib.on_device(dup.device):
         rc = _lib.fn("ossid_upsample_nearest_bwd_nhwc")(dup.data_ptr(), B, Hs, Ws, H, W, C, rs.data_ptr(), cs.data_ptr(),
                                                         out.data_ptr(), _lib.stream())
     _lib.check(rc, "ossid_upsample_nearest_bwd_nhwc")
@@ -410,6 +410,43 @@ def bn_fold(sums, n, bn):
     """(scale, shift) of a training-mode nn.BatchNorm2d given the column sums of its input."""
     st = BNFold.apply(sums, bn.weight, bn.bias, n, bn)
     return st[0], st[1]
+
+
+# Weight gradients on a second HIP stream. A convolution's weight gradient feeds nothing but the optimizer, while its data
+# gradient is on the critical path of backward -- a chain of small launches (a dense layer's 3x3 / 1x1 data gradients and
+# the generic passes between them occupy a fraction of the chip each). With WGRAD_SIDE the weight-gradient launches go to
+# a side stream that waits for the main stream at the point of issue; the main stream joins it when the backward pass
+# ends (an autograd engine callback, so a bare loss.backward() is as safe as finetune_step) and wherever gradients are
+# read earlier (GradSync's per-bucket hooks). Tensors the side stream reads are record_stream()ed: the caching allocator
+# then keeps their memory until that work has run.
+WGRAD_SIDE = os.environ.get("OSSID_WGRAD_STREAM", "1") != "0"
+_wg_streams, _wg_dirty = {}, set()
+
+
+def join_wgrad_stream():
+    """Main stream(s) wait for the weight gradients in flight on the side stream(s)."""
+    for idx in list(_wg_dirty):
+        torch.cuda.current_stream(idx).wait_stream(_wg_streams[idx])
+    _wg_dirty.clear()
+
+
+def _wgrad_async(tensors, fn, device):
+    if not WGRAD_SIDE or device.type != "cuda":
+        return fn()
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    main = torch.cuda.current_stream(idx)
+    side = _wg_streams.get(idx)
+    if side is None:
+        side = _wg_streams[idx] = torch.cuda.Stream(device=idx)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    if not _wg_dirty:
+        torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
+    _wg_dirty.add(idx)
 
 
 USE_WINO = os.environ.get("OSSID_TRAIN_WINO", "1") != "0"
@@ -483,8 +520,8 @@ class FusedConv(torch.autograd.Function):
         dw = None
         if need[1]:
             dw = torch.empty_like(w)
-            wgrad_raw(x, dv, B, H, W, Cin, Cout, taps, dw, pre=pre, pre_relu=pre_relu,
-                      src_hw=(Hs, Ws) if (H, W) != (Hs, Ws) else (0, 0))
+            _wgrad_async([x, dv, ps, pt, dw], lambda: wgrad_raw(x, dv, B, H, W, Cin, Cout, taps, dw, pre=pre, pre_relu=pre_relu,
+                                                                src_hw=(Hs, Ws) if (H, W) != (Hs, Ws) else (0, 0)), dev)
         # 3. data gradient
         dx = dps = dpt = None
         if need[0] or (pre is not None and (need[3] or need[4])):
@@ -520,7 +557,7 @@ class AvgPool2(torch.autograd.Function):
         B, C, H, W = x.shape
         Ho, Wo = (H - 2) // stride + 1, (W - 2) // stride + 1
         out = empty_nhwc(B, C, Ho, Wo, x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.fn("ossid_avgpool2_nhwc")(x.data_ptr(), B, H, W, C, stride, out.data_ptr(), 0, _lib.stream()),
                        "ossid_avgpool2_nhwc")
         ctx.cfg = (B, C, H, W, stride)
@@ -531,7 +568,7 @@ class AvgPool2(torch.autograd.Function):
         B, C, H, W, stride = ctx.cfg
         g = nhwc(g)
         dx = empty_nhwc(B, C, H, W, g.device)
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             _lib.check(_lib.fn("ossid_avgpool2_nhwc")(g.data_ptr(), B, H, W, C, stride, dx.data_ptr(), 1, _lib.stream()),
                        "ossid_avgpool2_nhwc")
         return dx, None
@@ -647,7 +684,9 @@ class DenseBlockTrain(torch.autograd.Function):
             r1 = torch.empty((2, c), dtype=torch.float32, device=dev)
             bn_fold_bwd(None, None, g1, f1[2], f1[3], c, N, r1[0], r1[1], coef[0], coef[1], accumulate=True, partials=s)
             grads[6 * li:6 * li + 6] = [r1[0], r1[1], dw1, r2[0], r2[1], dw2]
-        wgrad_group(deferred)
+        touched = [G, buf, dz_all] + [t for sv in saved for t in (sv[1], sv[0][0], sv[0][1], sv[2][0], sv[2][1])] + \
+            [it["dw"] for it in deferred]
+        _wgrad_async(touched, lambda: wgrad_group(deferred), dev)
         # the block's input channels
         chan_op(G, N, C0, x=buf, out=G, g_cs=Ct, x_cs=Ct, out_cs=Ct, beta=coef[0, :C0], kappa=coef[1, :C0])
         dx = G[:, :C0].contiguous(memory_format=torch.channels_last)
@@ -664,7 +703,7 @@ class DwXcorrAdd(torch.autograd.Function):
         B, C, H, W = x.shape
         k = k.float().contiguous()
         out = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.fn("ossid_dw_add_nhwc")(x.data_ptr(), k.data_ptr(), C * 9 if k.shape[0] > 1 else 0, B, H, W, C, 0,
                                                     out.data_ptr(), _lib.stream()), "ossid_dw_add_nhwc")
         ctx.save_for_backward(x, k)
@@ -676,7 +715,7 @@ class DwXcorrAdd(torch.autograd.Function):
         B, C, H, W = x.shape
         g = nhwc(g)
         dx = dk = None
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 _lib.check(_lib.fn("ossid_dw_add_nhwc")(g.data_ptr(), k.data_ptr(), C * 9 if k.shape[0] > 1 else 0, B, H, W, C, 1,
@@ -704,7 +743,7 @@ class MaxPoolNHWC(torch.autograd.Function):
         Ho, Wo = osz(H), osz(W)
         out = empty_nhwc(B, C, Ho, Wo, x.device)
         idx = torch.empty(B * Ho * Wo * C, dtype=torch.uint8, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.fn("ossid_maxpool_idx_nhwc")(x.data_ptr(), B, H, W, C, k, stride, pad, 1 if ceil_mode else 0,
                                                          out.data_ptr(), idx.data_ptr(), _lib.stream()), "ossid_maxpool_idx_nhwc")
         ctx.save_for_backward(idx)
@@ -717,7 +756,7 @@ class MaxPoolNHWC(torch.autograd.Function):
         B, C, H, W, k, stride, pad, Ho, Wo = ctx.cfg
         g = nhwc(g)
         dx = empty_nhwc(B, C, H, W, g.device)
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             _lib.check(_lib.fn("ossid_maxpool_bwd_nhwc")(g.data_ptr(), idx.data_ptr(), B, H, W, C, k, stride, pad, Ho, Wo,
                                                          dx.data_ptr(), _lib.stream()), "ossid_maxpool_bwd_nhwc")
         return dx, None, None, None, None

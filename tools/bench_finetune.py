@@ -50,6 +50,13 @@ def main():
         return (time.perf_counter() - t0) / reps * 1e3
     res = {"impl": a.impl, "batch": B}
     res["eager_ms"] = timed(lambda: finetune.finetune_step(m, batch, opt), 2, a.reps)
+    # host time to ENQUEUE one eager step (no synchronisation inside): the eager step is launch-bound once this
+    # approaches the device time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    finetune.finetune_step(m, batch, opt)
+    res["eager_host_enqueue_ms"] = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
     if a.phases:
         def fwd():
             return m(batch)["loss"]
