@@ -214,6 +214,9 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* desc_host, void* stream);
 size_t ossid_conv_wino_packed_floats(int Cout, int Cin);
 int ossid_conv_pack_weights_wino(const float* w, int Cout, int Cin, int dgrad, float* wpk, void* stream);
 int ossid_conv3x3_wino_fwd(const ossid_conv_desc* desc_host, void* stream);
+/* two independent layers (the i-th convolutions of the classification and the regression trunk, network.py:113-121 /
+ * :146-154) in ONE grid: their workgroups fill the chip's slots together instead of each launch ending in a ragged round */
+int ossid_conv3x3_wino_fwd_pair(const ossid_conv_desc* desc0_host, const ossid_conv_desc* desc1_host, void* stream);
 
 /* D6 (tail)  the last two layers of the segmentation decoder in one launch (network.py:357-362):
  *   out[b][y][x] = b2 + conv3x3_{16->1}( post( ELU( b1 + conv3x3_{32->16}( nearest_upsample(x -> [H][W]) ) ) ) )

@@ -97,6 +97,7 @@ _PROTOS = {
     "ossid_conv_wino_packed_floats": (C.c_size_t, [_i, _i]),
     "ossid_conv_pack_weights_wino": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ossid_conv3x3_wino_fwd": (_i, [_vp, _vp]),
+    "ossid_conv3x3_wino_fwd_pair": (_i, [_vp, _vp, _vp]),
     "ossid_chan_op_partials": (_i, [C.c_longlong, _i]),
     "ossid_chan_op": (_i, [_vp, _vp]),
     "ossid_bn_fold_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

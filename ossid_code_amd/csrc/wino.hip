@@ -51,7 +51,7 @@ struct WinoArgs {
 
 constexpr int KCH = 16, F4 = 4, VBUF = 16 * 32 * F4;      // float4 per LDS buffer
 
-__global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs A) {
+__device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int block) {
     extern __shared__ __attribute__((aligned(16))) float4 vb[];   // [2][16 xi][32 tiles][4 quads]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
     const int wm = wave & 1, wx = wave >> 1;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs A) {
     // XCD streams the transformed weights of ONE channel group (64 x Cin x 16 floats: 2.6 MB at Cin = 640) through its L2
     int bx, by;
     {
-        const int L = blockIdx.x, P = A.gx;
+        const int L = block, P = A.gx;
         int pt;
         if (A.gy <= 8 && (8 % A.gy) == 0) {
             const int k = L & 7, R = 8 / A.gy, per = (P + R - 1) / R;
@@ -273,6 +273,20 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs A) {
     }
 }
 
+__global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs A) { wino_conv_body(A, blockIdx.x); }
+
+// Two independent layers in ONE grid (the classification and the regression trunk's i-th convolution, network.py:113-121 /
+// :146-154: same shapes, different inputs and weights): 2 x 788 workgroups fill the chip's 512 slots in 3.08 rounds
+// where two launches of 788 take 2 x 2.
+struct WinoPair {
+    WinoArgs a, b;
+    int n0;
+};
+__global__ __launch_bounds__(256, 2) void wino_conv_pair_kernel(const WinoPair G) {
+    if ((int)blockIdx.x < G.n0) wino_conv_body(G.a, blockIdx.x);
+    else wino_conv_body(G.b, blockIdx.x - G.n0);
+}
+
 // U = G g G^T packed as the kernel streams it. dgrad != 0: the weights of the data gradient (the transposed layer:
 // output channels = the forward's inputs, filter rotated by 180 degrees), w stays the forward [Cout][Cin][3][3].
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int dgrad,
@@ -298,7 +312,7 @@ int ossid_conv_pack_weights_wino(const float* w, int Cout, int Cin, int dgrad, f
     return ossid_launch_status();
 }
 
-int ossid_conv3x3_wino_fwd(const ossid_conv_desc* d, void* stream) {
+static int wino_args(const ossid_conv_desc* d, WinoArgs& a, long& nwg) {
     if (!d || !d->x || !d->wpk || !d->out) return OSSID_EINVAL;
     const int B = d->batch, H = d->height, W = d->width, Cin = d->cin, Cout = d->cout;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 16 || d->taps != 9 || d->act < 0 || d->act > 2)
@@ -306,7 +320,6 @@ int ossid_conv3x3_wino_fwd(const ossid_conv_desc* d, void* stream) {
     if ((d->src_height > 0 && d->src_height != H) || (d->src_width > 0 && d->src_width != W)) return OSSID_EINVAL;   // no fused up-sampling
     if (d->epi_aux || d->epi_alpha || d->epi_mask_scale || d->epi_mask_shift || d->epi_mask_mode || d->epi_accumulate || d->epi_sum_mode)
         return OSSID_EINVAL;                                                                                          // no training extras
-    WinoArgs a;
     a.x = d->x, a.wpk = (const float4*)d->wpk, a.bias = d->bias, a.bn_scale = d->post_scale, a.bn_shift = d->post_shift;
     a.pre_scale = d->pre_scale, a.pre_shift = d->pre_shift, a.out = d->out, a.pre_relu = d->pre_relu;
     a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout, a.n_cotiles = (Cout + 31) / 32, a.act = d->act;
@@ -323,16 +336,36 @@ int ossid_conv3x3_wino_fwd(const ossid_conv_desc* d, void* stream) {
     if (T > 0x7fffffffLL) return OSSID_EINVAL;
     a.T = (int)T;
     a.gx = (int)((T + 31) / 32), a.gy = (a.n_cotiles + 1) / 2;
-    const size_t lds = (size_t)2 * VBUF * 16;
-    OSSID_ENSURE_LDS(wino_conv_kernel, lds);
     const long P = a.gx;
-    long nwg;
     if (a.gy <= 8 && 8 % a.gy == 0)
         nwg = 8 * ((P + 8 / a.gy - 1) / (8 / a.gy));
     else
         nwg = P * a.gy;
-    if (nwg > 0x7fffffffL) return OSSID_EINVAL;
+    return nwg > 0x3fffffffL ? OSSID_EINVAL : OSSID_OK;
+}
+
+int ossid_conv3x3_wino_fwd(const ossid_conv_desc* d, void* stream) {
+    WinoArgs a;
+    long nwg = 0;
+    const int rc = wino_args(d, a, nwg);
+    if (rc != OSSID_OK) return rc;
+    const size_t lds = (size_t)2 * VBUF * 16;
+    OSSID_ENSURE_LDS(wino_conv_kernel, lds);
     hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)nwg), dim3(256), lds, (hipStream_t)stream, a);
+    return ossid_launch_status();
+}
+
+int ossid_conv3x3_wino_fwd_pair(const ossid_conv_desc* d0, const ossid_conv_desc* d1, void* stream) {
+    WinoPair g;
+    long n0 = 0, n1 = 0;
+    int rc = wino_args(d0, g.a, n0);
+    if (rc != OSSID_OK) return rc;
+    rc = wino_args(d1, g.b, n1);
+    if (rc != OSSID_OK) return rc;
+    g.n0 = (int)n0;
+    const size_t lds = (size_t)2 * VBUF * 16;
+    OSSID_ENSURE_LDS(wino_conv_pair_kernel, lds);
+    hipLaunchKernelGGL(wino_conv_pair_kernel, dim3((unsigned)(n0 + n1)), dim3(256), lds, (hipStream_t)stream, g);
     return ossid_launch_status();
 }
 

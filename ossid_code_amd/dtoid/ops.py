@@ -305,9 +305,8 @@ class PackedConv:
                 sc.copy_(a)
                 sh.copy_(b)
 
-    def run(self, x_nhwc, B, H, W, out_nhwc, in_cs=0, out_cs=0, out_coff=0, src_hw=(0, 0), in_bs=-1, pre=None):
-        """Raw call on physical [B][H][W][C] buffers (tensors only provide pointers). in_bs = 0: x is ONE image shared by
-        the whole batch; pre = (scale [B,Cin], shift [B,Cin]): a per-image input affine instead of the stored one."""
+    def _desc(self, x_nhwc, B, H, W, out_nhwc, in_cs=0, out_cs=0, out_coff=0, src_hw=(0, 0), in_bs=-1, pre=None):
+        """(ossid_conv_desc, entry name) of one launch; the Winograd form when the layer has it and the launch fills the chip."""
         d = _lib.ConvDesc()
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         d.x, d.wpk, d.bias, d.out = x_nhwc.data_ptr(), self.wpk.data_ptr(), p(self.bias), out_nhwc.data_ptr()
@@ -325,9 +324,30 @@ class PackedConv:
             # kernel's split-reduction variants are the better fit
             if ((B * ((H + 1) // 2) * ((W + 1) // 2) + 31) // 32) * ((self.cout + 63) // 64) >= WINO_MIN_WGS:
                 name, d.wpk = "ossid_conv3x3_wino_fwd", self.wpk_wino.data_ptr()
+        return d, name
+
+    def run(self, x_nhwc, B, H, W, out_nhwc, in_cs=0, out_cs=0, out_coff=0, src_hw=(0, 0), in_bs=-1, pre=None):
+        """Raw call on physical [B][H][W][C] buffers (tensors only provide pointers). in_bs = 0: x is ONE image shared by
+        the whole batch; pre = (scale [B,Cin], shift [B,Cin]): a per-image input affine instead of the stored one."""
+        d, name = self._desc(x_nhwc, B, H, W, out_nhwc, in_cs, out_cs, out_coff, src_hw, in_bs, pre)
         with _lib.on_device(out_nhwc.device):
             _lib.check(_lib.fn(name)(C_byref(d), _lib.stream()), name)
         return out_nhwc
+
+    @staticmethod
+    def run_pair(pk0, args0, pk1, args1):
+        """Two independent layers (args = the positional / keyword arguments of run() as (tuple, dict)): ONE grid when
+        both take the Winograd kernel (ossid_conv3x3_wino_fwd_pair), two launches otherwise."""
+        d0, n0 = pk0._desc(*args0[0], **args0[1])
+        d1, n1 = pk1._desc(*args1[0], **args1[1])
+        dev = args0[0][4].device
+        with _lib.on_device(dev):
+            if n0 == n1 == "ossid_conv3x3_wino_fwd":
+                _lib.check(_lib.fn("ossid_conv3x3_wino_fwd_pair")(C_byref(d0), C_byref(d1), _lib.stream()),
+                           "ossid_conv3x3_wino_fwd_pair")
+            else:
+                _lib.check(_lib.fn(n0)(C_byref(d0), _lib.stream()), n0)
+                _lib.check(_lib.fn(n1)(C_byref(d1), _lib.stream()), n1)
 
     def __call__(self, x, size=None):
         """x: logical [B,Cin,Hs,Ws] tensor (any memory format; channels_last is consumed in place) -> logical
