@@ -246,16 +246,23 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     float4 st[NLD];
     const float* xb = A.x + (size_t)b * A.in_bs;          // this image (in_bs = 0: every batch entry reads the same one)
     const int jch = 4 * (tid % F4);   // this thread always stages channels ci0 + jch .. +3 (256 % F4 == 0)
+    // the loads only: nothing here may wait for them (they fly under the chunk's MFMAs). The input affine (+ReLU) is
+    // applied in stage_write, when the chunk's matrix work has been issued -- done right behind the loads it would put
+    // an s_waitcnt in FRONT of the MFMA section and expose the whole memory latency once per chunk
+    int st_ci0 = 0;
     auto stage_load = [&](int ci0) {
         // a ragged LAST chunk (Cin no multiple of KCH) stages zeros for the channels past Cin; their weight quads are
         // clamped to the last real one (quad_of), and 0 x w adds nothing
         const bool chan_ok = ci0 + jch < A.Cin;
+        st_ci0 = ci0;
 #pragma unroll
         for (int e = 0; e < NLD; ++e)
             st[e] = (goff[e] >= 0 && chan_ok) ? *(const float4*)(xb + (size_t)goff[e] + ci0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (A.pre_scale && chan_ok) {   // BN(eval) (+ReLU) of the INPUT, on real pixels only: the zero halo stays zero
-            const float4 ps = *(const float4*)(A.pre_scale + (size_t)b * A.pre_bs + ci0 + jch),
-                         pt = *(const float4*)(A.pre_shift + (size_t)b * A.pre_bs + ci0 + jch);
+    };
+    auto stage_write = [&](int buf) {
+        if (A.pre_scale && st_ci0 + jch < A.Cin) {   // BN(eval) (+ReLU) of the INPUT, on real pixels only: the zero halo stays zero
+            const float4 ps = *(const float4*)(A.pre_scale + (size_t)b * A.pre_bs + st_ci0 + jch),
+                         pt = *(const float4*)(A.pre_shift + (size_t)b * A.pre_bs + st_ci0 + jch);
 #pragma unroll
             for (int e = 0; e < NLD; ++e) {
                 if (goff[e] < 0) continue;
@@ -265,8 +272,6 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
                 st[e] = v;
             }
         }
-    };
-    auto stage_write = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < NLD; ++e)
             if (lidx[e] >= 0) patch[(size_t)buf * A.buf_pos * F4P + lidx[e]] = st[e];
@@ -650,6 +655,9 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
         // chunks a 1x1 layer has only 8 MFMAs per wave between barriers. Measured on the batch-8 DenseNet layers
         // (64..1024 -> 128..640 at 9 k..154 k pixels): forward 45 -> 56, data gradient 55 -> 59 TFLOP/s over the set
         static const int exp1 = getenv("OSSID_CONV1_EXP") ? atoi(getenv("OSSID_CONV1_EXP")) : 0;   // A/B experiments only
+        if (tiles >= 4 && px >= 4096 && exp1 == 2) return launch_conv<2, 2, 1, false, 4, 1, 128>(a, B, s);
+        if (tiles >= 4 && px >= 4096 && exp1 == 3) return launch_conv<1, 4, 1, false, 8, 1, 256>(a, B, s);
+        if (tiles >= 4 && px >= 4096 && exp1 == 4) return launch_conv<4, 1, 2, false, 4, 1, 64>(a, B, s);
         if (tiles >= 4 && px >= 4096 && exp1 != 1) return launch_conv<4, 1, 1, false, 2, 1, 64>(a, B, s);
         if (plain_wgs < 160) return launch_conv<1, 4, 1, false, 8, 1, 256>(a, B, s);
         if (tiles >= 4)

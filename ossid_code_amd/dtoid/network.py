@@ -883,7 +883,20 @@ class Network(nn.Module):
             convs += [getattr(mod, "conv%d" % i) for i in (1, 2, 3, 4)] + [mod.output]
         plan = self.__dict__.get("_pack_plan")
         if plan is None or not plan.valid_for(convs):
-            plan = self.__dict__["_pack_plan"] = T.PackPlan(convs)
+            # which layouts the step asks for at finetune batch sizes (train_ops.wino_fits): the head's plain 3x3 layers run
+            # forward and data gradient on the Winograd kernel, the dense blocks' 3x3 only the data gradient; everything
+            # else (1x1, the decoder layers behind an up-sampling, layers with fewer than 64 output channels) the direct one
+            kinds = {}
+            plain = [corr.corr_conv_dot, corr.corr_conv_sub, corr.corr_conv_dot3x3, corr.cf, corr.s1] + \
+                [getattr(mod, "conv%d" % i) for mod in (self.classification, self.regression) for i in (1, 2, 3, 4)] + \
+                [self.regression.output]
+            for cv in plain:
+                kinds[cv] = ("wino_fwd", "wino_dgrad") if T.USE_WINO else ("fwd", "dgrad")
+            for m in list(ife.backdense_1) + list(ife.backdense_2):
+                if isinstance(m, DenseBlock):
+                    for layer in m.values():
+                        kinds[layer.conv2] = ("fwd", "wino_dgrad") if T.USE_WINO else ("fwd", "dgrad")
+            plan = self.__dict__["_pack_plan"] = T.PackPlan(convs, kinds)
         return plan
 
     def _head_train_hip(self, feat, local):
@@ -1016,21 +1029,18 @@ class Network(nn.Module):
         frame = {}
         for ci, chunk in enumerate(template_features):
             if fused is not None and self.use_branch_streams:
-                # the two detection trunks and the segmentation decoder only share their input: three HIP streams (three
-                # branches of the captured graph), so the ragged last round of workgroups of one branch's launches is
-                # filled by another's instead of leaving CUs idle
+                # the detection trunks and the segmentation decoder only share their input: two HIP streams, so the ragged
+                # last round of workgroups of one branch's launches is filled by the other's instead of leaving CUs idle
                 xc, heat, _ = fused.correlation(features, chunk, None if sides is None else sides[ci], frame, decoder=False)
                 cur = torch.cuda.current_stream(features.device)
-                sa, sb = self._branch_streams(features.device)
+                sa, _sb = self._branch_streams(features.device)
                 sa.wait_stream(cur)
-                sb.wait_stream(cur)
                 with torch.cuda.stream(sa):
-                    cls_out.append(fused.classification(xc))
-                with torch.cuda.stream(sb):
-                    reg_out.append(fused.regression(xc))
+                    c, r = fused.detection(xc)
+                cls_out.append(c)
+                reg_out.append(r)
                 seg = fused.decoder(xc)
                 cur.wait_stream(sa)
-                cur.wait_stream(sb)
             elif fused is not None:
                 xc, heat, seg = fused.correlation(features, chunk, None if sides is None else sides[ci], frame)
                 c, r = fused.detection(xc)

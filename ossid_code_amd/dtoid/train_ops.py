@@ -155,17 +155,18 @@ class PackPlan:
     of the forward pass instead of two small launches per layer. Built once per set of weight tensors (their addresses
     are stable: FlatParams views); `run()` marks them fresh so the per-layer _pack() calls only look the buffers up."""
 
-    def __init__(self, convs):
+    def __init__(self, convs, kinds=None):
+        """kinds: optional {conv: tuple of layouts} -- which of ("fwd", "dgrad", "wino_fwd", "wino_dgrad") the step will ask
+        for (a layout left out is simply packed by its layer's own _pack() launch if it is asked for after all)."""
         rows, keys, first = [], [], 0
         for conv in convs:
             w = conv.weight.detach()
             cout, cin, taps = int(w.shape[0]), int(w.shape[1]), int(w.shape[2] * w.shape[3])
-            for kind in ("fwd", "dgrad", "wino_fwd", "wino_dgrad"):
+            for kind in (("fwd", "dgrad") if kinds is None else kinds.get(conv, ("fwd", "dgrad"))):
                 if kind == "dgrad" and cout % 16:
                     continue
                 if kind == "fwd" and (cin % 16 or cout % 4):
                     continue
-                # the Winograd layouts of the layers wino_fits() can say yes to (its batch-independent conditions)
                 if kind == "wino_fwd" and not (USE_WINO and taps == 9 and cin % 16 == 0 and cout >= 64):
                     continue
                 if kind == "wino_dgrad" and not (USE_WINO and taps == 9 and cout % 16 == 0 and cin >= 64):
@@ -444,8 +445,10 @@ def _wgrad_async(tensors, fn, device):
     for t in tensors:
         if t is not None:
             t.record_stream(side)
-    if not _wg_dirty:
-        torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
+    # one callback per call, not "one while the set is empty": a backward pass that died in an exception never runs its
+    # callbacks, and a set left non-empty would then suppress the join of every later pass (the join itself is a no-op
+    # when nothing is in flight)
+    torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
     _wg_dirty.add(idx)
 
 
