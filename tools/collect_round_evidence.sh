@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collects the evidence files of a round on the GPU box into gpurun_out/<tag>/ (copied to profiles/ afterwards):
+#   tools/collect_round_evidence.sh r02
+set -e
+T=${1:-r02}
+O=gpurun_out/$T/ev
+mkdir -p $O
+R=$PWD
+python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+cd /tmp && export TMPDIR=/tmp && cd $R
+rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 > $O/bench_under_profiler.json 2> $O/stats.err
+cp $O/stats/*/*kernel_stats.csv $O/kernel_stats.csv
+rocprofv3 --kernel-trace -d $O/ft --output-format csv -- python3 tools/bench_finetune.py --reps 3 --no-graph > $O/ft.log 2>&1
+python tools/trace_step.py $O/ft/*/*kernel_trace.csv --top 45 > $O/finetune_step_kernels.txt
+rocprofv3 --kernel-trace -d $O/fw --output-format csv -- python3 tools/bench_dtoid.py --what forward > $O/fw.log 2>&1
+python tools/trace_step.py $O/fw/*/*kernel_trace.csv --marker nms_scan --top 40 > $O/forward_step_kernels.txt
+python tools/train_layers_bench.py --json $O/train_layers.json > $O/train_layers.txt 2>&1
+python tools/train_layers_bench.py --what fwd,dgrad --wino > $O/train_layers_wino.txt 2>&1
+python tools/train_layers_bench.py --what fwd --wino --batch 21 --only . > $O/forward_layers_wino_nt21.txt 2>&1
+rm -rf $O/stats $O/ft $O/fw
+ls -la $O
