@@ -851,7 +851,7 @@ class Network(nn.Module):
         n_px = B * x.shape[2] * x.shape[3]
         u, sums = T.bn_relu_conv(x, norm5, ife.c1, relu=False, act_elu=True, want_stats=True)
         s, t = T.bn_fold(sums, n_px, ife.n1)
-        feat = u * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)                 # n1(elu(c1(norm5(.)))), [B,640,29,39]
+        feat = T.AffineAct.apply(u, s, t, False)                             # n1(elu(c1(norm5(.)))), [B,640,29,39]: one pass
         if join_local is not None:
             self._join(join_local, [local])
         out = self._head_train_hip(feat, local)
@@ -939,14 +939,14 @@ class Network(nn.Module):
         if par:      # the two detection trunks beside the heat map + segmentation decoder
             (cls_raw, s_a) = self._fork(0, [u2, s2, t2_], lambda: trunk(self.classification))
             (reg_raw, s_b) = self._fork(1, [u2, s2, t2_], lambda: trunk(self.regression))
-        x2 = u2 * s2.view(1, -1, 1, 1) + t2_.view(1, -1, 1, 1)              # materialised once, for the 1-channel heat conv
+        x2 = T.AffineAct.apply(u2, s2, t2_, False)                          # materialised once, for the 1-channel heat conv
         heat_map = torch.sigmoid(corr.corr_conv_heatmap(x2))
         u, sc, sh = cab(u2, corr.s1, corr.ns1, pre=(s2, t2_))
         for i in (2, 3, 4):
             u, sc, sh = cab(u, getattr(corr, "s%d" % i), getattr(corr, "ns%d" % i), pre=(sc, sh),
                             size=(2 * u.shape[2], 2 * u.shape[3]))
         u, sc, sh = cab(u, corr.s5, corr.ns5, pre=(sc, sh), size=corr.img_size)
-        segmentation = corr.seg_final(u * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        segmentation = corr.seg_final(T.AffineAct.apply(u, sc, sh, False))
         if par:
             self._join(s_a, [cls_raw])
             self._join(s_b, [reg_raw])
