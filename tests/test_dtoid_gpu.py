@@ -862,3 +862,39 @@ def test_finetune_step_with_stem_and_template_encoders_on_own_kernels(hiplib):
         losses[own] = [float(finetune.finetune_step(m, batch, opt)) for _ in range(3)]
     assert abs(losses[True][0] - losses[False][0]) <= 2e-4 * abs(losses[False][0])
     assert all(np.isfinite(losses[True])) and losses[True][-1] < losses[True][0]
+
+
+@pytest.mark.gpu
+def test_side_streams_do_not_change_the_finetune_step(hiplib, monkeypatch):
+    """Weight gradients on the side stream (train_ops.WGRAD_SIDE) and the independent branches on theirs
+    (Network.use_train_streams) only reorder launches. The layers still on MIOpen (stem, template encoders) are not
+    run-to-run deterministic, so the yardstick is the one-stream step run twice: three steps with the streams must stay as
+    close to it as it stays to itself (a missing join or a recycled buffer shows up as garbage, not as rounding). The last
+    gradient is read straight after a bare loss.backward(): only the autograd-engine callback joins the side stream."""
+    from ossid_code_amd.dtoid import train_ops
+    cfg = dtoid.DtoidConfig()
+    results = []
+    for streams in (False, False, True):
+        monkeypatch.setattr(train_ops, "WGRAD_SIDE", streams)
+        torch.manual_seed(6)
+        m = dtoid.DtoidNet(cfg).cuda().train()
+        m.model.use_train_streams = streams
+        flat = finetune.FlatParams(m)
+        opt = finetune.FusedAMSGrad(flat, lr=1e-4, weight_decay=1e-6)
+        batches = [_batch(cfg, 4, "cuda", seed=s) for s in (0, 1, 2)]
+        losses = [float(finetune.finetune_step(m, b, opt)) for b in batches]
+        flat.detach_grads()
+        m(batches[0])["loss"].backward()                       # no finetune_step around it
+        grads = [m.model.correlation_model.cf.weight.grad.double().cpu(), m.model.regression.conv3.weight.grad.double().cpu(),
+                 m.model.image_feature_extractor.c1.weight.grad.double().cpu()]
+        results.append((losses, grads))
+
+    def dist(a, b):
+        dl = max(abs(x - y) / abs(x) for x, y in zip(a[0], b[0]))
+        dg = max(float((x - y).norm() / x.norm()) for x, y in zip(a[1], b[1]))
+        return dl, dg
+    noise_l, noise_g = dist(results[0], results[1])
+    dl, dg = dist(results[0], results[2])
+    assert dl <= max(3 * noise_l, 1e-5), (dl, noise_l)
+    assert dg <= max(3 * noise_g, 1e-4), (dg, noise_g)
+    assert all(np.isfinite(results[2][0]))

@@ -87,3 +87,56 @@ def test_wino_rejects_what_it_does_not_do(T):
         T.conv_raw(x, wpk, 1, 4, 4, 16, 32, 1, out, wino=True)           # not a 3x3
     with pytest.raises(Exception):
         T.conv_raw(x, wpk, 1, 4, 4, 16, 32, 9, out, wino=True, src_hw=(2, 2))   # fused up-sampling
+
+
+def test_wino_pair_launch_equals_two_launches(T):
+    """ossid_conv3x3_wino_fwd_pair: two independent layers in one grid, bit-equal to launching them one by one."""
+    import ctypes
+    from ossid_code_amd import _lib
+    g = torch.Generator().manual_seed(21)
+    outs = []
+    descs = []
+    keep = []
+    for (B, cin, cout, H, W) in ((3, 64, 96, 9, 7), (2, 32, 64, 12, 5)):
+        x = nhwc(torch.randn(B, cin, H, W, generator=g).cuda())
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).cuda()
+        bias = torch.randn(cout, generator=g).cuda()
+        single = T.empty_nhwc(B, cout, H, W, "cuda")
+        T.conv_raw(x, T._pack(w, "wino_fwd"), B, H, W, cin, cout, 9, single, bias=bias, act=1, wino=True)
+        out = T.empty_nhwc(B, cout, H, W, "cuda")
+        d = _lib.ConvDesc()
+        d.x, d.wpk, d.bias, d.out = x.data_ptr(), T._pack(w, "wino_fwd").data_ptr(), bias.data_ptr(), out.data_ptr()
+        d.in_batch_stride, d.batch, d.height, d.width, d.cin, d.cout, d.taps, d.act = -1, B, H, W, cin, cout, 9, 1
+        descs.append(d)
+        outs.append((single, out))
+        keep += [x, w, bias]
+    rc = _lib.fn("ossid_conv3x3_wino_fwd_pair")(ctypes.byref(descs[0]), ctypes.byref(descs[1]), _lib.stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    for single, out in outs:
+        assert torch.equal(single, out)
+    descs[1].cin = 24                                            # one bad descriptor rejects the pair
+    assert _lib.fn("ossid_conv3x3_wino_fwd_pair")(ctypes.byref(descs[0]), ctypes.byref(descs[1]), _lib.stream()) != 0
+
+
+def test_pack_table_winograd_rows_equal_the_standalone_pack(T):
+    """ossid_conv_pack_weights_table kinds 2 / 3 (the one-launch pack of a training step) write the same bytes as
+    ossid_conv_pack_weights_wino."""
+    class Conv:
+        pass
+    g = torch.Generator().manual_seed(8)
+    convs = []
+    for cout, cin in ((64, 64), (96, 128)):      # both layouts exist for these (the plan skips layouts the step never asks for)
+        c = Conv()
+        c.weight = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).cuda()
+        convs.append(c)
+    want = {(i, k): T._pack(c.weight, k).clone() for i, c in enumerate(convs) for k in ("wino_fwd", "wino_dgrad")}
+    for c in convs:
+        for k in ("wino_fwd", "wino_dgrad"):
+            T._Packed.get(c.weight, k).zero_()
+    plan = T.PackPlan(convs, {c: ("wino_fwd", "wino_dgrad") for c in convs})
+    plan.run()
+    for i, c in enumerate(convs):
+        for k in ("wino_fwd", "wino_dgrad"):
+            assert torch.equal(T._Packed.get(c.weight, k), want[(i, k)]), (i, k)
+    T.end_step()
