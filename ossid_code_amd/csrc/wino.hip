@@ -47,6 +47,7 @@ struct WinoArgs {
     long long in_bs;
     int TH, TW, T;     // tiles per image (rows, columns), tiles in the batch
     int gx, gy;        // groups of 32 tiles, groups of 2 channel tiles
+    float* dbg;        // -DOSSID_TIMING builds: per-wave time stamps (tools/conv_timeline.py --wino)
 };
 
 constexpr int KCH = 16, F4 = 4, VBUF = 16 * 32 * F4;      // float4 per LDS buffer
@@ -55,6 +56,27 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     extern __shared__ __attribute__((aligned(16))) float4 vb[];   // [2][16 xi][32 tiles][4 quads]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
     const int wm = wave & 1, wx = wave >> 1;
+#ifdef OSSID_TIMING   // diagnostic build only: per-wave s_memrealtime stamps (100 MHz), shader cycles of the main loop, HW_ID
+    auto tnow = []() {
+        unsigned long long t;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+        return t;
+    };
+    auto cnow = []() {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+        return t;
+    };
+    unsigned long long tstamp[4] = {tnow(), 0, 0, 0}, cstamp[2] = {0, 0};
+    auto tdump = [&]() {
+        if (lane == 0 && A.dbg) {
+            unsigned long long* o = (unsigned long long*)A.dbg + ((size_t)block * 4 + wave) * 6;
+            o[0] = tstamp[0], o[1] = tstamp[1], o[2] = tstamp[2], o[3] = tstamp[3];
+            o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) | ((cstamp[1] - cstamp[0]) << 8);
+        }
+    };
+#endif
     // ---- logical block (bx = tile group, by = channel group) from the 1-D launch id, XCD-aware as in conv.hip: every
     // XCD streams the transformed weights of ONE channel group (64 x Cin x 16 floats: 2.6 MB at Cin = 640) through its L2
     int bx, by;
@@ -77,6 +99,11 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
         bx = pt;
     }
     const int H = A.H, W = A.W, TPI = A.TH * A.TW;
+#ifdef OSSID_WINO_STAGGER
+    // the second workgroup a CU receives (ids 256..511 of a round-robin deal) starts half a chunk late, so that the two
+    // co-resident workgroups do not meet in their transform phases
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(OSSID_WINO_STAGGER);
+#endif
 
     // ---- staging role: (tile tl, channel quad j, transform half ih) -> 3 patch rows x 4 columns ------------------
     const int j = tid & 3, tl = (tid >> 2) & 31, ih = __builtin_amdgcn_readfirstlane(tid >> 7);   // (wave-uniform)
@@ -172,6 +199,10 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
 #pragma unroll
     for (int i = 0; i < 4; ++i) cur[i] = W4[(size_t)quad_of(0, i) * 64];
     __syncthreads();
+#ifdef OSSID_TIMING
+    tstamp[1] = tnow();
+    cstamp[0] = cnow();
+#endif
 
     int gi = 0;
 #pragma unroll 1
@@ -205,6 +236,10 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
         __syncthreads();
     }
 
+#ifdef OSSID_TIMING
+    cstamp[1] = cnow();
+    tstamp[2] = tnow();
+#endif
     // ---- output transform. M[i][j] = acc[(i - 2wx) * 4 + j]. S = this half's share of A^T M (rows a = 0, 1), then
     // P[a][b] = (S A)[a][b]; the wave keeps row a = wx and hands row 1 - wx to its partner through LDS (V is dead).
     v16f keep[2], give[2];
@@ -231,15 +266,18 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
 #pragma unroll
         for (int r = 0; r < 16; ++r) keep[b2][r] += ex[((size_t)((wm * 2 + (1 - wx)) * 2 + b2) * 16 + r) * 64 + lane];
 
+#ifdef OSSID_TIMING
+    if (!active) { tstamp[3] = tnow(); tdump(); return; }
+#endif
     if (!active) return;
     // ---- epilogue: bias -> (ELU / ReLU) -> per-channel affine -> 16-byte stores of output row 2 ty + wx --------------
     const int gt = bx * 32 + c;
-    if (gt >= A.T) return;
-    const int b = gt / TPI, rem = gt - b * TPI, ty = rem / A.TW, tx = rem - ty * A.TW;
+    const bool tile_ok = gt < A.T;
+    const int b = tile_ok ? gt / TPI : 0, rem = tile_ok ? gt - b * TPI : 0, ty = rem / A.TW, tx = rem - ty * A.TW;
     const int oy = 2 * ty + wx;
-    if (oy >= H) return;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+        if (!tile_ok || oy >= H) break;
         const int co = co_tile * 32 + 8 * q + 4 * h;
         float bi[4], sc[4], sh[4];
 #pragma unroll
@@ -271,6 +309,11 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
             }
         }
     }
+#ifdef OSSID_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    tstamp[3] = tnow();
+    tdump();
+#endif
 }
 
 __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs A) { wino_conv_body(A, blockIdx.x); }
@@ -328,6 +371,7 @@ static int wino_args(const ossid_conv_desc* d, WinoArgs& a, long& nwg) {
     a.pre_bs = d->pre_batch_stride;
     a.out_cs = d->out_channel_stride > 0 ? d->out_channel_stride : Cout;
     a.out_coff = d->out_channel_offset;
+    a.dbg = d->epi_partials;
     if (a.in_cs < Cin || a.out_cs < a.out_coff + Cout || (a.in_cs % 4) || (a.out_cs % 4) || (a.out_coff % 4) ||
         (a.pre_scale && !a.pre_shift) || (a.in_bs % 4) || a.pre_bs < 0 || (a.pre_bs % 4) || (long long)H * W * a.in_cs > 0x7fffffffLL)
         return OSSID_EINVAL;

@@ -22,17 +22,18 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--taps", type=int, default=9)
     ap.add_argument("--pre", action="store_true")
+    ap.add_argument("--wino", action="store_true", help="the Winograd kernel (csrc/wino.hip) instead of the direct one")
     a = ap.parse_args()
     B, cin, cout, (H, W), taps = a.batch, a.cin, a.cout, a.hw, a.taps
     k = 3 if taps == 9 else 1
     x = torch.randn(B, cin, H, W).cuda().contiguous(memory_format=torch.channels_last)
     w = (torch.randn(cout, cin, k, k) * 0.05).cuda()
-    wpk = T._pack(w, "fwd")
+    wpk = T._pack(w, "wino_fwd" if a.wino else "fwd")
     out = T.empty_nhwc(B, cout, H, W, "cuda")
     pre = (torch.rand(cin).cuda() + 0.5, torch.randn(cin).cuda() * 0.1) if a.pre else None
     buf = torch.zeros(6 << 20, dtype=torch.int64, device="cuda")
     tb = buf.view(torch.float32)
-    run = lambda: T.conv_raw(x, wpk, B, H, W, cin, cout, taps, out, pre=pre, pre_relu=a.pre, epi={"timing_buf": tb})
+    run = lambda: T.conv_raw(x, wpk, B, H, W, cin, cout, taps, out, pre=pre, pre_relu=a.pre, epi={"timing_buf": tb}, wino=a.wino)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -95,7 +96,7 @@ def main():
           (res.mean() / span, loop.mean() / span, first.mean() / span, last.mean() / span))
     print("mean waves concurrently in the main loop while any is: %.2f" % (loopsum.sum() / loop.sum()))
     # MFMA time owed per SIMD: every wave issues the same count
-    n_mfma_wave = flops / 4096.0 / len(r) * 1.0
+    n_mfma_wave = flops / 4096.0 / len(r) * (16.0 / 36.0 if a.wino else 1.0)     # Winograd: 16 of the 36 multiplies
     # s_memtime runs at a fixed 100 MHz-class clock on some parts: derive shader cycles from the event time at 2.4 GHz
     cyc_per_tick = ghz.mean() * 1000.0 / tick_us
     owed = np.array([len(idx) for idx in per.values()]) * n_mfma_wave * 64.0 / cyc_per_tick
