@@ -815,7 +815,7 @@ class Network(nn.Module):
         for t in outputs:
             t.record_stream(main)
 
-    def _forward_train_hip(self, image, g, local, join_local=None):
+    def _forward_train_hip(self, image, g, local, join_local=None, join_g=None):
         """Training-mode forward of everything behind the two template encoders on csrc/conv.hip + csrc/train.hip,
         channels-last end to end (same arithmetic as the module path below; BatchNorm batch statistics folded into the
         next convolution's input staging). Returns (classifications, regression, anchors, heat_map, segmentation)."""
@@ -828,11 +828,17 @@ class Network(nn.Module):
             # stem on this repo's kernels, channels-last from the first one: im2col -> 1x1 MFMA conv (weight gradient
             # by the same 1x1 wgrad kernel), template modulation, training BatchNorm + ReLU, max-pool
             conv0 = ife.backdense_0[0]
+            if join_g is not None:
+                self._join(join_g, [g])
+                join_g = None
             x0 = T.FusedConv.apply(ops.im2col_stem(image, 7, 2, 3, 160), T.relaid_stem_weight(conv0, 160), conv0.bias, None,
                                    None, False, 0, None, False)
             x = T.MaxPoolNHWC.apply(T.bn_act_train(T.DwXcorrAdd.apply(x0, g), seq[0], relu=True), 3, 2, 1, False)
         else:
             x0 = ife.backdense_0(image)
+            if join_g is not None:
+                self._join(join_g, [g])
+                join_g = None
             x0 = x0 + ops.dw_xcorr(x0, g)
             x = x0
             for m in seq[:3]:                                    # stem: 64 channels at 240x320, on torch
@@ -975,13 +981,17 @@ class Network(nn.Module):
             local = self._template_encoder_train_hip(self.template_feature_extractor,
                                                      torch.cat([template, template_mask], dim=1))
         else:
-            g = self.template_feature_extractor_global(torch.cat([global_template, global_template_mask], dim=1))
             if hip_train and self._branches_on(image.device):
-                # the local encoder's output is first read by the head: it runs beside the image backbone
+                # the local encoder's output is first read by the head: it runs beside the image backbone; the global
+                # one is read right behind the stem convolution: it runs beside that, and -- what matters more -- its
+                # backward runs beside the stem's at the tail of the step
+                (g, s_g) = self._fork(3, [global_template, global_template_mask],
+                                      lambda: self.template_feature_extractor_global(
+                                          torch.cat([global_template, global_template_mask], dim=1)))
                 (local, s_loc) = self._fork(2, [template, template_mask],
                                             lambda: self.template_feature_extractor(torch.cat([template, template_mask], dim=1)))
-                out = self._forward_train_hip(image, g, local, join_local=s_loc)
-                return out
+                return self._forward_train_hip(image, g, local, join_local=s_loc, join_g=s_g)
+            g = self.template_feature_extractor_global(torch.cat([global_template, global_template_mask], dim=1))
             local = self.template_feature_extractor(torch.cat([template, template_mask], dim=1))
         if hip_train:
             return self._forward_train_hip(image, g, local)
