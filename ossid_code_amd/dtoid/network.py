@@ -815,7 +815,7 @@ class Network(nn.Module):
         for t in outputs:
             t.record_stream(main)
 
-    def _forward_train_hip(self, image, g, local, join_local=None, join_g=None):
+    def _forward_train_hip(self, image, g, local, lazy_g=None, lazy_local=None):
         """Training-mode forward of everything behind the two template encoders on csrc/conv.hip + csrc/train.hip,
         channels-last end to end (same arithmetic as the module path below; BatchNorm batch statistics folded into the
         next convolution's input staging). Returns (classifications, regression, anchors, heat_map, segmentation)."""
@@ -828,26 +828,30 @@ class Network(nn.Module):
             # stem on this repo's kernels, channels-last from the first one: im2col -> 1x1 MFMA conv (weight gradient
             # by the same 1x1 wgrad kernel), template modulation, training BatchNorm + ReLU, max-pool
             conv0 = ife.backdense_0[0]
-            if join_g is not None:
-                self._join(join_g, [g])
-                join_g = None
             x0 = T.FusedConv.apply(ops.im2col_stem(image, 7, 2, 3, 160), T.relaid_stem_weight(conv0, 160), conv0.bias, None,
                                    None, False, 0, None, False)
+            if lazy_g is not None:
+                g, s_g = lazy_g()
+                self._join(s_g, [g])
             x = T.MaxPoolNHWC.apply(T.bn_act_train(T.DwXcorrAdd.apply(x0, g), seq[0], relu=True), 3, 2, 1, False)
         else:
             x0 = ife.backdense_0(image)
-            if join_g is not None:
-                self._join(join_g, [g])
-                join_g = None
+            if lazy_g is not None:
+                g, s_g = lazy_g()
+                self._join(s_g, [g])
             x0 = x0 + ops.dw_xcorr(x0, g)
             x = x0
             for m in seq[:3]:                                    # stem: 64 channels at 240x320, on torch
                 x = m(x)
             x = T.nhwc(x)
         norm5 = None
+        join_local, n_blocks = None, 0
         for m in seq[3:]:
             if isinstance(m, DenseBlock):
                 x = T.dense_block_train(x, m)
+                n_blocks += 1
+                if n_blocks == 2 and lazy_local is not None:          # (see forward(): the middle of the backbone)
+                    local, join_local = lazy_local()
             elif isinstance(m, Transition):
                 stride = m.pool.stride if isinstance(m.pool.stride, int) else m.pool.stride[0]
                 x = T.AvgPool2.apply(T.bn_relu_conv(x, m.norm, m.conv), stride)
@@ -982,15 +986,17 @@ class Network(nn.Module):
                                                      torch.cat([template, template_mask], dim=1))
         else:
             if hip_train and self._branches_on(image.device):
-                # the local encoder's output is first read by the head: it runs beside the image backbone; the global
-                # one is read right behind the stem convolution: it runs beside that, and -- what matters more -- its
-                # backward runs beside the stem's at the tail of the step
-                (g, s_g) = self._fork(3, [global_template, global_template_mask],
-                                      lambda: self.template_feature_extractor_global(
-                                          torch.cat([global_template, global_template_mask], dim=1)))
-                (local, s_loc) = self._fork(2, [template, template_mask],
+                # both encoders run on side streams, and WHEN the host enqueues them matters as much as where they run
+                # (each is ~100 small launches: 1-2 ms of host time, and autograd replays backward in reverse order of
+                # creation): the global one right behind the stem convolution that does not need it; the local one in the
+                # middle of the backbone, so that its backward is enqueued in the middle of the backbone's backward, while
+                # the host is ahead of the device, instead of as a host-bound tail behind everything else
+                lazy_g = lambda: self._fork(3, [global_template, global_template_mask],          # noqa: E731
+                                            lambda: self.template_feature_extractor_global(
+                                                torch.cat([global_template, global_template_mask], dim=1)))
+                lazy_l = lambda: self._fork(2, [template, template_mask],                        # noqa: E731
                                             lambda: self.template_feature_extractor(torch.cat([template, template_mask], dim=1)))
-                return self._forward_train_hip(image, g, local, join_local=s_loc, join_g=s_g)
+                return self._forward_train_hip(image, None, None, lazy_g=lazy_g, lazy_local=lazy_l)
             g = self.template_feature_extractor_global(torch.cat([global_template, global_template_mask], dim=1))
             local = self.template_feature_extractor(torch.cat([template, template_mask], dim=1))
         if hip_train:
