@@ -75,10 +75,14 @@ def test_module_path_and_postprocessing_match_full_size_reference_fixture():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dot_gemm", [False, True])
-def test_fused_head_product_path_matches_full_size_reference_fixture(hiplib, dot_gemm):
+@pytest.mark.parametrize("dot_gemm,wino", [(False, False), (True, False), (False, True), (True, True)])
+def test_fused_head_product_path_matches_full_size_reference_fixture(hiplib, dot_gemm, wino, monkeypatch):
     """FusedHead (hand-written MFMA convolutions, fused decoder tail, sub / dot / phase reassociations), chunk by chunk as
-    forward_all_templates drives it, directly against the reference's outputs."""
+    forward_all_templates drives it, directly against the reference's outputs. wino: every plain 3x3 layer with >= 64 output
+    channels on the Winograd kernel (at the fixture's two templates per chunk the product's dispatch would keep the direct
+    kernel: the workgroup threshold is lowered to force it), trunks through detection() (merged first layer, paired launches)."""
+    from ossid_code_amd.dtoid import ops
+    monkeypatch.setattr(ops, "WINO_MIN_WGS", 1 if wino else 10 ** 9)
     net = build_net("cuda")
     feat, tmpl = inputs("cuda")
     fused = net._fused_head()
@@ -88,7 +92,7 @@ def test_fused_head_product_path_matches_full_size_reference_fixture(hiplib, dot
         parts = []
         for t in tmpl:
             x2, heat, seg = fused.correlation(feat, t, None, frame)
-            parts.append((x2, heat, seg, fused.classification(x2), fused.regression(x2)))
+            parts.append((x2, heat, seg) + (fused.detection(x2) if wino else (fused.classification(x2), fused.regression(x2))))
         x2, heat, seg, cls, reg = (torch.cat([p[i] for p in parts]) for i in range(5))
     check_dense(x2, heat, seg, cls, reg, 1e-4)
     with torch.no_grad():

@@ -642,11 +642,16 @@ def test_network_forward_on_pairs_eval_runs_on_the_fused_kernels_and_matches_the
 
 
 @pytest.mark.gpu
-def test_hip_training_head_matches_reference_golden(hiplib):
+@pytest.mark.parametrize("wino", [False, True])
+def test_hip_training_head_matches_reference_golden(hiplib, wino, monkeypatch):
     """The PRODUCT training path of the head (Network._head_train_hip: FusedConv / BNFold / wgrad / chan_op kernels,
     channels-last, BatchNorm folded into the next conv) against the REFERENCE's forward and backward
     (tests/golden/dtoid_head.npz, produced by the reference classes): outputs, the four losses, and the gradients with
-    respect to both inputs and a sample of parameters -- same keys and tolerances as the module-path test above."""
+    respect to both inputs and a sample of parameters -- same keys and tolerances as the module-path test above.
+    wino: forward and data gradient of every plain 3x3 layer on the Winograd kernel (the fixture's 4x5 grid is far
+    below the dispatch threshold, which is lowered to force it), with the branches on their side streams either way."""
+    from ossid_code_amd.dtoid import train_ops
+    monkeypatch.setattr(train_ops, "WINO_MIN_WGS", 1 if wino else 10 ** 9)
     from test_dtoid_cpu import GRID, IMG, SEED, seeded_inputs, seeded_state
     net = dtoid.Network(img_size=IMG, heatmap_size=GRID)
     for i, m in enumerate((net.correlation_model, net.classification, net.regression)):
