@@ -83,6 +83,13 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     {
         const int L = block, P = A.gx;
         int pt;
+#ifdef OSSID_WINO_MAP_TILES      // A/B: an XCD owns tile groups (all channel groups of each) instead of one channel group
+        if (true) {
+            const int xcd = L & 7, idx = L >> 3;
+            by = idx % A.gy;
+            pt = (idx / A.gy) * 8 + xcd;
+        } else
+#endif
         if (A.gy <= 8 && (8 % A.gy) == 0) {
             const int k = L & 7, R = 8 / A.gy, per = (P + R - 1) / R;
             by = k % A.gy;
@@ -381,10 +388,14 @@ static int wino_args(const ossid_conv_desc* d, WinoArgs& a, long& nwg) {
     a.T = (int)T;
     a.gx = (int)((T + 31) / 32), a.gy = (a.n_cotiles + 1) / 2;
     const long P = a.gx;
+#ifdef OSSID_WINO_MAP_TILES
+    nwg = ((P + 7) / 8) * 8 * a.gy;
+#else
     if (a.gy <= 8 && 8 % a.gy == 0)
         nwg = 8 * ((P + 8 / a.gy - 1) / (8 / a.gy));
     else
         nwg = P * a.gy;
+#endif
     return nwg > 0x3fffffffL ? OSSID_EINVAL : OSSID_OK;
 }
 
