@@ -89,7 +89,10 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     constexpr int GPC = TAPS == 9 ? NKB * 3 : (TAPS == 4 ? NKB * 2 : NKB / GQ);   // groups per chunk per wave
     static_assert(WM * WK * WN == 4 && KCH % (8 * WK) == 0 && 256 % F4 == 0, "bad tiling");
     extern __shared__ __attribute__((aligned(16))) float4 patch[];   // [2][buf_pos][F4P]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    // the wave id is uniform, and the compiler must KNOW it: the weight-quad index (channel tile, chunk, tap) is then scalar
+    // arithmetic and a weight load costs one vector instruction (base + lane) instead of six
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wk = (wave / WM) % WK, wn = wave / (WM * WK);
 #ifdef OSSID_TIMING   // diagnostic build only (tools/conv_timeline.py): per-wave s_memrealtime stamps (100 MHz, one clock for the whole chip) + HW_ID go to e_partials
     auto tnow = []() {
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     const int co_tile = by * WM + wm;
     const bool active = co_tile < A.n_cotiles;
     const int nq = (A.Cin / 8) * TAPS;                          // weight quads per channel tile
-    const float4* W4 = A.wpk + ((size_t)phase * A.n_cotiles + (active ? co_tile : 0)) * nq * 64 + lane;
+    const float4* W4 = A.wpk + ((size_t)phase * A.n_cotiles + (active ? co_tile : 0)) * nq * 64;     // (+ lane at the load)
 
     v16f acc[NT];
     {
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
 #pragma unroll
     for (int d = 0; d < PF; ++d)
 #pragma unroll
-        for (int i = 0; i < GQ; ++i) wq[d][i] = W4[(size_t)quad_of(d, i) * 64];
+        for (int i = 0; i < GQ; ++i) wq[d][i] = W4[(size_t)quad_of(d, i) * 64 + lane];
     __syncthreads();
 #ifdef OSSID_TIMING
     tstamp[1] = tnow();
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         for (int g = 0; g < GPC; ++g) {
 #pragma unroll
 #ifndef OSSID_ABL_NOW
-            for (int i = 0; i < GQ; ++i) wq[PF][i] = W4[(size_t)quad_of(gi + PF, i) * 64];
+            for (int i = 0; i < GQ; ++i) wq[PF][i] = W4[(size_t)quad_of(gi + PF, i) * 64 + lane];
 #else
             for (int i = 0; i < GQ; ++i) wq[PF][i] = wq[0][i];
 #endif

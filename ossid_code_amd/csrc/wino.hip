@@ -31,6 +31,8 @@
 namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));      // (vector arithmetic lowers to v_pk_add_f32 with neg modifiers)
 
 __device__ __forceinline__ v16f mfma(float a, float b, v16f c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -47,6 +49,7 @@ struct WinoArgs {
     long long in_bs;
     int TH, TW, T;     // tiles per image (rows, columns), tiles in the batch
     int gx, gy;        // groups of 32 tiles, groups of 2 channel tiles
+    unsigned x_bytes;  // extent of x in bytes (the staging loads are bounds-checked buffer loads)
     float* dbg;        // -DOSSID_TIMING builds: per-wave time stamps (tools/conv_timeline.py --wino)
 };
 
@@ -54,7 +57,8 @@ constexpr int KCH = 16, F4 = 4, VBUF = 16 * 32 * F4;      // float4 per LDS buff
 
 __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int block) {
     extern __shared__ __attribute__((aligned(16))) float4 vb[];   // [2][16 xi][32 tiles][4 quads]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform TO THE COMPILER: weight addresses become scalar
     const int wm = wave & 1, wx = wave >> 1;
 #ifdef OSSID_TIMING   // diagnostic build only: per-wave s_memrealtime stamps (100 MHz), shader cycles of the main loop, HW_ID
     auto tnow = []() {
@@ -114,17 +118,19 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
 
     // ---- staging role: (tile tl, channel quad j, transform half ih) -> 3 patch rows x 4 columns ------------------
     const int j = tid & 3, tl = (tid >> 2) & 31, ih = __builtin_amdgcn_readfirstlane(tid >> 7);   // (wave-uniform)
-    int gbase = 0;              // float offset of patch element (row ih, column 0), possibly outside the image
+    // Staging loads are bounds-checked buffer loads: an element outside the image (or of a tile past the last) gets the
+    // byte offset 0xffffffff and the hardware returns zeros -- no per-lane branch, no select of the four loaded words.
+    // Which lanes hold a real pixel for patch element k is wave-uniform DATA (a 64-bit lane mask in scalar registers,
+    // built once): one v_cndmask per load picks the offset.
+    unsigned gbase = 0;         // BYTE offset of patch element (row ih, column 0) incl. the image, possibly "negative"
     unsigned gmask = 0;         // bit r*4+cc: that element is a real pixel
-    const float* xb = A.x;
     const float *psb = A.pre_scale, *ptb = A.pre_shift;
     {
         const int gt = bx * 32 + tl;
         const bool tv = gt < A.T;
         const int b = tv ? gt / TPI : 0, rem = tv ? gt - b * TPI : 0, ty = rem / A.TW, tx = rem - ty * A.TW;
-        xb += (size_t)b * A.in_bs;
         if (psb) psb += (size_t)b * A.pre_bs, ptb += (size_t)b * A.pre_bs;
-        gbase = ((2 * ty - 1 + ih) * W + 2 * tx - 1) * A.in_cs + 4 * j;
+        gbase = (unsigned)(((long long)b * A.in_bs + ((2 * ty - 1 + ih) * W + 2 * tx - 1) * A.in_cs + 4 * j) * 4);
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -133,51 +139,66 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
                 if (tv && yy >= 0 && yy < H && xx >= 0 && xx < W) gmask |= 1u << (r * 4 + cc);
             }
     }
-    const int rstride = W * A.in_cs;
-    float4 st[3][4];
+    unsigned long long lanes[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) lanes[k] = __ballot((gmask >> k) & 1);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)A.x, 0, A.x_bytes, 0x00020000);
+    const int rstride = W * A.in_cs * 4, cstride = A.in_cs * 4;          // bytes
+    v4f st[3][4];
     auto stage_load = [&](int ci0) {
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc)
-                st[r][cc] = (gmask >> (r * 4 + cc)) & 1 ? *(const float4*)(xb + (ptrdiff_t)(gbase + r * rstride + cc * A.in_cs + ci0))
-                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (psb) {      // affine (+ReLU) of the INPUT on real pixels only: the zero padding stays zero
-            const float4 ps = *(const float4*)(psb + ci0 + 4 * j), pt = *(const float4*)(ptb + ci0 + 4 * j);
+            for (int cc = 0; cc < 4; ++cc) {
+                unsigned off = gbase + (unsigned)(r * rstride + cc * cstride + ci0 * 4);
+                asm("v_cndmask_b32 %0, -1, %1, %2" : "=v"(off) : "v"(off), "s"(lanes[r * 4 + cc]));
+                const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0);
+                st[r][cc] = __builtin_bit_cast(v4f, v);
+            }
+        if (psb) {      // affine (+ReLU) of the INPUT on real pixels only: the zero padding stays zero (x validity, 0 or 1)
+            const v4f ps = *(const v4f*)(psb + ci0 + 4 * j), pt = *(const v4f*)(ptb + ci0 + 4 * j);
+            const float lo1 = A.pre_relu ? 0.0f : -__builtin_inff();        // ReLU or nothing as ONE max (no per-word select)
+            const v4f lo = {lo1, lo1, lo1, lo1};
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
-                    if (!((gmask >> (r * 4 + cc)) & 1)) continue;
-                    float4 v = st[r][cc];
-                    v.x = v.x * ps.x + pt.x, v.y = v.y * ps.y + pt.y, v.z = v.z * ps.z + pt.z, v.w = v.w * ps.w + pt.w;
-                    if (A.pre_relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
-                    st[r][cc] = v;
+                    float ok;
+                    asm("v_cndmask_b32 %0, 0, 1.0, %1" : "=v"(ok) : "s"(lanes[r * 4 + cc]));
+                    st[r][cc] = __builtin_elementwise_max(st[r][cc] * ps + pt, lo) * ok;
                 }
         }
     };
     // rows of B^T d for this half (loaded patch rows p, q, s = rows ih, ih+1, ih+2 of d), then the column transform
     auto transform_write = [&](int buf) {
-        float4* o = vb + (size_t)buf * VBUF + (size_t)tl * F4 + j;
+        v4f* o = (v4f*)(vb + (size_t)buf * VBUF + (size_t)tl * F4 + j);
 #ifdef OSSID_WABL_NOTRANSFORM
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[(size_t)(8 * ih + k) * 32 * F4] = st[k % 3][k & 3];
         return;
 #endif
+        // a - b as fma(b, -1, a): exact, and one v_pk_fma_f32 per two floats where a plain subtraction is scalarised
+        const v4f m1 = {-1.f, -1.f, -1.f, -1.f};
+        auto sub = [&](v4f x, v4f y) { return __builtin_elementwise_fma(y, m1, x); };
+        auto cols = [&](int i, const v4f (&R)[4]) {
+            o[(size_t)(i * 4 + 0) * 32 * F4] = sub(R[0], R[2]);
+            o[(size_t)(i * 4 + 1) * 32 * F4] = R[1] + R[2];
+            o[(size_t)(i * 4 + 2) * 32 * F4] = sub(R[2], R[1]);
+            o[(size_t)(i * 4 + 3) * 32 * F4] = sub(R[1], R[3]);
+        };
+        v4f Ra[4], Rb[4];
+        if (ih == 0) {            // (two code paths, not selects: ih is wave-uniform)
+            asm volatile("" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            float4 R[4];
+            for (int cc = 0; cc < 4; ++cc) Ra[cc] = sub(st[0][cc], st[2][cc]), Rb[cc] = st[1][cc] + st[2][cc];   // d0 - d2, d1 + d2
+            cols(0, Ra);
+            cols(1, Rb);
+        } else {
+            asm volatile("" ::: "memory");
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const float4 p = st[0][cc], q = st[1][cc], s = st[2][cc];
-                if (ih == 0) R[cc] = k == 0 ? f4sub(p, s) : f4add(q, s);     // i = 0: d0 - d2;  i = 1: d1 + d2
-                else R[cc] = k == 0 ? f4sub(q, p) : f4sub(p, s);             // i = 2: d2 - d1;  i = 3: d1 - d3
-            }
-            const int i = 2 * ih + k;
-            o[(size_t)(i * 4 + 0) * 32 * F4] = f4sub(R[0], R[2]);
-            o[(size_t)(i * 4 + 1) * 32 * F4] = f4add(R[1], R[2]);
-            o[(size_t)(i * 4 + 2) * 32 * F4] = f4sub(R[2], R[1]);
-            o[(size_t)(i * 4 + 3) * 32 * F4] = f4sub(R[1], R[3]);
+            for (int cc = 0; cc < 4; ++cc) Ra[cc] = sub(st[1][cc], st[0][cc]), Rb[cc] = sub(st[0][cc], st[2][cc]);   // d2 - d1, d1 - d3
+            cols(2, Ra);
+            cols(3, Rb);
         }
     };
 
@@ -185,7 +206,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     const int co_tile = by * 2 + wm;
     const bool active = co_tile < A.n_cotiles;
     const int nq = (A.Cin / 8) * 16;                              // weight quads per channel tile
-    const float4* W4 = A.wpk + (size_t)(active ? co_tile : 0) * nq * 64 + lane;
+    const float4* W4 = A.wpk + (size_t)(active ? co_tile : 0) * nq * 64;      // (scalar; + lane at the load)
     // prefetch group gi = (chunk, 8-channel block kb, half xh of the wave's 8 positions): 4 quads, 16 MFMAs
     auto quad_of = [&](int gi, int i) {
         const int q = ((gi >> 1) * 16) + 8 * wx + 4 * (gi & 1) + i;
@@ -204,7 +225,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     // issued right behind the four MFMAs that consumed this one, so every quad still has 16 MFMAs of cover
     float4 cur[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cur[i] = W4[(size_t)quad_of(0, i) * 64];
+    for (int i = 0; i < 4; ++i) cur[i] = W4[(size_t)quad_of(0, i) * 64 + lane];
     __syncthreads();
 #ifdef OSSID_TIMING
     tstamp[1] = tnow();
@@ -233,7 +254,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
                 acc[e] = mfma(a.z, b4.z, acc[e]);
                 acc[e] = mfma(a.w, b4.w, acc[e]);
 #ifndef OSSID_WABL_NOW
-                cur[i] = W4[(size_t)quad_of(gi + 1, i) * 64];
+                cur[i] = W4[(size_t)quad_of(gi + 1, i) * 64 + lane];
 #endif
                 __builtin_amdgcn_sched_barrier(0);      // keep this order: the compiler would sink the load to its use
             }
@@ -379,6 +400,11 @@ static int wino_args(const ossid_conv_desc* d, WinoArgs& a, long& nwg) {
     a.out_cs = d->out_channel_stride > 0 ? d->out_channel_stride : Cout;
     a.out_coff = d->out_channel_offset;
     a.dbg = d->epi_partials;
+    {
+        const long long xb = (a.in_bs == 0 ? (long long)H * W * a.in_cs : (long long)B * a.in_bs) * 4;
+        if (xb > 0x7fffffffLL) return OSSID_EINVAL;       // 32-bit byte offsets in the staging loads
+        a.x_bytes = (unsigned)xb;
+    }
     if (a.in_cs < Cin || a.out_cs < a.out_coff + Cout || (a.in_cs % 4) || (a.out_cs % 4) || (a.out_coff % 4) ||
         (a.pre_scale && !a.pre_shift) || (a.in_bs % 4) || a.pre_bs < 0 || (a.pre_bs % 4) || (long long)H * W * a.in_cs > 0x7fffffffLL)
         return OSSID_EINVAL;
