@@ -211,7 +211,8 @@ def dtoid_leg(a, dev, dist, world):
             "latency; executed = what the build's direct kernels would do after the exact reassociations (DESIGN.md 5, "
             "bench.dtoid_flops; the Winograd kernel's further 2.25x on its layers is not subtracted); per-layer rates in "
             "profiles/. peak is the guide's 157.3 TFLOP/s at 2.4 GHz; under this load the part holds 1.95-2.08 GHz "
-            "(profiles/r02_conv_timeline.txt), i.e. ~128-136 TFLOP/s attainable")
+            "(profiles/r02_conv_timeline.txt), i.e. ~128-136 TFLOP/s attainable; achieved counts the reference's 36 multiplies "
+            "per 3x3 tap set where the Winograd kernel executes 16, so frac can reach 1")
 
     def roof(flops_nom, flops_exec, t):
         return {"bound": "mfma", "achieved": flops_nom / t / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
