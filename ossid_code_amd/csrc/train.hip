@@ -455,16 +455,30 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& A, const int L) {
     float4 sdy[NLD_DY], sx[NLD_X];
 
     const int H = A.H, W = A.W;
-    auto chunk_geom = [&](long long ch, int& b, int& y, int& x0) {
-        const int cr = (int)(ch % A.chunks_per_row);
-        const long long row = ch / A.chunks_per_row;
-        y = (int)(row % H);
-        b = (int)(row / H);
-        x0 = cr * KT;
+    // Chunk geometry (image b, row y, chunk-in-row cr) is stepped, not divided out: a workgroup visits chunks split,
+    // split + nsplit, ... and the three quotients of that stride are computed once. Likewise every thread's staging map
+    // (which (kernel row, position) of the patch its e-th float4 is) is fixed: computed once, not per chunk. (The first
+    // version did a 64-bit divide + modulo per chunk and a runtime divide per staged element per chunk.)
+    const int cpr = A.chunks_per_row;
+    const int d_cr = A.nsplit % cpr, d_row = A.nsplit / cpr, d_y = d_row % H, d_b = d_row / H;
+    auto advance = [&](int& b, int& y, int& cr) {
+        cr += d_cr;
+        int carry = cr >= cpr ? 1 : 0;
+        cr -= carry * cpr;
+        y += d_y + carry;
+        carry = y >= H ? 1 : 0;
+        y -= carry * H;
+        b += d_b + carry;
     };
-    auto stage_load = [&](long long ch) {
-        int b, y, x0;
-        chunk_geom(ch, b, y, x0);
+    int xkr[NLD_X], xp[NLD_X];
+#pragma unroll
+    for (int e = 0; e < NLD_X; ++e) {
+        const int idx = (tid + e * 256) / X4;              // (ky row, position)
+        xkr[e] = idx / (KT + HALO);
+        xp[e] = idx - xkr[e] * (KT + HALO);
+    }
+    auto stage_load = [&](int b, int y, int cr) {
+        const int x0 = cr * KT;
         const float* dyr = A.dy + ((size_t)(b * H + y) * W) * A.dy_cs + co0 + 4 * dyq;
 #pragma unroll
         for (int e = 0; e < NLD_DY; ++e) {
@@ -474,8 +488,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& A, const int L) {
         }
 #pragma unroll
         for (int e = 0; e < NLD_X; ++e) {
-            const int idx = (tid + e * 256) / X4;              // (ky row, position)
-            const int kr = idx / (KT + HALO), p = idx - kr * (KT + HALO);
+            const int kr = xkr[e], p = xp[e];
             const int yy = y + (TAPS == 9 ? ky0 + kr - 1 : 0), xx = x0 + p - (TAPS == 9 ? 1 : 0);
             const bool ok = kr < KYB && yy >= 0 && yy < H && xx >= 0 && xx < W && xq_ok;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -506,8 +519,14 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& A, const int L) {
     };
 
     long long ch = split;
+    int gb, gy, gcr;                                          // geometry of the chunk being PREFETCHED
+    {
+        gcr = split % cpr;
+        const int row = split / cpr;
+        gy = row % H, gb = row / H;
+    }
     if (ch < A.n_chunks) {
-        stage_load(ch);
+        stage_load(gb, gy, gcr);
         stage_write(0);
     }
     __syncthreads();
@@ -516,7 +535,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& A, const int L) {
 #pragma unroll 1
     for (; ch < A.n_chunks; ch += A.nsplit) {
         const long long nxt = ch + A.nsplit;
-        if (nxt < A.n_chunks) stage_load(nxt);
+        advance(gb, gy, gcr);
+        if (nxt < A.n_chunks) stage_load(gb, gy, gcr);
         const float* da = dyl + (size_t)buf * dy_buf + (size_t)h * CO_T + wm * TM * 32 + c;
         const float* xb = xl + (size_t)buf * x_buf + (size_t)h * CI_T + wn * TN * 32 + c;
         float a[2][TM], bv[2][KYB][TN][KX];

@@ -431,7 +431,12 @@ def join_wgrad_stream():
     _wg_dirty.clear()
 
 
+_SKIP_WGRAD = os.environ.get("OSSID_ABL_SKIP_WGRAD", "0") != "0"       # timing ablation only: results are then wrong
+
+
 def _wgrad_async(tensors, fn, device):
+    if _SKIP_WGRAD:
+        return None
     if not WGRAD_SIDE or device.type != "cuda" or torch.cuda.is_current_stream_capturing():
         return fn()      # (a captured graph does not run a side branch to any profit: measured 48.4 vs 47.3 ms)
     idx = device.index if device.index is not None else torch.cuda.current_device()
