@@ -194,7 +194,7 @@ def dtoid_leg(a, dev, dist, world):
     # the product path: eager launches, weight gradients and the independent branches of the head on side HIP streams
     # (train_ops.WGRAD_SIDE, Network.use_train_streams). The single-stream hipGraph replay of the same step is timed
     # beside it: a captured graph does not run its branches side by side to any profit.
-    t_ft = timed(lambda: finetune.finetune_step(m, batch, opt, sync), 2, 6)
+    t_ft = timed(lambda: finetune.finetune_step(m, batch, opt, sync), 3, 10)
     t_ft_graph = None
     if use_graph:
         graphed = finetune.GraphedForwardBackward(m, flat, batch)

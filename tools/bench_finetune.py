@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--reps", type=int, default=6)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also time forward and backward separately (eager)")
+    ap.add_argument("--main-priority", type=int, default=None,
+                    help="run the step on a stream of this priority instead of the default stream (-1 = high): do the side "
+                         "streams' kernels then stay out of the critical path's way?")
     a = ap.parse_args()
     cfg = dtoid.DtoidConfig()
     torch.manual_seed(0)
@@ -49,6 +52,11 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e3
     res = {"impl": a.impl, "batch": B}
+    if a.main_priority is not None:
+        hp = torch.cuda.Stream(priority=a.main_priority)
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)
+        res["main_priority"] = a.main_priority
     res["eager_ms"] = timed(lambda: finetune.finetune_step(m, batch, opt), 2, a.reps)
     # host time to ENQUEUE one eager step (no synchronisation inside): the eager step is launch-bound once this
     # approaches the device time
