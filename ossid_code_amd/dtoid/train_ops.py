@@ -432,6 +432,10 @@ def join_wgrad_stream():
 
 
 _SKIP_WGRAD = os.environ.get("OSSID_ABL_SKIP_WGRAD", "0") != "0"       # timing ablation only: results are then wrong
+if _SKIP_WGRAD:
+    import warnings
+    warnings.warn("OSSID_ABL_SKIP_WGRAD is set: convolution weight gradients are NOT computed (timing ablation; every "
+                  "training result of this process is wrong)")
 
 
 def _wgrad_async(tensors, fn, device):
