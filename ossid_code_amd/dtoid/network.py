@@ -289,6 +289,15 @@ class _PadOne:
         return self.conv.bias
 
 
+# Side-stream slots of the training step (Network._fork). HIP maps streams onto a few hardware queues, and two streams on one
+# queue serialise: with the encoders on slots of their own (six streams in all with the weight-gradient one) the step ran
+# 42.3 ms in a fresh process but 48.4 ms once a test-time graph had been captured in it (other streams created first, another
+# mapping); with the encoders REUSING the two branch slots -- they are never busy at the same time as the branches -- it is
+# 41.9 ms either way. (GPU_MAX_HW_QUEUES=8 made it 79 ms; left alone.)
+ENC_G_STREAM = int(os.environ.get("OSSID_ENC_G_STREAM", "0"))
+ENC_L_STREAM = int(os.environ.get("OSSID_ENC_L_STREAM", "1"))
+
+
 class _CatConv:
     """Several nn.Conv2d layers that read the SAME input (same kernel, padding, stride), presented to PackedConv as one
     layer with their output channels concatenated (weights are re-read at every refresh)."""
@@ -991,10 +1000,10 @@ class Network(nn.Module):
                 # creation): the global one right behind the stem convolution that does not need it; the local one in the
                 # middle of the backbone, so that its backward is enqueued in the middle of the backbone's backward, while
                 # the host is ahead of the device, instead of as a host-bound tail behind everything else
-                lazy_g = lambda: self._fork(3, [global_template, global_template_mask],          # noqa: E731
+                lazy_g = lambda: self._fork(ENC_G_STREAM, [global_template, global_template_mask],          # noqa: E731
                                             lambda: self.template_feature_extractor_global(
                                                 torch.cat([global_template, global_template_mask], dim=1)))
-                lazy_l = lambda: self._fork(2, [template, template_mask],                        # noqa: E731
+                lazy_l = lambda: self._fork(ENC_L_STREAM, [template, template_mask],                        # noqa: E731
                                             lambda: self.template_feature_extractor(torch.cat([template, template_mask], dim=1)))
                 return self._forward_train_hip(image, None, None, lazy_g=lazy_g, lazy_local=lazy_l)
             g = self.template_feature_extractor_global(torch.cat([global_template, global_template_mask], dim=1))

@@ -20,6 +20,10 @@ def main():
     ap.add_argument("--reps", type=int, default=6)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also time forward and backward separately (eager)")
+    ap.add_argument("--with-inference", action="store_true",
+                    help="run a test-time frame first (captures the dense-forward hipGraph in this process), as the online stream does")
+    ap.add_argument("--sync-each", action="store_true",
+                    help="synchronise after every step (a loop that reads the loss every step: the host never runs ahead)")
     ap.add_argument("--main-priority", type=int, default=None,
                     help="run the step on a stream of this priority instead of the default stream (-1 = high): do the side "
                          "streams' kernels then stay out of the critical path's way?")
@@ -52,11 +56,25 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e3
     res = {"impl": a.impl, "batch": B}
+    if a.with_inference:
+        m.eval()
+        test = {"img": torch.rand(1, 3, 480, 640, generator=g).cuda(), "obj_id": torch.tensor([1]),
+                "limg": torch.rand(1, 21, 3, 124, 124, generator=g).cuda(),
+                "lmask": (torch.rand(1, 21, 1, 124, 124, generator=g) > 0.5).float().cuda()}
+        with torch.no_grad():
+            for _ in range(3):
+                m.forwardTestTime(test)
+        torch.cuda.synchronize()
+        m.train()
     if a.main_priority is not None:
         hp = torch.cuda.Stream(priority=a.main_priority)
         hp.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(hp)
         res["main_priority"] = a.main_priority
+    if a.sync_each:
+        def one():
+            float(finetune.finetune_step(m, batch, opt))          # .item(): the host waits for the step
+        res["eager_sync_each_ms"] = timed(one, 2, a.reps)
     res["eager_ms"] = timed(lambda: finetune.finetune_step(m, batch, opt), 2, a.reps)
     # host time to ENQUEUE one eager step (no synchronisation inside): the eager step is launch-bound once this
     # approaches the device time

@@ -99,6 +99,12 @@ def main():
                     torch.cuda.synchronize()
                     note("step B=%d: fwd %.2f s, bwd %.2f s, sync %.2f s, opt %.3f s" %
                          (len(mine), t2 - t1, t3 - t2, t4 - t3, time.perf_counter() - t4))
+                elif os.environ.get("OSSID_STREAM_STEPTIMES"):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    finetune.finetune_step(det, batch, opt, sync)
+                    torch.cuda.synchronize()
+                    note("finetune step %d: %.1f ms (B=%d)" % (ft_steps[0], 1e3 * (time.perf_counter() - t1), len(mine)))
                 else:
                     finetune.finetune_step(det, batch, opt, sync)
                 ft_steps[0] += 1
