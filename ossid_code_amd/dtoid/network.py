@@ -805,11 +805,8 @@ class Network(nn.Module):
     def _fork(self, k, inputs, fn):
         """Run fn() on side stream k behind everything queued on the current stream; returns (outputs, stream)."""
         dev = inputs[0].device
-        pool = self.__dict__.setdefault("_train_stream_pool", {})
-        key = (str(dev), k)
-        if key not in pool:
-            pool[key] = torch.cuda.Stream(device=dev)
-        side = pool[key]
+        from . import train_ops
+        side = train_ops.side_streams(dev)["b%d" % (k & 1)]     # two branch slots (train_ops.side_streams: probed once)
         side.wait_stream(torch.cuda.current_stream(dev))
         for t in inputs:
             t.record_stream(side)

@@ -423,6 +423,52 @@ def bn_fold(sums, n, bn):
 WGRAD_SIDE = os.environ.get("OSSID_WGRAD_STREAM", "1") != "0"
 _wg_streams, _wg_dirty = {}, set()
 
+# Which HIP streams actually run beside the main one. HIP maps streams onto a few hardware queues (4 by default) in order of
+# creation, and two streams on one queue serialise: whether a side stream created "now" shares the main stream's queue depends
+# on how many streams the process created before (measured: the same step 42.0 or 48.4 ms depending on whether a test-time graph
+# had been captured first). So the side streams are CHOSEN, once per device: a handful of streams created back to back spread over the
+# queues; each is probed -- a long kernel on the main stream, a short one on the candidate, did the short one finish
+# first? -- and the three that run concurrently with the main stream become the weight-gradient stream and the two branch slots.
+_side_pools = {}
+N_STREAM_CANDIDATES = int(os.environ.get("OSSID_STREAM_CANDIDATES", "8"))
+
+
+def side_streams(device):
+    """{"wgrad": Stream, "b0": Stream, "b1": Stream} for `device`, chosen by the probe above (cached)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _side_pools.get(idx)
+    if pool is not None:
+        return pool
+    if torch.cuda.is_current_stream_capturing():           # no probing inside a capture: plain streams, not cached
+        return {k: torch.cuda.Stream(device=idx) for k in ("wgrad", "b0", "b1")}
+    with torch.cuda.device(idx):
+        main = torch.cuda.current_stream(idx)
+        cands = [torch.cuda.Stream(device=idx) for _ in range(N_STREAM_CANDIDATES)]
+        small = torch.zeros(64, dtype=torch.float32, device=device)
+        torch.cuda._sleep(1000)                              # (loads the spin kernel)
+        torch.cuda.synchronize(idx)
+        good = []
+        for c in cands:
+            ev_c = torch.cuda.Event()
+            ev_m = torch.cuda.Event()
+            torch.cuda._sleep(4000000)                       # one thread spinning ~2 ms on the main stream: occupies its
+            ev_m.record(main)                                # hardware queue and nothing else
+            with torch.cuda.stream(c):                       # (no wait on the main stream: independent work)
+                small.add_(1.0)
+                ev_c.record(c)
+            ev_c.synchronize()
+            concurrent = not ev_m.query()                    # the short kernel is done while the main stream still spins
+            torch.cuda.synchronize(idx)
+            if concurrent:
+                good.append(c)
+            if len(good) == 3:
+                break
+    rest = [c for c in cands if c not in good]
+    order = good + rest                                      # fewer than three concurrent ones: take what there is
+    pool = {"wgrad": order[0], "b0": order[1], "b1": order[2], "concurrent": len(good)}
+    _side_pools[idx] = pool
+    return pool
+
 
 def join_wgrad_stream():
     """Main stream(s) wait for the weight gradients in flight on the side stream(s)."""
@@ -447,7 +493,7 @@ def _wgrad_async(tensors, fn, device):
     main = torch.cuda.current_stream(idx)
     side = _wg_streams.get(idx)
     if side is None:
-        side = _wg_streams[idx] = torch.cuda.Stream(device=idx)
+        side = _wg_streams[idx] = side_streams(device)["wgrad"]
     side.wait_stream(main)
     with torch.cuda.stream(side):
         fn()
