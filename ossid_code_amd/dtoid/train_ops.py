@@ -428,7 +428,7 @@ _wg_streams, _wg_dirty = {}, set()
 # on how many streams the process created before (measured: the same step 42.0 or 48.4 ms depending on whether a test-time graph
 # had been captured first). So the side streams are CHOSEN, once per device: a handful of streams created back to back spread over the
 # queues; each is probed -- a long kernel on the main stream, a short one on the candidate, did the short one finish
-# first? -- and the three that run concurrently with the main stream become the weight-gradient stream and the two branch slots.
+# first? -- and three that run beside the main stream AND beside each other become the weight-gradient stream and the two branch slots.
 _side_pools = {}
 N_STREAM_CANDIDATES = int(os.environ.get("OSSID_STREAM_CANDIDATES", "8"))
 
@@ -447,25 +447,32 @@ def side_streams(device):
         small = torch.zeros(64, dtype=torch.float32, device=device)
         torch.cuda._sleep(1000)                              # (loads the spin kernel)
         torch.cuda.synchronize(idx)
-        good = []
-        for c in cands:
-            ev_c = torch.cuda.Event()
-            ev_m = torch.cuda.Event()
-            torch.cuda._sleep(4000000)                       # one thread spinning ~2 ms on the main stream: occupies its
-            ev_m.record(main)                                # hardware queue and nothing else
-            with torch.cuda.stream(c):                       # (no wait on the main stream: independent work)
+        def runs_beside(busy, cand):
+            """A ~2 ms one-thread spin kernel on `busy` (occupies its hardware queue and nothing else), a tiny kernel on
+            `cand` with no dependency on it: is the tiny one done while the spin still runs?"""
+            ev_c, ev_b = torch.cuda.Event(), torch.cuda.Event()
+            with torch.cuda.stream(busy):
+                torch.cuda._sleep(4000000)
+                ev_b.record(busy)
+            with torch.cuda.stream(cand):
                 small.add_(1.0)
-                ev_c.record(c)
+                ev_c.record(cand)
             ev_c.synchronize()
-            concurrent = not ev_m.query()                    # the short kernel is done while the main stream still spins
+            beside = not ev_b.query()
             torch.cuda.synchronize(idx)
-            if concurrent:
-                good.append(c)
-            if len(good) == 3:
+            return beside
+
+        good = [c for c in cands if runs_beside(main, c)]
+        chosen = []
+        for c in good:                                       # ... and beside each other
+            if all(runs_beside(x, c) for x in chosen):
+                chosen.append(c)
+            if len(chosen) == 3:
                 break
+        good = chosen + [c for c in good if c not in chosen]
     rest = [c for c in cands if c not in good]
     order = good + rest                                      # fewer than three concurrent ones: take what there is
-    pool = {"wgrad": order[0], "b0": order[1], "b1": order[2], "concurrent": len(good)}
+    pool = {"wgrad": order[0], "b0": order[1], "b1": order[2], "concurrent": len(good), "mutual": len(chosen)}
     _side_pools[idx] = pool
     return pool
 
