@@ -1,4 +1,4 @@
-"""The bench.py output contract, checked on the committed evidence (profiles/r02_f_bench.json is an unedited bench.py line
+"""The bench.py output contract, checked on the committed evidence (profiles/r02_g_bench.json is an unedited bench.py line
 from an MI355X) and on the argument defaults -- no GPU needed."""
 import json
 import os
@@ -12,7 +12,7 @@ def _line(name):
 
 
 def test_committed_bench_line_has_every_contract_field():
-    d = _line("r02_f_bench.json")
+    d = _line("r02_g_bench.json")
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -32,7 +32,7 @@ def test_committed_bench_line_has_every_contract_field():
 
 def test_rocprof_summary_agrees_with_the_bench_line():
     """roofline.avg_launch_ms (HIP events inside bench.py) vs the committed rocprofv3 --stats average of the same kernel."""
-    d = _line("r02_f_bench.json")
+    d = _line("r02_g_bench.json")
     kernel = d["roofline"]["kernel"]
     import csv
     avg_ns = None
