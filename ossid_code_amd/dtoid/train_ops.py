@@ -439,7 +439,8 @@ def side_streams(device):
     pool = _side_pools.get(idx)
     if pool is not None:
         return pool
-    if torch.cuda.is_current_stream_capturing():           # no probing inside a capture: plain streams, not cached
+    if torch.cuda.is_current_stream_capturing() or not hasattr(torch.cuda, "_sleep"):
+        # no probing inside a capture (or without torch's spin kernel): plain streams, not cached
         return {k: torch.cuda.Stream(device=idx) for k in ("wgrad", "b0", "b1")}
     with torch.cuda.device(idx):
         main = torch.cuda.current_stream(idx)
