@@ -208,3 +208,18 @@ def test_dense_block_inplace_gradient_function_equals_cat_path():
         assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-4), n
     for (n, p), (_, q) in zip(blk.named_buffers(), blk2.named_buffers()):
         assert torch.allclose(p.float(), q.float(), rtol=1e-6, atol=1e-6), n
+
+
+def test_winograd_dispatch_policy_is_pure_host_logic():
+    """train_ops.wino_fits: plain 3x3 layers with the reduction channels in 16s, >= 64 output channels and enough workgroups
+    (32 tiles of 2x2 outputs x 64 channels each) -- nothing else."""
+    from ossid_code_amd.dtoid import train_ops as T
+    if not T.USE_WINO:
+        return
+    assert T.wino_fits(8, 29, 39, 768, 512, 9)                  # the fusion layer at batch 8: 75 x 8 workgroups
+    assert T.wino_fits(8, 120, 160, 32, 128, 9)                 # a dense block's 3x3 data gradient
+    assert not T.wino_fits(8, 29, 39, 768, 512, 1)              # 1x1
+    assert not T.wino_fits(8, 29, 39, 768, 48, 9)               # under 64 output channels
+    assert not T.wino_fits(8, 29, 39, 24, 64, 9)                # reduction channels not in 16s
+    assert not T.wino_fits(1, 8, 8, 64, 64, 9)                  # one workgroup
+    assert not T.wino_fits(8, 58, 78, 256, 128, 9, plain=False)  # behind a fused up-sampling

@@ -355,3 +355,25 @@ def test_batch_statistics_survive_a_large_mean_with_a_small_spread(hiplib):
     y64.backward(go)
     assert rel(y, y64) < 2e-3 and rel(bn.running_var, r64.running_var) < 1e-3      # (the inputs themselves carry ~1e-7 * 100 / 0.01)
     assert rel(bn.weight.grad, r64.weight.grad) < 5e-3
+
+
+def test_side_stream_probe_returns_streams_that_run_beside_the_main_one(hiplib):
+    """train_ops.side_streams: three distinct streams per device, chosen once; at least the weight-gradient stream must
+    really run beside the main stream (a spin kernel on the main stream does not delay a kernel on it)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    T._side_pools.clear()
+    pool = T.side_streams(dev)
+    assert len({pool["wgrad"].cuda_stream, pool["b0"].cuda_stream, pool["b1"].cuda_stream}) == 3
+    assert pool["concurrent"] >= 1 and T.side_streams(dev) is pool
+    main = torch.cuda.current_stream()
+    small = torch.zeros(8, device="cuda")
+    torch.cuda.synchronize()
+    ev_m, ev_s = torch.cuda.Event(), torch.cuda.Event()
+    torch.cuda._sleep(4000000)
+    ev_m.record(main)
+    with torch.cuda.stream(pool["wgrad"]):
+        small.add_(1)
+        ev_s.record(pool["wgrad"])
+    ev_s.synchronize()
+    assert not ev_m.query()
+    torch.cuda.synchronize()
