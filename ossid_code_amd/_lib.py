@@ -157,7 +157,75 @@ def fn(name):
     f = getattr(lib(), name, None)
     if f is None:
         raise RuntimeError("libossid_hip.so does not export %s -- rebuild the library" % name)
+    if _MFMA_COUNT is not None and name in _MFMA_RULES:
+        return _counting(f, _MFMA_RULES[name])
     return f
+
+
+# ---- executed matrix-core work, counted where the launches are issued ------------------------------------------------------
+# `with count_mfma() as c:` around an EAGER pass (no hipGraph replay: a replay issues no host calls) sums, per launch of a
+# matrix-core kernel of this library, the multiply-adds the launch asks the MFMA pipe for on real (unpadded) operands:
+# direct / phase convolutions 2*B*px*Cout*Cin*taps, the Winograd form 16 multiplies per 2x2 output tile and channel pair
+# (not the 36 of the convolution it replaces), weight gradients 2*B*px*Cout*Cin*taps, the decoder tail's first convolution
+# with its merged kernel rows. bench.py divides by the measured time for `roofline.frac_mfma`: the pipe's own fraction, which
+# cannot exceed 1 -- unlike a fraction on the reference's nominal flop count.
+_MFMA_COUNT = None
+
+
+def _conv_flops(args):
+    d = args[0]._obj
+    px = d.height * d.width * (4 if d.taps == 4 else 1)        # taps 4: four 2x2 phase convolutions of the SOURCE image
+    return 2.0 * d.batch * px * d.cout * d.cin * d.taps
+
+
+def _wino_flops_d(d):
+    return 2.0 * d.batch * ((d.height + 1) // 2) * ((d.width + 1) // 2) * 16 * d.cout * d.cin
+
+
+def _wgrad_flops_d(d):
+    return 2.0 * d.batch * d.height * d.width * d.cout * d.cin * d.taps
+
+
+_MFMA_RULES = {
+    "ossid_conv_nhwc_fwd": _conv_flops,
+    "ossid_conv3x3_wino_fwd": lambda a: _wino_flops_d(a[0]._obj),
+    "ossid_conv3x3_wino_fwd_pair": lambda a: _wino_flops_d(a[0]._obj) + _wino_flops_d(a[1]._obj),
+    "ossid_conv_wgrad": lambda a: _wgrad_flops_d(a[0]._obj),
+    "ossid_conv_wgrad_group": lambda a: sum(_wgrad_flops_d(a[0][i]) for i in range(a[1])),
+    # (x, B, Hs, Ws, C, H, W, ...): 32 -> 16 on the up-sampled image, kernel rows merged 3 -> 2 away from the border
+    "ossid_seg_tail_fwd": lambda a: 2.0 * a[1] * a[5] * a[6] * 16 * a[4] * 6,
+}
+
+
+def _counting(f, rule):
+    def call(*args):
+        if _MFMA_COUNT is not None:
+            _MFMA_COUNT.flops += rule(args)
+            _MFMA_COUNT.launches += 1
+        return f(*args)
+    return call
+
+
+class count_mfma:
+    """Context manager: .flops / .launches of the matrix-core launches issued inside (see above)."""
+
+    def __enter__(self):
+        global _MFMA_COUNT
+        self.flops, self.launches, self._outer = 0.0, 0, _MFMA_COUNT
+        _MFMA_COUNT = self
+        return self
+
+    def __exit__(self, *a):
+        global _MFMA_COUNT
+        _MFMA_COUNT = self._outer
+        return False
+
+    @staticmethod
+    def add(flops):
+        """For matrix-core work this library does not launch itself (a library GEMM on the product path)."""
+        if _MFMA_COUNT is not None:
+            _MFMA_COUNT.flops += flops
+            _MFMA_COUNT.launches += 1
 
 
 def check(rc, what):

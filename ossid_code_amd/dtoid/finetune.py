@@ -143,10 +143,14 @@ class GradSync:
                   all ranks at the start of the next forward. Without this the eval-mode detectors drift apart and the
                   speculative stream (stream.run_speculative) would commit frames scored by different detectors."""
 
-    def __init__(self, flat, process_group=None, bucket_mb=32, model=None, overlap=True):
+    def __init__(self, flat, process_group=None, bucket_mb=32, model=None, overlap=True, force_collectives=False):
+        """force_collectives: issue every collective even at world size 1 (a 1-rank RCCL group on one GPU executes every
+        RCCL call, hook and stream hand-off of the multi-GPU step; tests/test_rccl_gpu.py)."""
         import torch.distributed as dist
         self.dist, self.flat, self.group, self.model = dist, flat, process_group, model
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.collectives = self.world > 1 or (bool(force_collectives) and dist.is_initialized())
+        self._comm = {}
         n = flat.n_used
         per = max(1, int(bucket_mb * (1 << 20) // 4))
         self.bounds = [(s, min(n, s + per)) for s in range(0, n, per)]
@@ -155,7 +159,7 @@ class GradSync:
         # bucket k = the parameters whose flat range STARTS inside bounds[k] (a tensor straddling a boundary belongs to
         # the bucket it starts in; the bucket's all-reduce range is stretched to cover it)
         self._buckets = []
-        if self.world > 1 or overlap:
+        if self.collectives or overlap:
             used = [(name, p) + flat.offsets[name] for name, p in flat.entries if flat.offsets[name][0] < n]
             k = 0
             cur = {"params": [], "lo": 0, "hi": 0}
@@ -185,6 +189,8 @@ class GradSync:
             b["pending"], b["flushed"] = len(b["params"]), False
         self._next = len(self._buckets) - 1          # buckets go out last-to-first: backward produces them in that order
         self._works, self._armed = [], True
+        # the stream loss.backward() is called on (begin() runs on it): where the step continues after finish()
+        self._caller = torch.cuda.current_stream(self.flat.grad.device) if self.flat.grad.is_cuda else None
 
     def _make_hook(self, bi):
         def hook(param):
@@ -202,28 +208,62 @@ class GradSync:
             self._flush(self._buckets[self._next])
             self._next -= 1
 
+    def _comm_stream(self, dev):
+        """The stream a bucket is gathered and reduced on, once every stream that can hold a producer of its gradients
+        has been waited for. A bucket is flushed from the post-accumulate hook of its LAST parameter, so its current
+        stream is that one AccumulateGrad node's stream -- the stream the parameter was first used on in forward: main,
+        or a branch slot (Network.use_train_streams) -- while the bucket mixes parameters from all of them, and
+        convolution weight gradients are still in flight on the weight-gradient stream (train_ops.WGRAD_SIDE). The
+        autograd engine itself only joins those streams when backward ENDS. When a hook fires, every kernel producing a
+        gradient of its bucket has been ENQUEUED (the hook runs after AccumulateGrad), so waiting for what each candidate
+        stream holds now is sufficient. Doing the gather + all-reduce on an own stream keeps those waits off the critical
+        path: the main stream never waits for a side stream here, and the weight-gradient stream's dirty mark is left
+        alone, so the end-of-backward join (train_ops.join_wgrad_stream) still happens."""
+        from . import train_ops
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        comm = self._comm.get(idx)
+        if comm is None:
+            comm = self._comm[idx] = torch.cuda.Stream(device=idx)
+        producers = [torch.cuda.current_stream(idx), self._caller]
+        pool = train_ops._side_pools.get(idx) or {}
+        producers += [pool.get(k) for k in ("wgrad", "b0", "b1")] + [train_ops._wg_streams.get(idx)]
+        seen = set()
+        for st in producers:
+            if st is not None and st.cuda_stream not in seen and st.cuda_stream != comm.cuda_stream:
+                seen.add(st.cuda_stream)
+                comm.wait_stream(st)
+        return comm
+
     def _flush(self, b):
-        if self.flat.grad.is_cuda:
-            from . import train_ops
-            train_ops.join_wgrad_stream()      # weight gradients still in flight on the side stream (train_ops.WGRAD_SIDE)
+        comm = self._comm_stream(self.flat.grad.device) if self.flat.grad.is_cuda else None
         dst, src = [], []
         for (p, off, cnt), v in zip(b["params"], b["views"]):
             if p.grad is None:
-                v.zero_()                         # no gradient this step: contributes zero, like gather_grads
+                dst.append(v)                     # no gradient this step: contributes zero, like gather_grads
+                src.append(None)
             elif p.grad.data_ptr() != v.data_ptr():
                 dst.append(v)
                 src.append(p.grad)
-        if dst:
-            torch._foreach_copy_(dst, src)
+        import contextlib
+        with (torch.cuda.stream(comm) if comm is not None else contextlib.nullcontext()):
+            for v, g_ in zip(dst, src):
+                if g_ is None:
+                    v.zero_()
+            pairs = [(v, g_) for v, g_ in zip(dst, src) if g_ is not None]
+            if pairs:
+                torch._foreach_copy_([v for v, _ in pairs], [g_ for _, g_ in pairs])
+                if comm is not None:
+                    for _, g_ in pairs:           # freed when p.grad is re-pointed below: the allocator must not hand the
+                        g_.record_stream(comm)    # memory to the producer's stream while the copy is still reading it
+            if self.collectives:
+                g = self.flat.grad[b["lo"]:b["hi"]]
+                g.mul_(1.0 / self.world)
+                if g.is_cuda and self.dist.get_backend(self.group) != "nccl":
+                    torch.cuda.synchronize(g.device)          # see sync(): host-staged gloo on a shared device
+                self._works.append(self.dist.all_reduce(g, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
         for (p, _, _), v in zip(b["params"], b["views"]):
             p.grad = v
         b["flushed"] = True
-        if self.world > 1:
-            g = self.flat.grad[b["lo"]:b["hi"]]
-            g.mul_(1.0 / self.world)
-            if g.is_cuda and self.dist.get_backend(self.group) != "nccl":
-                torch.cuda.synchronize(g.device)          # see sync(): host-staged gloo on a shared device
-            self._works.append(self.dist.all_reduce(g, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """After loss.backward(): flush what the hooks could not (parameters that got no gradient), wait for all
@@ -234,13 +274,17 @@ class GradSync:
         self._launch_ready()
         for w in self._works:
             w.wait()
-        if self._works and self.flat.grad.is_cuda and self.dist.get_backend(self.group) != "nccl":
-            torch.cuda.synchronize(self.flat.grad.device)
+        if self.flat.grad.is_cuda:
+            cur = torch.cuda.current_stream(self.flat.grad.device)
+            for comm in self._comm.values():      # the gathers (and, through w.wait() above, the reductions) of every bucket
+                cur.wait_stream(comm)
+            if self._works and self.dist.get_backend(self.group) != "nccl":
+                torch.cuda.synchronize(self.flat.grad.device)
         self._works = []
 
     # ---- non-overlapped form ------------------------------------------------------------------------------------------
     def sync(self):
-        if self.world == 1:
+        if not self.collectives:
             return
         g = self.flat.used_grad()
         g.mul_(1.0 / self.world)          # pre-scale once; SUM of the scaled buffers is the mean
@@ -260,7 +304,7 @@ class GradSync:
 
     def broadcast_params(self, src=0):
         """Make every replica start from rank `src`'s weights AND buffers (DDP's constructor does the same)."""
-        if self.world > 1:
+        if self.collectives:
             self.dist.broadcast(self.flat.param, src=src, group=self.group)
             self.sync_buffers(src)
 
@@ -268,7 +312,7 @@ class GradSync:
         """Broadcast every buffer of the model from rank `src`, coalesced per dtype (BatchNorm statistics of the whole
         detector: ~0.4 MB of floats + ~240 int64 counters -> two messages)."""
         model = self.model if model is None else model
-        if self.world == 1 or model is None:
+        if not self.collectives or model is None:
             return
         by_dtype = {}
         for b in model.buffers():
@@ -281,35 +325,88 @@ class GradSync:
                                  [c.view_as(b) for c, b in zip(flat.split([b.numel() for b in bufs]), bufs)])
 
 
+_PIN_KEY = "ossid_capture_probe"
+
+
+def pinned_grad_accumulators(params):
+    """The parameters whose AccumulateGrad node is being KEPT ALIVE by an autograd graph of an earlier iteration (a loss or
+    an output dict that still has its grad_fn, a leaked graph). Such a node carries the stream it was created on; a
+    backward pass inside a hipGraph capture then has the engine record / wait events between that (non-capturing) stream
+    and the capture stream, which invalidates the capture -- and ending an invalidated capture crashed the HIP runtime
+    (DESIGN.md 5d). A node nothing else holds dies with our reference and a fresh one (with an empty metadata dict) is made on
+    the next access; a pinned one comes back with the mark we left."""
+    token, pinned = object(), []
+    for p in params:
+        if not p.requires_grad:
+            continue
+        node = p.view_as(p).grad_fn.next_functions[0][0]
+        node.metadata[_PIN_KEY] = token
+        del node
+        node = p.view_as(p).grad_fn.next_functions[0][0]
+        if node.metadata.pop(_PIN_KEY, None) is token:
+            pinned.append(p)
+        del node
+    return pinned
+
+
 class GraphedForwardBackward:
     """zero_grad + DtoidNet.forward + loss.backward() of one fixed batch shape, captured once in a hipGraph and
-    replayed (the eager step is ~3 700 launches and partly host-bound). Gradients land in the FlatParams buffer, whose
+    replayed (the eager step is ~2 100 launches and partly host-bound). Gradients land in the FlatParams buffer, whose
     address never changes; the gradient all-reduce and the one-launch optimizer step stay outside the graph.
-    BatchNorm buffers are saved and restored around the warm-up passes, so capturing changes no state."""
+    BatchNorm buffers are saved and restored around the warm-up passes, so capturing changes no state.
+
+    Capture hygiene (the round-2 `capture_end` crash): the warm-up passes run ON the capture stream and in the
+    captured form of the step (one stream: no branch streams, weight gradients in line), so every autograd node the warm-up
+    could leave behind belongs to the stream the capture uses; and the capture is REFUSED with a RuntimeError while any
+    parameter's AccumulateGrad node is pinned by an older graph (pinned_grad_accumulators)."""
 
     def __init__(self, model, flat, example_batch, warmup=2):
+        from . import train_ops
         self.model, self.flat = model, flat
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         dev = flat.param.device
+        params = [p for _, p in flat.entries]
+        pinned = pinned_grad_accumulators(params)
+        if pinned:
+            raise RuntimeError(
+                "GraphedForwardBackward: %d parameter(s) still belong to an autograd graph of an earlier iteration (a loss / "
+                "output that was kept with its grad_fn). Their AccumulateGrad nodes carry that iteration's stream into the "
+                "capture and would invalidate it: drop or .detach() those tensors before capturing." % len(pinned))
+        train_ops.join_wgrad_stream()                      # nothing of an earlier eager step may still be in flight
         saved = [b.detach().clone() for b in model.buffers()]
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        nets = [m for m in model.modules() if hasattr(m, "use_train_streams")]
+        old_flags = [(m, m.__dict__.get("use_train_streams")) for m in nets]
+        old_side = train_ops.WGRAD_SIDE
+        try:
+            for m in nets:
+                m.use_train_streams = False
+            train_ops.WGRAD_SIDE = False
+            with torch.cuda.stream(cap):
+                for _ in range(warmup):
+                    flat.detach_grads()
+                    model(self.static)["loss"].backward()
+                    flat.gather_grads()
+            torch.cuda.current_stream(dev).wait_stream(cap)
+            with torch.no_grad():
+                for b, s0 in zip(model.buffers(), saved):
+                    b.copy_(s0)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=cap):
                 flat.detach_grads()
-                model(self.static)["loss"].backward()
+                out = model(self.static)
+                out["loss"].backward()
                 flat.gather_grads()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        with torch.no_grad():
-            for b, s0 in zip(model.buffers(), saved):
-                b.copy_(s0)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            flat.detach_grads()
-            out = model(self.static)
-            out["loss"].backward()
-            flat.gather_grads()
-            self.loss = out["loss"].detach()
+                self.loss = out["loss"].detach()
+                del out
+        finally:
+            train_ops.WGRAD_SIDE = old_side
+            for m, v in old_flags:
+                if v is None:
+                    m.__dict__.pop("use_train_streams", None)
+                else:
+                    m.use_train_streams = v
         flat.zero_grad()
 
     def __call__(self, batch):

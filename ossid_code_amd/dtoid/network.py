@@ -497,6 +497,7 @@ class FusedHead:
                 G = frame["G"]
                 with torch.cuda.device(xin.device):
                     z = a2 @ G                                                   # [B, HW*Cout] = [t][px][o]
+                    ops._lib.count_mfma.add(2.0 * B * C * H * W * self.dot.cout)
                     ops._lib.check(ops._lib.fn("ossid_bias_elu_affine_slice")(
                         z.data_ptr(), B * H * W, self.dot.cout, None if self.dot.bias is None else self.dot.bias.data_ptr(),
                         self.dot.scale.data_ptr(), self.dot.shift.data_ptr(), x.data_ptr(), ctot, 0, ops._lib.stream()),
@@ -1081,7 +1082,15 @@ class Network(nn.Module):
         """Backbone once + head per template chunk. No host syncs, no data-dependent shapes: capturable in a hipGraph."""
         return self._dense_head(self._features(image, template_global, raw_image), template_features, sides)
 
-    def _graphed_dense(self, image, template_features, template_global, head_only=False, raw_image=False):
+    def _graphed_dense(self, *args, **kwargs):
+        """_graphed_dense_impl under torch.no_grad(): test-time inference builds no autograd graph. (Called with gradients
+        enabled, the layers still on torch modules would record a graph that the cached static outputs keep alive for
+        good -- and with it AccumulateGrad nodes carrying the CAPTURE stream into every later backward pass: the source of
+        torch's "AccumulateGrad node's stream does not match" warning in round 2's GPU test log)"""
+        with torch.no_grad():
+            return self._graphed_dense_impl(*args, **kwargs)
+
+    def _graphed_dense_impl(self, image, template_features, template_global, head_only=False, raw_image=False):
         """The dense part replayed from a captured hipGraph (the B=1 backbone alone is ~500 launches and otherwise
         host-bound). One graph per (input shape, chunk sizes, packed-head identity); inputs are copied into the
         graph's static buffers, outputs are read from them. head_only: `image` is already the feature map [1,640,h,w]

@@ -121,9 +121,17 @@ class _Packed:
                 n = _lib.fn("ossid_conv_packed_floats")(cout, cin, taps) if kind == "fwd" else \
                     _lib.fn("ossid_conv_packed_floats")(cin, cout, taps)
             if len(cls._cache) > 4096:
-                cls._cache.clear()
+                cls.clear()
             ent = cls._cache[key] = torch.empty(n, dtype=torch.float32, device=w.device)
         return ent
+
+    @classmethod
+    def clear(cls):
+        """Forget every packed buffer. A live PackPlan keeps its own buffers alive (PackPlan.bufs) but is no longer
+        `valid_for` anything (its buffers are not the cache's any more) and nothing it packed counts as fresh."""
+        global _ACTIVE_PLAN
+        cls._cache.clear()
+        _ACTIVE_PLAN = None
 
 
 _ACTIVE_PLAN = None  # weakref to the PackPlan that packed last. Its `fresh` dict maps (weight pointer, shape, kind) -> the
@@ -138,7 +146,8 @@ def _pack(w, kind):
     cout, cin, taps = int(w.shape[0]), int(w.shape[1]), int(w.shape[2] * w.shape[3])
     buf = _Packed.get(w, kind)
     plan = _ACTIVE_PLAN() if _ACTIVE_PLAN is not None else None
-    if plan is not None and plan.fresh.get((w.data_ptr(), tuple(w.shape), kind)) == w._version:
+    key = (w.data_ptr(), tuple(w.shape), kind)
+    if plan is not None and plan.fresh.get(key) == w._version and plan.buf_ptr.get(key) == buf.data_ptr():
         return buf
     with _lib.on_device(w.device):
         if kind in ("wino_fwd", "wino_dgrad"):
@@ -159,6 +168,7 @@ class PackPlan:
         """kinds: optional {conv: tuple of layouts} -- which of ("fwd", "dgrad", "wino_fwd", "wino_dgrad") the step will ask
         for (a layout left out is simply packed by its layer's own _pack() launch if it is asked for after all)."""
         rows, keys, first = [], [], 0
+        self.bufs, self.buf_ptr = [], {}       # strong references: the table below holds raw addresses of these buffers
         for conv in convs:
             w = conv.weight.detach()
             cout, cin, taps = int(w.shape[0]), int(w.shape[1]), int(w.shape[2] * w.shape[3])
@@ -175,6 +185,8 @@ class PackPlan:
                 rows.append((w.data_ptr(), buf.data_ptr(), first, cout, cin, taps,
                              {"fwd": 0, "dgrad": 1, "wino_fwd": 2, "wino_dgrad": 3}[kind]))
                 keys.append((w.data_ptr(), tuple(w.shape), kind))
+                self.bufs.append(buf)
+                self.buf_ptr[keys[-1]] = buf.data_ptr()
                 first += (buf.numel() // 4 + 255) // 256
         arr = (_lib.PackRow * len(rows))()
         for i, r in enumerate(rows):
@@ -188,7 +200,10 @@ class PackPlan:
         self.fresh = {}
 
     def valid_for(self, convs):
-        return len(convs) == len(self.sig) and all(c.weight.data_ptr() == p for c, p in zip(convs, self.sig))
+        """Same weight tensors at the same addresses, and the packed buffers in the table are still the cache's."""
+        if len(convs) != len(self.sig) or any(c.weight.data_ptr() != p for c, p in zip(convs, self.sig)):
+            return False
+        return all(_Packed._cache.get(k) is b for k, b in zip(self.keys, self.bufs))
 
     def run(self):
         with _lib.on_device(self.device):
@@ -423,59 +438,7 @@ def bn_fold(sums, n, bn):
 WGRAD_SIDE = os.environ.get("OSSID_WGRAD_STREAM", "1") != "0"
 _wg_streams, _wg_dirty = {}, set()
 
-# Which HIP streams actually run beside the main one. HIP maps streams onto a few hardware queues (4 by default) in order of
-# creation, and two streams on one queue serialise: whether a side stream created "now" shares the main stream's queue depends
-# on how many streams the process created before (measured: the same step 42.0 or 48.4 ms depending on whether a test-time graph
-# had been captured first). So the side streams are CHOSEN, once per device: a handful of streams created back to back spread over the
-# queues; each is probed -- a long kernel on the main stream, a short one on the candidate, did the short one finish
-# first? -- and three that run beside the main stream AND beside each other become the weight-gradient stream and the two branch slots.
-_side_pools = {}
-N_STREAM_CANDIDATES = int(os.environ.get("OSSID_STREAM_CANDIDATES", "8"))
-
-
-def side_streams(device):
-    """{"wgrad": Stream, "b0": Stream, "b1": Stream} for `device`, chosen by the probe above (cached)."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    pool = _side_pools.get(idx)
-    if pool is not None:
-        return pool
-    if torch.cuda.is_current_stream_capturing() or not hasattr(torch.cuda, "_sleep"):
-        # no probing inside a capture (or without torch's spin kernel): plain streams, not cached
-        return {k: torch.cuda.Stream(device=idx) for k in ("wgrad", "b0", "b1")}
-    with torch.cuda.device(idx):
-        main = torch.cuda.current_stream(idx)
-        cands = [torch.cuda.Stream(device=idx) for _ in range(N_STREAM_CANDIDATES)]
-        small = torch.zeros(64, dtype=torch.float32, device=device)
-        torch.cuda._sleep(1000)                              # (loads the spin kernel)
-        torch.cuda.synchronize(idx)
-        def runs_beside(busy, cand):
-            """A ~2 ms one-thread spin kernel on `busy` (occupies its hardware queue and nothing else), a tiny kernel on
-            `cand` with no dependency on it: is the tiny one done while the spin still runs?"""
-            ev_c, ev_b = torch.cuda.Event(), torch.cuda.Event()
-            with torch.cuda.stream(busy):
-                torch.cuda._sleep(4000000)
-                ev_b.record(busy)
-            with torch.cuda.stream(cand):
-                small.add_(1.0)
-                ev_c.record(cand)
-            ev_c.synchronize()
-            beside = not ev_b.query()
-            torch.cuda.synchronize(idx)
-            return beside
-
-        good = [c for c in cands if runs_beside(main, c)]
-        chosen = []
-        for c in good:                                       # ... and beside each other
-            if all(runs_beside(x, c) for x in chosen):
-                chosen.append(c)
-            if len(chosen) == 3:
-                break
-        good = chosen + [c for c in good if c not in chosen]
-    rest = [c for c in cands if c not in good]
-    order = good + rest                                      # fewer than three concurrent ones: take what there is
-    pool = {"wgrad": order[0], "b0": order[1], "b1": order[2], "concurrent": len(good), "mutual": len(chosen)}
-    _side_pools[idx] = pool
-    return pool
+from ..streams import N_STREAM_CANDIDATES, _side_pools, side_streams  # noqa: E402,F401  (the probe lives in ossid_code_amd/streams.py)
 
 
 def join_wgrad_stream():
@@ -492,10 +455,17 @@ if _SKIP_WGRAD:
                   "training result of this process is wrong)")
 
 
-def _wgrad_async(tensors, fn, device):
+def _wgrad_async(tensors, fn, device, weights=()):
+    """Run fn() -- weight-gradient launches writing the `dw` tensors a backward() is about to return -- on the side stream.
+    Returning a tensor the side stream is still writing is safe ONLY while autograd's AccumulateGrad takes it over without
+    reading it, i.e. while the parameter's .grad is None (finetune_step's protocol: FlatParams.detach_grads() before
+    backward). A parameter that already holds a gradient (optimizer.zero_grad() that keeps the tensors, gradient
+    accumulation over two backward passes) gets `p.grad += dw` on the caller's stream straight after the node returns, so
+    for those -- `weights`: the parameters whose gradients fn() produces -- the launches stay in line."""
     if _SKIP_WGRAD:
         return None
-    if not WGRAD_SIDE or device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+    if not WGRAD_SIDE or device.type != "cuda" or torch.cuda.is_current_stream_capturing() or \
+            any(w is not None and w.grad is not None for w in weights):
         return fn()      # (a captured graph does not run a side branch to any profit: measured 48.4 vs 47.3 ms)
     idx = device.index if device.index is not None else torch.cuda.current_device()
     main = torch.cuda.current_stream(idx)
@@ -587,7 +557,8 @@ class FusedConv(torch.autograd.Function):
         if need[1]:
             dw = torch.empty_like(w)
             _wgrad_async([x, dv, ps, pt, dw], lambda: wgrad_raw(x, dv, B, H, W, Cin, Cout, taps, dw, pre=pre, pre_relu=pre_relu,
-                                                                src_hw=(Hs, Ws) if (H, W) != (Hs, Ws) else (0, 0)), dev)
+                                                                src_hw=(Hs, Ws) if (H, W) != (Hs, Ws) else (0, 0)), dev,
+                         weights=(w,))
         # 3. data gradient
         dx = dps = dpt = None
         if need[0] or (pre is not None and (need[3] or need[4])):
@@ -688,12 +659,18 @@ class DenseBlockTrain(torch.autograd.Function):
                 batch_stats(flat(buf, c), N, growth, cs=Ct, sums=table.view(-1)[c:], sums_row_stride=Ct)
             saved.append((f1, y1, f2))
             c += growth
-        ctx.block, ctx.saved, ctx.buf, ctx.params, ctx.C0 = block, saved, buf, params, C0
+        # The OUTPUT must go through save_for_backward: `ctx.buf = buf` would close a cycle ctx -> buf -> grad_fn -> ctx
+        # through a C++ shared_ptr that Python's collector cannot see, so a training-mode forward whose backward never runs
+        # (a forward-only timing pass, a backward that raises) leaked the whole upstream graph -- and with it every
+        # AccumulateGrad node, which then carried a stale stream into the next hipGraph capture.
+        ctx.save_for_backward(buf)
+        ctx.block, ctx.saved, ctx.params, ctx.C0 = block, saved, params, C0
         return buf
 
     @staticmethod
     def backward(ctx, gbuf):
-        block, saved, buf, params, C0 = ctx.block, ctx.saved, ctx.buf, ctx.params, ctx.C0
+        block, saved, params, C0 = ctx.block, ctx.saved, ctx.params, ctx.C0
+        (buf,) = ctx.saved_tensors
         B, Ct, H, W = buf.shape
         dev = buf.device
         N = B * H * W
@@ -752,11 +729,11 @@ class DenseBlockTrain(torch.autograd.Function):
             grads[6 * li:6 * li + 6] = [r1[0], r1[1], dw1, r2[0], r2[1], dw2]
         touched = [G, buf, dz_all] + [t for sv in saved for t in (sv[1], sv[0][0], sv[0][1], sv[2][0], sv[2][1])] + \
             [it["dw"] for it in deferred]
-        _wgrad_async(touched, lambda: wgrad_group(deferred), dev)
+        _wgrad_async(touched, lambda: wgrad_group(deferred), dev, weights=[params[6 * li + k] for li in range(L) for k in (2, 5)])
         # the block's input channels
         chan_op(G, N, C0, x=buf, out=G, g_cs=Ct, x_cs=Ct, out_cs=Ct, beta=coef[0, :C0], kappa=coef[1, :C0])
         dx = G[:, :C0].contiguous(memory_format=torch.channels_last)
-        ctx.saved = ctx.buf = None
+        ctx.saved = None
         return (dx, None) + tuple(grads)
 
 

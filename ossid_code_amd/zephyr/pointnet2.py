@@ -10,6 +10,8 @@ Linear) so a state_dict saved from that architecture loads key for key. The forw
 torch: the parameters are folded (BN into the convolution), permuted into SPEC.md's canonical channel order,
 packed into the MFMA operand layout of csrc/pn2.hip and handed to libossid_hip.so.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -117,6 +119,13 @@ def pack_pn2(folded):
 
 class PointNet2SSG(nn.Module):
     MAX_CHUNK = 4096  # hypotheses per C-ABI call (bounds the workspace at ~0.72 MB each)
+    # One frame's hypotheses are scored in OVERLAP_CHUNKS pieces alternating two HIP side streams (ossid_code_amd.streams:
+    # probed to really run beside each other): the sampling / grouping kernels of piece k+1 (fps, ball query: vector-ALU and
+    # LDS work, ~6 % of the step) run under the matrix-core stages of piece k instead of in front of them. Hypotheses are
+    # independent, so the scores are bit-identical to the one-launch form (tests/test_zephyr_gpu.py chunking property).
+    # 1 = one stream, one launch per stage (what the per-kernel roofline measurements use).
+    OVERLAP_CHUNKS = int(os.environ.get("OSSID_PN2_OVERLAP_CHUNKS", "4"))
+    OVERLAP_MIN_PER_CHUNK = 128     # below this a piece no longer fills the chip's 256 CUs with its MLP workgroups
 
     def __init__(self, dim_in, args=None, num_class=1):
         super().__init__()
@@ -175,8 +184,11 @@ class PointNet2SSG(nn.Module):
             self._ws[key] = ws
         return ws
 
-    def score(self, point_x, debug=False, stage_events=None):
-        """point_x [B, M, 8] float32 on the GPU -> scores [B] (and the stage tensors when debug)."""
+    def score(self, point_x, debug=False, stage_events=None, overlap=None):
+        """point_x [B, M, 8] float32 on the GPU -> scores [B] (and the stage tensors when debug).
+        overlap: number of pieces scored on two alternating side streams (None = OVERLAP_CHUNKS when the batch is large
+        enough, 1 = everything on the current stream). stage_events: one _lib.StageEvents (one-stream form) or a list with
+        one per piece."""
         _lib.require_cuda(point_x)
         if self.training:
             raise NotImplementedError("PointNet2SSG is inference-only on this path: call .eval() "
@@ -200,18 +212,56 @@ class PointNet2SSG(nn.Module):
                        feat3=torch.empty(B, 1024, **f32))
         f = _lib.fn("ossid_pn2_score")
         wsb = _lib.fn("ossid_pn2_workspace_bytes")
+
+        def launch(b0, nb, events):
+            nbytes = wsb(nb, M, np1, np2)
+            ws = self._workspace(nbytes, dev)
+            dargs = [None] * 7
+            if dbg is not None:
+                dargs = [dbg[k][b0:b0 + nb].data_ptr() for k in ("fps1", "ball1", "feat1", "fps2", "ball2", "feat2", "feat3")]
+            rc = f(point_x[b0:b0 + nb].data_ptr(), nb, M, w, ws.data_ptr(), nbytes, scores[b0:b0 + nb].data_ptr(),
+                   *dargs, None if events is None else events.arr, _lib.stream())
+            _lib.check(rc, "ossid_pn2_score")
+
+        pieces = self.overlap_pieces(B) if overlap is None else max(1, min(int(overlap), max(B, 1)))
+        if stage_events is not None and not isinstance(stage_events, (list, tuple)):
+            pieces = 1                                        # one set of events = the one-stream, one-launch-per-stage form
+        if isinstance(stage_events, (list, tuple)) and len(stage_events) != pieces:
+            raise ValueError("stage_events: one StageEvents per piece (%d), got %d" % (pieces, len(stage_events)))
+        if debug or torch.cuda.is_current_stream_capturing():
+            pieces = 1
         with torch.cuda.device(dev):
-            for b0 in range(0, B, self.MAX_CHUNK):
-                nb = min(self.MAX_CHUNK, B - b0)
-                nbytes = wsb(nb, M, np1, np2)
-                ws = self._workspace(nbytes, dev)
-                dargs = [None] * 7
-                if dbg is not None:
-                    dargs = [dbg[k][b0:b0 + nb].data_ptr() for k in ("fps1", "ball1", "feat1", "fps2", "ball2", "feat2", "feat3")]
-                rc = f(point_x[b0:b0 + nb].data_ptr(), nb, M, w, ws.data_ptr(), nbytes, scores[b0:b0 + nb].data_ptr(),
-                       *dargs, None if stage_events is None else stage_events.arr, _lib.stream())
-                _lib.check(rc, "ossid_pn2_score")
+            if pieces <= 1:
+                ev = stage_events[0] if isinstance(stage_events, (list, tuple)) else stage_events
+                for b0 in range(0, B, self.MAX_CHUNK):
+                    launch(b0, min(self.MAX_CHUNK, B - b0), ev)
+            else:
+                from ..streams import side_streams
+                pool = side_streams(dev)
+                sides = (pool["b0"], pool["b1"])
+                cur = torch.cuda.current_stream(dev)
+                for sd in sides:
+                    sd.wait_stream(cur)
+                per = -(-B // pieces)
+                per = (per + 7) // 8 * 8                      # the FC head scores 8 hypotheses per workgroup
+                k = 0
+                for b0 in range(0, B, per):
+                    with torch.cuda.stream(sides[k & 1]):
+                        launch(b0, min(per, B - b0), None if stage_events is None else stage_events[k])
+                    k += 1
+                for sd in sides:
+                    cur.wait_stream(sd)
+                    point_x.record_stream(sd)
+                    scores.record_stream(sd)
         return (scores, dbg) if debug else scores
+
+    def overlap_pieces(self, B):
+        """How many pieces score() cuts B hypotheses into by default."""
+        n = min(self.OVERLAP_CHUNKS, B // self.OVERLAP_MIN_PER_CHUNK)
+        if n <= 1 or B > self.MAX_CHUNK * n:
+            return 1
+        per = (-(-B // n) + 7) // 8 * 8
+        return -(-B // per)
 
     def forward(self, data):
         x = data["point_x"] if isinstance(data, dict) else data

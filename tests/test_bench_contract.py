@@ -1,54 +1,10 @@
-"""The bench.py output contract, checked on the committed evidence (profiles/r02_g_bench.json is an unedited bench.py line
-from an MI355X) and on the argument defaults -- no GPU needed."""
+"""The bench.py output contract, checked on the CODE that builds the line (bench.make_line on synthetic stage times) and on
+the argument defaults -- no GPU needed. (The round's measured lines live in profiles/ as evidence, not as test input.)"""
 import json
 import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _line(name):
-    return json.load(open(os.path.join(ROOT, "profiles", name)))
-
-
-def test_committed_bench_line_has_every_contract_field():
-    d = _line("r02_g_bench.json")
-    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert key in d, key
-    assert d["metric"] in json.dumps(base) and d["n_gpus"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
-    assert "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] - 1000.0 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]      # whole-job hypotheses per second
-    r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
-    assert r["traffic"] is None or r["traffic"] > 0
-    c = d["cpu_baseline"]
-    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-    assert c["unit"] == d["unit"]
-
-
-def test_rocprof_summary_agrees_with_the_bench_line():
-    """roofline.avg_launch_ms (HIP events inside bench.py) vs the committed rocprofv3 --stats average of the same kernel."""
-    d = _line("r02_g_bench.json")
-    kernel = d["roofline"]["kernel"]
-    import csv
-    avg_ns = None
-    for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats.csv"))):
-        if re.search(r"\b%s\(" % re.escape(kernel), row["Name"]):
-            avg_ns = float(row["AverageNs"])
-            break
-    assert avg_ns is not None, kernel
-    assert abs(avg_ns * 1e-6 - d["roofline"]["avg_launch_ms"]) / d["roofline"]["avg_launch_ms"] < 0.05
-
-
-def test_bench_defaults_are_one_gpu_and_minutes():
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    assert re.search(r'"--gpus", type=int, default=1', src)
-    steps = int(re.search(r'"--steps", type=int, default=(\d+)', src).group(1))
-    assert 1 <= steps <= 100
 
 
 def _bench_module():
@@ -57,6 +13,70 @@ def _bench_module():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+STAGES = ["fps1", "ball1", "sa1", "p2", "fps2", "ball2", "sa2", "sa3", "fc"]
+
+
+def test_make_line_has_every_contract_field_and_consistent_arithmetic():
+    bench = _bench_module()
+    stage_ms = [0.44, 0.43, 6.2, 0.26, 0.07, 0.05, 6.0, 0.8, 0.13]
+    base = {"value": 104.0, "unit": "hyp/s", "cores": 16, "kind": "port", "sample": "192 of the 1000 hypotheses"}
+    steps, world, elapsed = 20, 2, 0.31
+    d = bench.make_line(STAGES, stage_ms, 0.035, elapsed, world, steps, 3, 1, 0, base, {"forward": {}})
+    d = json.loads(json.dumps(d))                                    # it must survive the trip through JSON
+    baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] in json.dumps(baseline) and d["n_gpus"] == world and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["steps"] == steps and d["warmup"] == 3
+    assert "workload" in d["config"] and "model" not in d["config"] and "configs[1]" in d["config"]["workload"]
+    # whole-job hypotheses per second over ALL ranks; ms_per_step is one frame per rank
+    assert abs(d["ms_per_step"] - 1e3 * elapsed / steps) < 1e-9
+    assert abs(d["value"] - world * 1000.0 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["kernel"] == "sa1_kernel"      # the slowest MFMA stage
+    assert r["peak"] == bench.PEAK_F32_MATRIX_TFLOPS
+    assert abs(r["achieved"] - bench.SA1_FLOPS * 1000 / 6.2e-3 / 1e12) < 1e-9
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert abs(r["flops_per_launch"] - bench.SA1_FLOPS * 1000) < 1
+    f = d["featurize"]
+    assert f["bound"] == "hbm" and f["unit"] == "GB/s" and abs(f["frac"] - f["achieved"] / f["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert c["unit"] == d["unit"]
+    assert set(d["stage_ms"]) == set(STAGES)
+    # another stage dominating moves the roofline block with it
+    stage_ms2 = list(stage_ms)
+    stage_ms2[6] = 7.5
+    assert bench.make_line(STAGES, stage_ms2, 0.035, elapsed, 1, steps, 3, 1, 0, None, None)["roofline"]["kernel"] == "sa2_kernel"
+
+
+def test_dtoid_flop_model_is_consistent():
+    """nominal = the survey's 39.7 + 45.96 n_t GFLOP; the executed count never exceeds it and the GEMM reassociation only
+    switches on from 16 templates."""
+    bench = _bench_module()
+    for nt in (1, 10, 15, 16, 21, 160):
+        nominal, executed = bench.dtoid_flops(nt)
+        assert abs(nominal - (39.7e9 + 45.96e9 * nt)) < 1 and 0 < executed < nominal
+    assert bench.dtoid_flops(16)[1] - bench.dtoid_flops(15)[1] < bench.dtoid_flops(15)[1] - bench.dtoid_flops(14)[1]
+
+
+def test_a_failed_dtoid_leg_exits_non_zero_after_printing_the_line():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tail = src[src.index("    emit(dtoid_out)"):]
+    assert "os._exit(4)" in tail and tail.index("emit(dtoid_out)") < tail.index("os._exit(4)")
+    assert "GraphedForwardBackward" not in src                 # the graph-replay comparison lives in tools/bench_finetune.py
+
+
+def test_bench_defaults_are_one_gpu_and_minutes():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert re.search(r'"--gpus", type=int, default=1', src)
+    steps = int(re.search(r'"--steps", type=int, default=(\d+)', src).group(1))
+    assert 1 <= steps <= 100
 
 
 def test_reported_world_is_the_launched_world_never_the_gpus_flag():

@@ -1,0 +1,168 @@
+"""Round-3 GPU tests of the finetune step's plumbing (D16 / SURVEY 8e): hipGraph capture hygiene after eager steps, the
+RCCL gradient exchange executed on a 1-rank group with every stream hand-off live, and weight gradients when the
+parameters already hold a gradient. Reference contract: scripts/online_learning.py:650-679, train.py:93-102."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ossid_code_amd import dtoid
+from ossid_code_amd.dtoid import finetune
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(cfg, B, dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    H, W, hh, hw = cfg.model.img_h, cfg.model.img_w, cfg.model.heatmap_h, cfg.model.heatmap_w
+    mask = torch.zeros(B, 1, H, W)
+    mask[:, :, H // 4: H // 2, W // 4: W // 2] = 1
+    b = {"img": torch.rand(B, 3, H, W, generator=g), "limg": torch.rand(B, 3, 124, 124, generator=g),
+         "lmask": (torch.rand(B, 1, 124, 124, generator=g) > 0.5).float(),
+         "gimg": torch.rand(B, 3, 124, 124, generator=g), "gmask": (torch.rand(B, 1, 124, 124, generator=g) > 0.5).float(),
+         "bbox_gt": torch.tensor([[[W / 4.0, H / 4.0, W / 2.0, H / 2.0, 1.0]]]).repeat(B, 1, 1),
+         "heatmap": torch.rand(B, 1, hh, hw, generator=g).double(), "mask": mask}
+    return {k: v.to(dev) for k, v in b.items()}
+
+
+def _used(flat):
+    """The gradient values of the used parameters (without the float4 padding at the end of the flat buffer)."""
+    return torch.cat([flat.grad[off:off + n] for off, n in (flat.offsets[name] for name, _ in flat.entries)
+                      if off < flat.n_used])
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-30))
+
+
+def test_capture_after_eager_steps_and_a_forward_only_pass(hiplib):
+    """The round-2 `capture_end` crash scenario, fenced: eager multi-stream finetune steps (losses kept), a training-mode
+    forward whose backward never runs (it used to leak its graph through DenseBlockTrain's ctx), THEN
+    GraphedForwardBackward -- the capture must go through and replay == eager. While an output WITH its grad_fn is still
+    held, the capture is refused with a RuntimeError instead of being attempted."""
+    cfg = dtoid.DtoidConfig()
+    torch.manual_seed(0)
+    m = dtoid.DtoidNet(cfg).cuda().train()
+    flat = finetune.FlatParams(m)
+    opt = finetune.FusedAMSGrad(flat, lr=1e-4, weight_decay=1e-6)
+    b = _batch(cfg, 2, "cuda")
+    kept = [finetune.finetune_step(m, b, opt) for _ in range(2)]          # detached losses, kept alive
+    loss_fwd_only = m(b)["loss"]                                           # forward only
+    assert loss_fwd_only.grad_fn is not None
+    params = [p for _, p in flat.entries]
+    assert len(finetune.pinned_grad_accumulators(params)) > 0              # the live graph pins its AccumulateGrad nodes
+    with pytest.raises(RuntimeError, match="earlier iteration"):
+        finetune.GraphedForwardBackward(m, flat, b)
+    del loss_fwd_only
+    assert finetune.pinned_grad_accumulators(params) == []                 # nothing leaked once the loss is gone
+    state = flat.param.clone()
+    bufs = [t.detach().clone() for t in m.buffers()]
+    graphed = finetune.GraphedForwardBackward(m, flat, b)
+    for t, s0 in zip(m.buffers(), bufs):                                   # capturing changed no state
+        assert torch.equal(t.detach(), s0)
+    assert torch.equal(flat.param, state)
+    # replay vs eager from the same state, same batch: losses and gradients
+    flat.detach_grads()
+    m(b)["loss"].backward()
+    flat.gather_grads()
+    g_eager, l_eager = flat.grad.clone(), float(m(b)["loss"].detach())
+    l_graph = float(graphed(b))
+    g_graph = flat.grad.clone()
+    assert abs(l_graph - l_eager) <= 1e-4 * abs(l_eager)
+    assert _rel(g_graph, g_eager) < 2e-3
+    assert all(np.isfinite(float(k)) for k in kept)
+
+
+@pytest.fixture(scope="module")
+def rccl_world1():
+    """A 1-rank RCCL ("nccl") process group on the leased GPU: every collective really goes through RCCL."""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        yield dist
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    port = 29600 + os.getpid() % 2000
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_gradsync_on_rccl_world1_overlapped_equals_plain(hiplib, rccl_world1):
+    """GradSync with force_collectives on a 1-rank RCCL group, weight gradients on their side stream and the head /
+    encoder branches on theirs (the product defaults): the overlapped exchange (per-bucket gather + all-reduce issued from
+    autograd hooks on GradSync's own stream) must give the gradient buffer of the plain form (backward, gather, one
+    all-reduce) -- equal to within the run-to-run noise of the plain form itself (bit for bit when that noise is zero;
+    MIOpen layers are not run-to-run deterministic). A missing cross-stream wait shows up as stale or partial
+    gradients, i.e. as differences of order one."""
+    from ossid_code_amd.dtoid import train_ops
+    dist = rccl_world1
+    assert dist.get_backend() == "nccl"
+    assert train_ops.WGRAD_SIDE
+    cfg = dtoid.DtoidConfig()
+    torch.manual_seed(4)
+    m = dtoid.DtoidNet(cfg).cuda().train()
+    assert m.model.use_train_streams
+    flat = finetune.FlatParams(m)
+    b = _batch(cfg, 4, "cuda", seed=1)
+
+    def grads(sync):
+        flat.grad.fill_(float("nan"))                      # whatever is not written this pass must show
+        out = m(b)
+        flat.detach_grads()
+        if sync.overlap:
+            sync.begin()
+            out["loss"].backward()
+            sync.finish()
+        else:
+            out["loss"].backward()
+            flat.gather_grads()
+            sync.sync()
+        torch.cuda.synchronize()
+        return _used(flat)
+    plain = finetune.GradSync(flat, model=m, overlap=False, force_collectives=True)
+    over = finetune.GradSync(flat, model=m, overlap=True, force_collectives=True, bucket_mb=8)
+    assert plain.collectives and over.collectives and len(over._buckets) >= 8
+    plain.broadcast_params(0)
+    g0 = grads(plain)
+    g1 = grads(plain)
+    noise = _rel(g1, g0)
+    for _ in range(2):                                      # twice: the second pass reuses hooks and the comm stream
+        g2 = grads(over)
+        assert torch.isfinite(g2).all()
+        d = _rel(g2, g0)
+        if noise == 0.0:
+            assert torch.equal(g2, g0)
+        assert d <= max(4 * noise, 1e-6), (d, noise)
+    assert len(over._works) == 0
+    # the whole step through finetune_step on RCCL: finite, loss falls, replicas' buffers "broadcast" from rank 0
+    opt = finetune.FusedAMSGrad(flat, lr=1e-4, weight_decay=1e-6)
+    losses = [float(finetune.finetune_step(m, b, opt, over)) for _ in range(3)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_weight_gradients_when_parameters_already_hold_a_gradient(hiplib, monkeypatch):
+    """`optimizer.zero_grad(); loss.backward(); optimizer.step()` with FlatParams' preset .grad views (the reference loop,
+    online_learning.py:666-668, with FusedAMSGrad substituted): AccumulateGrad then ADDS the weight gradient on the main
+    stream as soon as the convolution's backward returns, so the side-stream launch would be read before it ran.
+    _wgrad_async keeps such launches in line: gradients equal the one-stream result (to MIOpen's run-to-run noise)."""
+    from ossid_code_amd.dtoid import train_ops
+    cfg = dtoid.DtoidConfig()
+    b = _batch(cfg, 2, "cuda", seed=3)
+    got = []
+    for side in (False, False, True):
+        monkeypatch.setattr(train_ops, "WGRAD_SIDE", side)
+        torch.manual_seed(8)
+        m = dtoid.DtoidNet(cfg).cuda().train()
+        flat = finetune.FlatParams(m)
+        opt = finetune.FusedAMSGrad(flat)
+        opt.zero_grad()
+        assert m.model.correlation_model.cf.weight.grad is not None
+        m(b)["loss"].backward()
+        torch.cuda.synchronize()
+        got.append(flat.used_grad().clone())
+    noise = _rel(got[1], got[0])
+    d = _rel(got[2], got[0])
+    assert d <= max(4 * noise, 1e-6), (d, noise)
+    assert float(got[2].abs().max()) > 0
