@@ -48,13 +48,11 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=192, help="hypotheses in the CPU-oracle sample")
     p.add_argument("--no-dtoid", action="store_true", help="skip the secondary DTOID measurements")
-    p.add_argument("--streams", type=int, default=1,
-                   help="frames in flight per GPU (HIP streams). 2 overlaps the VALU/LDS-bound sampling kernels of one "
-                        "frame with the MFMA-bound MLP kernels of another (+3.6 %% measured) but then the per-kernel "
-                        "HIP-event durations include the other frame's kernels, so the roofline leg needs 1 (default)")
-    p.add_argument("--overlap-chunks", type=int, default=None,
-                   help="pieces a frame's hypotheses are scored in, alternating two HIP side streams (PointNet2SSG.score; "
-                        "default: the product default, 4 at 1000 hypotheses; 1 = one stream)")
+    p.add_argument("--streams", type=int, default=2,
+                   help="frames in flight per GPU in the timed region, on alternating HIP streams (the product form: "
+                        "scoring.networkInferenceMany keeps two in flight). The kernels of one frame fill the launch tails of "
+                        "the other's (+3.5 %% measured). Per-kernel HIP-event durations for the roofline block are taken in a "
+                        "second pass with ONE frame in flight, so that they do not include another frame's kernels")
     p.add_argument("--dtoid-templates", type=int, default=21)
     p.add_argument("--dtoid-images", type=int, default=32, help="images per batch of the configs[2] leg")
     p.add_argument("--dtoid-timeout", type=int, default=420, help="watchdog (s) for the secondary DTOID leg")
@@ -347,8 +345,7 @@ def make_line(names, stage_ms, feat_ms, elapsed, world, steps, warmup, n_streams
     """THE json line (pure host logic: tests/test_bench_contract.py checks its schema and arithmetic on synthetic stage
     times). names / stage_ms: the scorer's stage names and their mean HIP-event durations (ms) per frame with every kernel
     alone on the chip (one stream, one launch per stage); feat_ms: the featurize kernel's; elapsed: seconds for `steps`
-    frames per rank (max over ranks) in the product form. extra: {"pieces": n, "stage_ms_timed": per-stage ms summed over
-    the frame's pieces inside the timed region}."""
+    frames per rank (max over ranks) with n_streams frames in flight. extra: reserved."""
     traffic = None
     try:   # HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py)
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
@@ -370,24 +367,17 @@ def make_line(names, stage_ms, feat_ms, elapsed, world, steps, warmup, n_streams
                                "SA 128/0.4/64 [131,128,128,256], SA all [259,256,512,1024], FC 512-256-1); "
                                "BASELINE.json configs[1]" % (N_HYP, N_PTS, IMG_W, IMG_H),
                    "frames_per_step_per_gpu": 1, "frames_in_flight_per_gpu": n_streams,
-                   "pieces_per_frame_on_two_streams": 1 if extra is None else int(extra["pieces"]),
                    "parallelism": "frames sharded, %d rank(s)" % world, "top1": top1},
         "roofline": {"bound": "mfma", "kernel": dom + "_kernel", "achieved": achieved,
                      "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
                      "traffic": traffic, "avg_launch_ms": dom_ms,
                      "flops_per_launch": STAGE_FLOPS[dom] * N_HYP,
-                     "measured": "HIP events around the kernel, one launch over all %d hypotheses, alone on the chip%s"
-                                 % (N_HYP, "" if extra is None or int(extra["pieces"]) <= 1 else
-                                    " (a second pass over the same frames; in the timed region the frame runs as %d pieces "
-                                    "on two streams and this kernel's launches, overlapped by the other stream's, sum to "
-                                    "%.3f ms: %.3f of peak)" % (
-                                        int(extra["pieces"]), float(extra["stage_ms_timed"][names.index(dom)]),
-                                        STAGE_FLOPS[dom] * N_HYP / (float(extra["stage_ms_timed"][names.index(dom)]) * 1e-3)
-                                        / 1e12 / PEAK_F32_MATRIX_TFLOPS)),
+                     "measured": "HIP events on the launch stream around the kernel, one launch over all %d hypotheses, alone "
+                                 "on the chip: a second pass over the timed region's frames with one frame in flight (the timed "
+                                 "region keeps %d in flight, whose kernels run in each other's launch tails)" % (N_HYP, n_streams),
                      "whole_step_frac": sum(STAGE_FLOPS.values()) * N_HYP / (elapsed / steps) / 1e12 / PEAK_F32_MATRIX_TFLOPS},
         "stage_ms": {n: round(float(v), 4) for n, v in zip(names, stage_ms)},
-        "stage_ms_timed_region": None if extra is None else
-        {n: round(float(v), 4) for n, v in zip(names, extra["stage_ms_timed"])},
+        "stage_ms_sum": round(float(sum(stage_ms)), 4),
         "featurize": {"bound": "hbm", "avg_launch_ms": feat_ms, "achieved": feat_bytes / (feat_ms * 1e-3) / 1e9,
                       "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": feat_bytes / (feat_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                       "bytes_per_launch": feat_bytes},
@@ -438,15 +428,11 @@ def main():
     K = d["cam_K"]
     cam = tuple(float(np.float32(v)) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
     names = _lib.StageEvents.names()
-    # The timed region runs the PRODUCT form of the step: the frame's hypotheses scored in `pieces` pieces alternating two
-    # HIP side streams, so that the sampling kernels of one piece run under the matrix-core stages of another
-    # (PointNet2SSG.OVERLAP_CHUNKS). One set of HIP events per timed step and piece: recorded on the launch stream inside the
-    # timed region (a record is an enqueue, no sync), read back after the region's final synchronize.
-    pieces = model.overlap_pieces(N_HYP) if a.overlap_chunks is None else max(1, a.overlap_chunks)
-    ev_sets = [[_lib.StageEvents() for _ in range(pieces)] for _ in range(a.steps)]
+    # The timed region runs the product form of the loop: `--streams` frames in flight on alternating HIP streams
+    # (scoring.networkInferenceMany). Per-kernel HIP events are taken in a second pass (below), one frame at a time.
     feat_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
-    def step(i=None, events=None, overlap=None):
+    def step(i=None, events=None):
         rgbd = zephyr.stage_frame(img, depth, dev, blur=True)
         tab = zephyr.stage_model(pts, nrm, col, dev)
         if i is not None:
@@ -454,7 +440,7 @@ def main():
         px, uv = zephyr.featurize(rgbd, T, tab, cam, want_uv=True)
         if i is not None:
             feat_evs[i][1].record()
-        scores = model.score(px, stage_events=events, overlap=pieces if overlap is None else overlap)
+        scores = model.score(px, stage_events=events)
         return scores, scores.argmax()
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
@@ -470,7 +456,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         with torch.cuda.stream(streams[i % len(streams)]):
-            scores, top = step(i, ev_sets[i])
+            scores, top = step(i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -480,27 +466,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel durations of those same K steps: per stage, the sum over the frame's pieces (kernels of the two side
-    # streams share the chip, so these include each other's interference)
-    stage_ms_timed = np.mean([np.sum([e.elapsed_ms() for e in evs], axis=0) for evs in ev_sets], axis=0)
     feat_ms = float(np.mean([s0.elapsed_time(s1) for s0, s1 in feat_evs]))
-    for evs in ev_sets:
-        for e in evs:
-            e.close()
-    # The roofline leg: the same K frames once more on ONE stream, one launch per stage over all 1000 hypotheses, HIP events
-    # around every stage -- each kernel alone on the chip, which is what a per-kernel fraction of peak means and what the
-    # committed rocprofv3 summary of this command shows for the 1000-hypothesis grids. (With one piece the timed region
-    # already is that form and its own events are used.)
-    if pieces > 1 or len(streams) > 1:
-        clean = [_lib.StageEvents() for _ in range(a.steps)]
-        for i in range(a.steps):
-            step(None, clean[i], overlap=1)
-        torch.cuda.synchronize()
-        stage_ms = np.mean([e.elapsed_ms() for e in clean], axis=0)
-        for e in clean:
-            e.close()
-    else:
-        stage_ms = stage_ms_timed
+    # The roofline leg: the same K frames once more, ONE frame in flight, HIP events recorded on the launch stream around
+    # every stage (ossid_pn2_score's stage_events_host) -- each kernel alone on the chip, which is what a per-kernel
+    # fraction of peak means. (rocprofv3's per-kernel averages over this command mix both passes: launches of the timed
+    # region run beside another frame's kernels and take a few per cent longer.)
+    clean = [_lib.StageEvents() for _ in range(a.steps)]
+    for i in range(a.steps):
+        step(None, clean[i])
+    torch.cuda.synchronize()
+    stage_ms = np.mean([e.elapsed_ms() for e in clean], axis=0)
+    for e in clean:
+        e.close()
 
     top1 = int(top.item())
     got_sample = scores[: len(base_scores)].cpu().numpy() if base_scores is not None else None
@@ -511,7 +488,7 @@ def main():
             return
         if base_scores is not None:   # the GPU scores of the sampled hypotheses are the oracle's, bit for bit
             assert np.array_equal(got_sample, base_scores), "GPU scores differ from the CPU oracle"
-        extra = {"pieces": pieces, "stage_ms_timed": stage_ms_timed}
+        extra = None
         print(json.dumps(make_line(names, stage_ms, feat_ms, elapsed, world, a.steps, a.warmup, len(streams), top1, base,
                                    dtoid_out, extra)), flush=True)
 

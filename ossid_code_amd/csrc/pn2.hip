@@ -1060,73 +1060,117 @@ const char* ossid_pn2_kernel_names(void) {
     return "fps_reg_kernel,fps_kernel,ball_query_kernel,sa1_kernel,p2_kernel,sa2_kernel,sa3_kernel,fc_head_kernel";
 }
 
+// The nine stages of ossid_pn2_score, one launcher each.
+}  // extern "C"
+namespace {
+struct Pn2Call {
+    const float* point_x;
+    int B, M, np1, np2;
+    const ossid_pn2_weights* w;
+    Workspace ws;
+    hipStream_t s;
+};
+
+int pn2_check(const float* point_x, int B, int M, const ossid_pn2_weights* w, void* workspace, size_t workspace_bytes,
+              void* stream, Pn2Call* c) {
+    if (B < 0 || !w) return OSSID_EINVAL;
+    if (B == 0) return 1;      // nothing to do
+    const int np1 = w->npoint1, np2 = w->npoint2;
+    if (!point_x || !workspace || !w->blob) return OSSID_EINVAL;
+    if (np1 <= 0 || np2 <= 0 || np1 % 32 || np2 % 32 || M < np1 || np1 < np2) return OSSID_EINVAL;
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)point_x & 15)) return OSSID_EINVAL;
+    c->ws = carve((char*)workspace, B, M, np1, np2);
+    if (c->ws.bytes > workspace_bytes) return OSSID_EINVAL;
+    c->point_x = point_x; c->B = B; c->M = M; c->np1 = np1; c->np2 = np2; c->w = w; c->s = (hipStream_t)stream;
+    return OSSID_OK;
+}
+
+int pn2_fps1(const Pn2Call& c) { return launch_fps(c.point_x, 8, c.B, c.M, c.np1, c.ws.fps1, c.ws.xyz1, c.s); }
+int pn2_ball1(const Pn2Call& c) { return launch_ball(c.point_x, 8, c.B, c.M, c.ws.xyz1, c.np1, c.w->radius1, c.ws.ball1, c.s); }
+int pn2_fps2(const Pn2Call& c) { return launch_fps(c.ws.xyz1, 3, c.B, c.np1, c.np2, c.ws.fps2, c.ws.xyz2, c.s); }
+int pn2_ball2(const Pn2Call& c) { return launch_ball(c.ws.xyz1, 3, c.B, c.np1, c.ws.xyz2, c.np2, c.w->radius2, c.ws.ball2, c.s); }
+
+int pn2_sa1(const Pn2Call& c) {
+    const float* blob = c.w->blob;
+    const int total = c.B * c.np1;
+    const int grid = (total + 4 * SA1_CPW - 1) / (4 * SA1_CPW);
+    OSSID_ENSURE_LDS(sa1_kernel, (size_t)SA1_LDS_FLOATS * 4);
+    hipLaunchKernelGGL(sa1_kernel, dim3(grid), dim3(256), SA1_LDS_FLOATS * 4, c.s, c.point_x, c.M, c.ws.ball1, c.ws.xyz1, c.np1, total,
+                       blob + c.w->w_off[0], blob + c.w->b_off[0], blob + c.w->w_off[1], blob + c.w->b_off[1],
+                       blob + c.w->w_off[2], blob + c.w->b_off[2], c.ws.feat1);
+    return ossid_launch_status();
+}
+int pn2_p2(const Pn2Call& c) {
+    const float* blob = c.w->blob;
+    const int tiles = c.B * c.np1 / 32;
+    hipLaunchKernelGGL(p2_kernel, dim3((tiles + 7) / 8), dim3(256), 0, c.s, c.ws.feat1, tiles, blob + c.w->w_off[3],
+                       blob + c.w->b_off[3], c.ws.p2);
+    return ossid_launch_status();
+}
+int pn2_sa2(const Pn2Call& c) {
+    const float* blob = c.w->blob;
+    const int total = c.B * c.np2;
+    const int per_wg = (SA2_THREADS / 64) * SA2_CPW;
+    const int grid = (total + per_wg - 1) / per_wg;
+    OSSID_ENSURE_LDS(sa2_kernel, (size_t)SA2_LDS_FLOATS * 4);
+    hipLaunchKernelGGL(sa2_kernel, dim3(grid), dim3(SA2_THREADS), SA2_LDS_FLOATS * 4, c.s, c.ws.p2, c.ws.xyz1, c.np1, c.ws.ball2,
+                       c.ws.xyz2, c.np2, total, blob + c.w->wxyz2_off, blob + c.w->w_off[4], blob + c.w->b_off[4],
+                       blob + c.w->w_off[5], blob + c.w->b_off[5], c.ws.feat2);
+    return ossid_launch_status();
+}
+int pn2_sa3(const Pn2Call& c) {
+    const float* blob = c.w->blob;
+    hipLaunchKernelGGL(sa3_kernel, dim3(c.B), dim3(256), 0, c.s, c.ws.feat2, c.ws.xyz2, c.np2, blob + c.w->w_off[6],
+                       blob + c.w->b_off[6], blob + c.w->w_off[7], blob + c.w->b_off[7], blob + c.w->w_off[8],
+                       blob + c.w->b_off[8], c.ws.feat3);
+    return ossid_launch_status();
+}
+int pn2_fc(const Pn2Call& c, float* scores) {
+    const float* blob = c.w->blob;
+    hipLaunchKernelGGL(fc_head_kernel, dim3((c.B + FC_HB - 1) / FC_HB), dim3(256), 0, c.s, c.ws.feat3, c.B, blob + c.w->w_off[9],
+                       blob + c.w->b_off[9], blob + c.w->w_off[10], blob + c.w->b_off[10], blob + c.w->w_off[11],
+                       blob + c.w->b_off[11], scores);
+    return ossid_launch_status();
+}
+}  // namespace
+
+extern "C" {
+
 int ossid_pn2_score(const float* point_x, int B, int M, const ossid_pn2_weights* w, void* workspace,
                     size_t workspace_bytes, float* scores, int32_t* dbg_fps1, int32_t* dbg_ball1, float* dbg_feat1,
                     int32_t* dbg_fps2, int32_t* dbg_ball2, float* dbg_feat2, float* dbg_feat3,
                     void* const* stage_events_host, void* stream) {
-    if (B < 0 || !w) return OSSID_EINVAL;
-    if (B == 0) return OSSID_OK;
-    const int np1 = w->npoint1, np2 = w->npoint2;
-    if (!point_x || !scores || !workspace || !w->blob) return OSSID_EINVAL;
-    if (np1 <= 0 || np2 <= 0 || np1 % 32 || np2 % 32 || M < np1 || np1 < np2) return OSSID_EINVAL;
-    if (((uintptr_t)workspace & 255) || ((uintptr_t)point_x & 15)) return OSSID_EINVAL;
-    Workspace ws = carve((char*)workspace, B, M, np1, np2);
-    if (ws.bytes > workspace_bytes) return OSSID_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    const float* blob = w->blob;
-    auto W = [&](int i) { return blob + w->w_off[i]; };
-    auto Bv = [&](int i) { return blob + w->b_off[i]; };
-    int rc;
+    Pn2Call c;
+    int rc = pn2_check(point_x, B, M, w, workspace, workspace_bytes, stream, &c);
+    if (rc) return rc < 0 ? rc : OSSID_OK;
+    if (!scores) return OSSID_EINVAL;
+    const Workspace& ws = c.ws;
+    const int np1 = c.np1, np2 = c.np2;
+    hipStream_t s = c.s;
     int stage = 0;
     auto mark = [&]() {
         if (stage_events_host && hipEventRecord((hipEvent_t)stage_events_host[stage], s) != hipSuccess) rc = OSSID_ELAUNCH;
         ++stage;
     };
-
-    // SA1
+    rc = OSSID_OK;
     mark();
-    if ((rc = launch_fps(point_x, 8, B, M, np1, ws.fps1, ws.xyz1, s))) return rc;
+    if ((rc = pn2_fps1(c))) return rc;
     mark();
-    if ((rc = launch_ball(point_x, 8, B, M, ws.xyz1, np1, w->radius1, ws.ball1, s))) return rc;
+    if ((rc = pn2_ball1(c))) return rc;
     mark();
-    {
-        const int total = B * np1;
-        const int grid = (total + 4 * SA1_CPW - 1) / (4 * SA1_CPW);
-        OSSID_ENSURE_LDS(sa1_kernel, (size_t)SA1_LDS_FLOATS * 4);
-        hipLaunchKernelGGL(sa1_kernel, dim3(grid), dim3(256), SA1_LDS_FLOATS * 4, s, point_x, M, ws.ball1, ws.xyz1, np1, total, W(0),
-                           Bv(0), W(1), Bv(1), W(2), Bv(2), ws.feat1);
-        if ((rc = ossid_launch_status())) return rc;
-    }
-    // SA2
+    if ((rc = pn2_sa1(c))) return rc;
     mark();
-    {
-        const int tiles = B * np1 / 32;
-        hipLaunchKernelGGL(p2_kernel, dim3((tiles + 7) / 8), dim3(256), 0, s, ws.feat1, tiles, W(3), Bv(3), ws.p2);
-        if ((rc = ossid_launch_status())) return rc;
-    }
+    if ((rc = pn2_p2(c))) return rc;
     mark();
-    if ((rc = launch_fps(ws.xyz1, 3, B, np1, np2, ws.fps2, ws.xyz2, s))) return rc;
+    if ((rc = pn2_fps2(c))) return rc;
     mark();
-    if ((rc = launch_ball(ws.xyz1, 3, B, np1, ws.xyz2, np2, w->radius2, ws.ball2, s))) return rc;
+    if ((rc = pn2_ball2(c))) return rc;
     mark();
-    {
-        const int total = B * np2;
-        const int per_wg = (SA2_THREADS / 64) * SA2_CPW;
-        const int grid = (total + per_wg - 1) / per_wg;
-        OSSID_ENSURE_LDS(sa2_kernel, (size_t)SA2_LDS_FLOATS * 4);
-        hipLaunchKernelGGL(sa2_kernel, dim3(grid), dim3(SA2_THREADS), SA2_LDS_FLOATS * 4, s, ws.p2, ws.xyz1, np1, ws.ball2, ws.xyz2, np2,
-                           total, blob + w->wxyz2_off, W(4), Bv(4), W(5), Bv(5), ws.feat2);
-        if ((rc = ossid_launch_status())) return rc;
-    }
-    // SA3 + FC head
+    if ((rc = pn2_sa2(c))) return rc;
     mark();
-    hipLaunchKernelGGL(sa3_kernel, dim3(B), dim3(256), 0, s, ws.feat2, ws.xyz2, np2, W(6), Bv(6), W(7), Bv(7), W(8),
-                       Bv(8), ws.feat3);
-    if ((rc = ossid_launch_status())) return rc;
+    if ((rc = pn2_sa3(c))) return rc;
     mark();
-    hipLaunchKernelGGL(fc_head_kernel, dim3((B + FC_HB - 1) / FC_HB), dim3(256), 0, s, ws.feat3, B, W(9), Bv(9),
-                       W(10), Bv(10), W(11), Bv(11), scores);
-    if ((rc = ossid_launch_status())) return rc;
+    if ((rc = pn2_fc(c, scores))) return rc;
     mark();
 
     auto cp = [&](void* dst, const void* src, size_t n) {

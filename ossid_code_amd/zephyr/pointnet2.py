@@ -119,13 +119,14 @@ def pack_pn2(folded):
 
 class PointNet2SSG(nn.Module):
     MAX_CHUNK = 4096  # hypotheses per C-ABI call (bounds the workspace at ~0.72 MB each)
-    # One frame's hypotheses are scored in OVERLAP_CHUNKS pieces alternating two HIP side streams (ossid_code_amd.streams:
-    # probed to really run beside each other): the sampling / grouping kernels of piece k+1 (fps, ball query: vector-ALU and
-    # LDS work, ~6 % of the step) run under the matrix-core stages of piece k instead of in front of them. Hypotheses are
-    # independent, so the scores are bit-identical to the one-launch form (tests/test_zephyr_gpu.py chunking property).
-    # 1 = one stream, one launch per stage (what the per-kernel roofline measurements use).
-    OVERLAP_CHUNKS = int(os.environ.get("OSSID_PN2_OVERLAP_CHUNKS", "4"))
-    OVERLAP_MIN_PER_CHUNK = 128     # below this a piece no longer fills the chip's 256 CUs with its MLP workgroups
+    # Measured and NOT adopted (round 3, profiles/r03_scorer_overlap.txt): overlapping the sampling kernels (fps / ball query:
+    # vector-ALU and LDS work, 6.5 % of the step) with the matrix-core stages INSIDE one call. The sampling stages read
+    # coordinates only, so they can run ahead on a side stream -- but the MLP kernels fill the register file and 51-128 KB of LDS
+    # per workgroup, so nothing co-resides with them: all a second stream can do is fill the tail of each launch, and cutting
+    # one call into pieces adds more tails (and partial rounds: sa3 runs one workgroup per hypothesis, 1000 = 3.9 rounds of
+    # 256) than it fills. One call, one stream: 15.19 ms; 4 pieces alternating two streams 15.78; sampling ahead on a side
+    # stream in pieces [128, 872] 16.00, [504, 496] 15.55. Two whole FRAMES in flight on two streams (scoring.networkInferenceMany,
+    # bench.py's timed region) do gain: 14.67 ms per frame.
 
     def __init__(self, dim_in, args=None, num_class=1):
         super().__init__()
@@ -184,11 +185,9 @@ class PointNet2SSG(nn.Module):
             self._ws[key] = ws
         return ws
 
-    def score(self, point_x, debug=False, stage_events=None, overlap=None):
+    def score(self, point_x, debug=False, stage_events=None):
         """point_x [B, M, 8] float32 on the GPU -> scores [B] (and the stage tensors when debug).
-        overlap: number of pieces scored on two alternating side streams (None = OVERLAP_CHUNKS when the batch is large
-        enough, 1 = everything on the current stream). stage_events: one _lib.StageEvents (one-stream form) or a list with
-        one per piece."""
+        stage_events: a _lib.StageEvents to time every stage of the call."""
         _lib.require_cuda(point_x)
         if self.training:
             raise NotImplementedError("PointNet2SSG is inference-only on this path: call .eval() "
@@ -223,45 +222,10 @@ class PointNet2SSG(nn.Module):
                    *dargs, None if events is None else events.arr, _lib.stream())
             _lib.check(rc, "ossid_pn2_score")
 
-        pieces = self.overlap_pieces(B) if overlap is None else max(1, min(int(overlap), max(B, 1)))
-        if stage_events is not None and not isinstance(stage_events, (list, tuple)):
-            pieces = 1                                        # one set of events = the one-stream, one-launch-per-stage form
-        if isinstance(stage_events, (list, tuple)) and len(stage_events) != pieces:
-            raise ValueError("stage_events: one StageEvents per piece (%d), got %d" % (pieces, len(stage_events)))
-        if debug or torch.cuda.is_current_stream_capturing():
-            pieces = 1
         with torch.cuda.device(dev):
-            if pieces <= 1:
-                ev = stage_events[0] if isinstance(stage_events, (list, tuple)) else stage_events
-                for b0 in range(0, B, self.MAX_CHUNK):
-                    launch(b0, min(self.MAX_CHUNK, B - b0), ev)
-            else:
-                from ..streams import side_streams
-                pool = side_streams(dev)
-                sides = (pool["b0"], pool["b1"])
-                cur = torch.cuda.current_stream(dev)
-                for sd in sides:
-                    sd.wait_stream(cur)
-                per = -(-B // pieces)
-                per = (per + 7) // 8 * 8                      # the FC head scores 8 hypotheses per workgroup
-                k = 0
-                for b0 in range(0, B, per):
-                    with torch.cuda.stream(sides[k & 1]):
-                        launch(b0, min(per, B - b0), None if stage_events is None else stage_events[k])
-                    k += 1
-                for sd in sides:
-                    cur.wait_stream(sd)
-                    point_x.record_stream(sd)
-                    scores.record_stream(sd)
+            for b0 in range(0, B, self.MAX_CHUNK):
+                launch(b0, min(self.MAX_CHUNK, B - b0), stage_events)
         return (scores, dbg) if debug else scores
-
-    def overlap_pieces(self, B):
-        """How many pieces score() cuts B hypotheses into by default."""
-        n = min(self.OVERLAP_CHUNKS, B // self.OVERLAP_MIN_PER_CHUNK)
-        if n <= 1 or B > self.MAX_CHUNK * n:
-            return 1
-        per = (-(-B // n) + 7) // 8 * 8
-        return -(-B // per)
 
     def forward(self, data):
         x = data["point_x"] if isinstance(data, dict) else data

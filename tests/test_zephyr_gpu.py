@@ -286,12 +286,6 @@ def test_full_size_properties(z, ozr):
     assert scores[777] == scores[3]
     perm = torch.randperm(1000, generator=torch.Generator().manual_seed(0)).cuda()
     assert torch.equal(m.score(px[perm].contiguous()), scores[perm])
-    # ... whether the frame runs as one launch per stage or as pieces on two side streams (the product default: 4)
-    assert m.overlap_pieces(1000) == 4
-    one = m.score(px, overlap=1)
-    for n in (2, 3, 4, 7):
-        assert torch.equal(m.score(px, overlap=n), one), n
-    assert torch.equal(one, scores)
     m.MAX_CHUNK = 96
     assert torch.equal(m.score(px), scores)
     # (3) feature ranges
