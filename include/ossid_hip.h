@@ -307,7 +307,17 @@ typedef struct ossid_chan_op_desc {
     int32_t channels, g_stride, x_stride, out_stride, mask_mode, accumulate, sum_mode;
     int32_t sums_row_stride;         /* floats between sums[0][.] and sums[1][.] (0 = channels): lets a layer write the
                                         statistics of its channel slice into a block-wide [2][C_total] table */
-    int32_t defer_finalize;          /* != 0: leave the column sums as the ossid_chan_op_partials(rows, channels)
+    int32_t defer_finalize;          /* Zero `bytes` bytes at `ptr` on `stream` (an accumulator a recorded launch sequence must clear on every replay: the
+ * coefficient table of a dense block's backward pass; replaces torch.zeros inside such a sequence). */
+int ossid_fill_zero(void* ptr, size_t bytes, void* stream);
+
+/* Convolution weights [cout][cin][k][k] -> the [cout][kpad] matrix in ossid_im2col_stem's column order
+ * ((ky * k + kx) * cin + c, zero-padded), or back (inverse = 1: a weight GRADIENT computed on the im2col columns returns to
+ * the parameter's layout). The strided stems (7x7 / 2 of the image backbone, network.py:164-170; 3x3 / 2 of the template
+ * encoders, :203-208) run as im2col + a 1x1 MFMA convolution. */
+int ossid_stem_weight_relayout(const float* src, float* dst, int cout, int cin, int k, int kpad, int inverse, void* stream);
+
+/* != 0: leave the column sums as the ossid_chan_op_partials(rows, channels)
                                         per-block partials in `partials` (sums may be NULL); the consumer --
                                         ossid_bn_fold_fwd / _bwd with n_partials > 0 -- combines them itself */
 } ossid_chan_op_desc;
@@ -388,6 +398,16 @@ int ossid_stem_tail_nhwc(const float* x0, const float* kernels, int kernels_batc
 /* D2-D4  nn.MaxPool2d(k, stride, padding, ceil_mode) channels-last (DenseNet pool0: 3, 2, 1; SqueezeNet: 3, 2, 0, ceil). */
 int ossid_maxpool_nhwc(const float* x, int B, int H, int W, int C, int k, int stride, int pad, int ceil_mode, float* out,
                        void* stream);
+
+/* Separable linear resampling of a channels-last image by tap tables (training path of the template encoders,
+ * models/dtoid/network.py:223-239, :265-279):
+ *   out[b][oy][ox][out_channel_offset + c] = sum_{i,j < T} wy[oy][i] wx[ox][j] x[b][iy[oy][i]][ix[ox][j]][c]
+ * taps_*_idx [n_out][T] int32 (-1 = unused tap), taps_*_w [n_out][T] float32, T <= 8; channel strides in floats (0 = C).
+ * Covers F.interpolate(mode="bilinear", align_corners=False) (T = 2), its adjoint (transposed tables), the crop that
+ * turns a padded 3x3 convolution into the reference's valid one (T = 1) and the crop's adjoint (zero padding). */
+int ossid_resample_taps_nhwc(const float* x, int B, int Hin, int Win, int C, int x_channel_stride, int Hout, int Wout,
+                             const int32_t* taps_y_idx, const float* taps_y_w, const int32_t* taps_x_idx, const float* taps_x_w,
+                             int T, float* out, int out_channel_stride, int out_channel_offset, void* stream);
 
 /* D16  training-side companions of the stem kernels (finetune step, channels-last):
  * ossid_dw_add_nhwc: out = x + conv2d_dw_group(x, kernels) (network.py:178-179), flip != 0: the taps rotated by 180 degrees

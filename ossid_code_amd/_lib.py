@@ -98,6 +98,8 @@ _PROTOS = {
     "ossid_conv_pack_weights_wino": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ossid_conv3x3_wino_fwd": (_i, [_vp, _vp]),
     "ossid_conv3x3_wino_fwd_pair": (_i, [_vp, _vp, _vp]),
+    "ossid_fill_zero": (_i, [_vp, _sz, _vp]),
+    "ossid_stem_weight_relayout": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ossid_chan_op_partials": (_i, [C.c_longlong, _i]),
     "ossid_chan_op": (_i, [_vp, _vp]),
     "ossid_bn_fold_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -115,6 +117,7 @@ _PROTOS = {
     "ossid_dw_add_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ossid_dw_bwd_k_workspace_floats": (_sz, [_i, _i, _i]),
     "ossid_dw_bwd_k_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ossid_resample_taps_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "ossid_maxpool_idx_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ossid_maxpool_bwd_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ossid_topk_workspace_bytes": (_sz, [_i, _i]),
@@ -157,9 +160,103 @@ def fn(name):
     f = getattr(lib(), name, None)
     if f is None:
         raise RuntimeError("libossid_hip.so does not export %s -- rebuild the library" % name)
-    if _MFMA_COUNT is not None and name in _MFMA_RULES:
-        return _counting(f, _MFMA_RULES[name])
-    return f
+    g = _counting(f, _MFMA_RULES[name]) if (_MFMA_COUNT is not None and name in _MFMA_RULES) else f
+    if _REC is not None:
+        return _REC.wrap(name, f, g)
+    return g
+
+
+# ---- recorded launch sequences ---------------------------------------------------------------------------------------------
+# The finetune step is ~2 000 small launches and the single host thread that enqueues all of its HIP streams is on the
+# critical path. A Seq is the list of C-ABI launches one fixed-shape piece of the step makes -- a dense block's
+# forward, a template encoder's backward -- recorded ONCE while the ordinary Python code runs (`with record(seq):` -- every
+# `fn(name)(...)` call is executed AND stored with its argument values, descriptors included) and replayed afterwards by a
+# loop that does nothing but call the same entry points with the same arguments and the current stream handles: no
+# descriptor building, no tensor allocation, no autograd bookkeeping per launch. Requirements, all the caller's: every
+# device address in the arguments is stable across steps (persistent buffers owned by the plan that owns the Seq; Seq.keep
+# holds them), and the recorded region contains NO torch kernels (they would run at record time only). Launches carry a
+# stream SLOT (0 = the stream current at replay, 1 = the weight-gradient side stream); "wait" entries order the slots.
+_REC = None
+# entry points that enqueue work (their last argument is the stream) and may appear in a sequence
+RECORDABLE = frozenset((
+    "ossid_conv_nhwc_fwd", "ossid_conv3x3_wino_fwd", "ossid_chan_op", "ossid_bn_fold_fwd", "ossid_bn_fold_bwd",
+    "ossid_colsum_finalize", "ossid_conv_wgrad", "ossid_conv_wgrad_group", "ossid_avgpool2_nhwc",
+    "ossid_upsample_nearest_bwd_nhwc", "ossid_maxpool_idx_nhwc", "ossid_maxpool_bwd_nhwc", "ossid_dw_add_nhwc",
+    "ossid_dw_bwd_k_nhwc", "ossid_im2col_stem", "ossid_conv_pack_weights", "ossid_conv_pack_weights_dgrad",
+    "ossid_conv_pack_weights_wino", "ossid_fill_zero", "ossid_resample_taps_nhwc",
+    "ossid_stem_weight_relayout"))
+# entry points that only compute sizes / return static data: called through, never stored
+_QUERIES = frozenset((
+    "ossid_conv_packed_floats", "ossid_conv_wino_packed_floats", "ossid_chan_op_partials", "ossid_conv_wgrad_workspace_bytes",
+    "ossid_conv_wgrad_group_workspace_bytes", "ossid_dw_bwd_k_workspace_floats", "ossid_conv_last_partial_rows",
+    "ossid_conv3x3_wgrad_splits", "ossid_abi_version"))
+
+
+class Seq:
+    """A recorded launch sequence (see above). ops: (callable, args without the stream, slot, name) or ("wait", waiter, signal)."""
+
+    def __init__(self):
+        self.ops, self.keep, self.uses_side = [], [], False
+
+    def __len__(self):
+        return len(self.ops)
+
+    def run(self, streams):
+        """streams: torch.cuda.Stream per slot (slot 0 first). Enqueues every recorded launch."""
+        raw = [st.cuda_stream for st in streams]
+        cnt = _MFMA_COUNT
+        for op in self.ops:
+            f = op[0]
+            if f == "wait":
+                streams[op[1]].wait_stream(streams[op[2]])
+                continue
+            rc = f(*op[1], raw[op[2]])
+            if rc:
+                raise RuntimeError("%s failed with status %d (replayed sequence)" % (op[3], rc))
+            if cnt is not None and op[3] in _MFMA_RULES:
+                cnt.flops += _MFMA_RULES[op[3]](op[1])
+                cnt.launches += 1
+
+
+class record:
+    """`with record(seq):` -- see Seq. Nested use is an error; `slot(k)` switches the stream slot of the launches inside."""
+
+    def __init__(self, seq):
+        self.seq, self.cur_slot = seq, 0
+
+    def __enter__(self):
+        global _REC
+        if _REC is not None:
+            raise RuntimeError("nested launch-sequence recording")
+        _REC = self
+        return self
+
+    def __exit__(self, *a):
+        global _REC
+        _REC = None
+        return False
+
+    def wrap(self, name, f, run_now):
+        """f: the raw entry point (stored); run_now: what executes it at record time (f, or f under bench's flop counter)."""
+        if name in _QUERIES:
+            return f
+        if name not in RECORDABLE:
+            raise RuntimeError("%s was called inside a recorded launch sequence but is not recordable" % name)
+
+        def call(*args):
+            self.seq.ops.append((f, args[:-1], self.cur_slot, name))
+            return run_now(*args)
+        return call
+
+    def wait(self, waiter, signal):
+        self.seq.ops.append(("wait", waiter, signal))
+
+    def keep(self, *tensors):
+        self.seq.keep.extend(t for t in tensors if t is not None)
+
+
+def recording():
+    return _REC
 
 
 # ---- executed matrix-core work, counted where the launches are issued ------------------------------------------------------

@@ -987,6 +987,40 @@ __global__ __launch_bounds__(256) void maxpool_bwd_nhwc_kernel(const float4* __r
     dx[i] = make_float4(s[0], s[1], s[2], s[3]);
 }
 
+// Separable linear resampling of a channels-last image by per-output-row / per-output-column TAP TABLES:
+//   out[b][oy][ox][c] (+)= sum_i sum_j wy[oy][i] * wx[ox][j] * x[b][iy[oy][i]][ix[ox][j]][c]
+// with T taps per output index (index -1 = unused). One kernel is bilinear resizing (T = 2: F.interpolate's neighbours and
+// weights), its adjoint (the transposed tables), cropping (T = 1, weight 1: the valid 3x3 convolutions of the template
+// encoders are padded convolutions whose interior is kept) and zero-padding back (the crop's adjoint).
+__global__ __launch_bounds__(256) void resample_taps_kernel(const float4* __restrict__ x, int Hin, int Win, int C4, int x_cs4,
+                                                            int Hout, int Wout, const int* __restrict__ ty_idx,
+                                                            const float* __restrict__ ty_w, const int* __restrict__ tx_idx,
+                                                            const float* __restrict__ tx_w, int T, size_t total,
+                                                            float4* __restrict__ out, int out_cs4, int out_coff4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int ox = (int)(r % Wout);
+    r /= Wout;
+    const int oy = (int)(r % Hout);
+    const int b = (int)(r / Hout);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < T; ++a) {
+        const int iy = ty_idx[oy * T + a];
+        if (iy < 0) continue;
+        const float wy = ty_w[oy * T + a];
+        for (int e = 0; e < T; ++e) {
+            const int ix = tx_idx[ox * T + e];
+            if (ix < 0) continue;
+            const float w = wy * tx_w[ox * T + e];
+            const float4 v = x[(((size_t)b * Hin + iy) * Win + ix) * x_cs4 + c4];
+            acc[0] += w * v.x, acc[1] += w * v.y, acc[2] += w * v.z, acc[3] += w * v.w;
+        }
+    }
+    out[(((size_t)b * Hout + oy) * Wout + ox) * out_cs4 + out_coff4 + c4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1013,6 +1047,22 @@ int ossid_dw_bwd_k_nhwc(const float* x, const float* g, int B, int H, int W, int
                        rows, workspace);
     const int n = B * C * 9;
     hipLaunchKernelGGL(dw_bwd_k_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)workspace, chunks, n, dk);
+    return ossid_launch_status();
+}
+
+int ossid_resample_taps_nhwc(const float* x, int B, int Hin, int Win, int C, int x_channel_stride, int Hout, int Wout,
+                             const int32_t* taps_y_idx, const float* taps_y_w, const int32_t* taps_x_idx, const float* taps_x_w,
+                             int T, float* out, int out_channel_stride, int out_channel_offset, void* stream) {
+    if (!x || !out || !taps_y_idx || !taps_y_w || !taps_x_idx || !taps_x_w) return OSSID_EINVAL;
+    if (B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C <= 0 || C % 4 || T <= 0 || T > 8) return OSSID_EINVAL;
+    const int xcs = x_channel_stride > 0 ? x_channel_stride : C, ocs = out_channel_stride > 0 ? out_channel_stride : C;
+    if (xcs % 4 || ocs % 4 || out_channel_offset % 4 || out_channel_offset < 0 || out_channel_offset + C > ocs || xcs < C)
+        return OSSID_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return OSSID_EINVAL;
+    const size_t total = (size_t)B * Hout * Wout * (C / 4);
+    hipLaunchKernelGGL(resample_taps_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x, Hin, Win, C / 4, xcs / 4, Hout, Wout, taps_y_idx, taps_y_w, taps_x_idx, taps_x_w, T, total,
+                       (float4*)out, ocs / 4, out_channel_offset / 4);
     return ossid_launch_status();
 }
 

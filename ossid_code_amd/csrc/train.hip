@@ -796,6 +796,28 @@ int launch_chan_op(const ChanOpArgs& a, int P, hipStream_t s) {
     return ossid_launch_status();
 }
 
+// [cout][cin][k][k] convolution weights <-> the [cout][kpad] matrix whose columns follow ossid_im2col_stem's order
+// ((ky * k + kx) * cin + c, zero-padded to kpad): the strided stems run as im2col + a 1x1 MFMA convolution.
+__global__ void stem_weight_relayout_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int k,
+                                            int kpad, int inverse) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int kk = k * k;
+    if (!inverse) {
+        if (i >= cout * kpad) return;
+        const int o = i / kpad, col = i % kpad;
+        float v = 0.f;
+        if (col < kk * cin) {
+            const int tap = col / cin, c = col % cin;
+            v = src[((size_t)o * cin + c) * kk + tap];
+        }
+        dst[i] = v;
+    } else {
+        if (i >= cout * cin * kk) return;
+        const int o = i / (cin * kk), r = i % (cin * kk), c = r / kk, tap = r % kk;
+        dst[i] = src[(size_t)o * kpad + tap * cin + c];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -810,6 +832,20 @@ int ossid_chan_op_partials(long long n_rows, int C) {
     if (P > maxP) P = maxP;
     if (P < 1) P = 1;
     return (int)P;
+}
+
+int ossid_stem_weight_relayout(const float* src, float* dst, int cout, int cin, int k, int kpad, int inverse, void* stream) {
+    if (!src || !dst || cout <= 0 || cin <= 0 || k <= 0 || kpad < k * k * cin) return OSSID_EINVAL;
+    const int n = inverse ? cout * cin * k * k : cout * kpad;
+    hipLaunchKernelGGL(stem_weight_relayout_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, cout, cin, k,
+                       kpad, inverse ? 1 : 0);
+    return ossid_launch_status();
+}
+
+int ossid_fill_zero(void* ptr, size_t bytes, void* stream) {
+    if (!ptr && bytes) return OSSID_EINVAL;
+    if (bytes == 0) return OSSID_OK;
+    return hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream) == hipSuccess ? OSSID_OK : OSSID_ELAUNCH;
 }
 
 int ossid_chan_op(const ossid_chan_op_desc* d, void* stream) {

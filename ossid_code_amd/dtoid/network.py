@@ -750,47 +750,13 @@ class Network(nn.Module):
 
     # finetune forward/backward on the hand-written kernels (train_ops.py); False = the nn.Module path (MIOpen)
     use_hip_training = os.environ.get("OSSID_TRAIN_IMPL", "hip") != "miopen"
-    # The 7x7 stem + norm0 + pool0 and the two SqueezeNet encoders ALSO have a training path on this repo's kernels
-    # (train_ops: im2col + 1x1 MFMA conv / wgrad, DwXcorrAdd, MaxPoolNHWC, bn_act_train; tested against the module path),
-    # but measured on one box (10 steps each, hipGraph replay) it is slower than torch / MIOpen on these few-channel,
-    # pass-dominated layers: 47.7 ms (both on torch) vs 48.3 (stem) / 48.0 (encoders) / 48.6 (both). Off by default.
+    # The two SqueezeNet template encoders train on this repo's kernels as one autograd node each, replaying recorded launch
+    # sequences (dtoid/train_encoders.py; round 3 -- round 2's form, ~25 autograd nodes per encoder, was 0.3-1.1 ms slower
+    # than torch / MIOpen because of its host cost). OSSID_TRAIN_TEMPLATES=0: the nn.Module path (MIOpen).
+    use_hip_template_training = os.environ.get("OSSID_TRAIN_TEMPLATES", "1") != "0"
+    # The 7x7 stem + norm0 + pool0 on this repo's kernels (im2col + 1x1 MFMA conv / wgrad, DwXcorrAdd, MaxPoolNHWC,
+    # bn_act_train; tested against the module path).
     use_hip_stem_training = os.environ.get("OSSID_TRAIN_STEM", "0") != "0"
-    use_hip_template_training = os.environ.get("OSSID_TRAIN_TEMPLATES", "0") != "0"
-
-    def _template_encoder_train_hip(self, mod, img):
-        """A SqueezeNet template encoder (TemplateFeatExtract / ...Global) in training mode on this repo's kernels,
-        channels-last: stem as im2col + 1x1 conv, Fire modules as FusedConv with ReLU epilogues, max-pools with argmax
-        indices, the training BatchNorms as column sums + fold + one generic pass, the valid 3x3 convs of the global
-        branch as padded convolutions whose interior is kept."""
-        from . import train_ops as T
-        stem = mod.backbone_0[0]
-        x = T.FusedConv.apply(ops.im2col_stem(img, 3, 2, 0, 48), T.relaid_stem_weight(stem, 48), stem.bias, None, None, False,
-                              2, None, False)
-
-        def run(part, x):
-            for m in part:
-                if isinstance(m, nn.MaxPool2d):
-                    x = T.MaxPoolNHWC.apply(x, m.kernel_size, m.stride, m.padding, m.ceil_mode)
-                elif isinstance(m, nn.ReLU):
-                    continue
-                else:
-                    sq = T.fused_conv(x, m.squeeze, act=2)
-                    x = torch.cat([T.fused_conv(sq, m.expand1x1, act=2), T.fused_conv(sq, m.expand3x3, act=2)], 1)
-            return x
-        x1 = run(mod.backbone_1, x)
-        x2 = run(mod.backbone_2, x1)
-        x1n, x2n = T.bn_act_train(x1, mod.norm_1), T.bn_act_train(x2, mod.norm_2)
-        xf = torch.cat([x2n, _bilinear_resize(x1n, x2.size(3))], dim=1)
-        if hasattr(mod, "final_conv_1"):
-            for conv, bn in ((mod.final_conv_1, mod.final_norm_1), (mod.final_conv_2, mod.final_norm_2)):
-                u = T.fused_conv(xf, conv, act=1)[:, :, 1:-1, 1:-1]          # valid 3x3 = interior of the padded conv
-                xf = T.bn_act_train(u, bn)
-        ts = mod.__dict__.get("_folded_bn_counters")
-        if ts is None:
-            ts = mod.__dict__["_folded_bn_counters"] = [b.num_batches_tracked for b in mod.modules()
-                                                        if isinstance(b, nn.BatchNorm2d)]
-        torch._foreach_add_(ts, 1)
-        return xf
 
     # Independent branches of the training step on side HIP streams (eager execution only -- under a graph capture the
     # branches run in line): the local template encoder beside the image backbone, the three correlation convolutions
@@ -898,6 +864,9 @@ class Network(nn.Module):
             [getattr(corr, "s%d" % i) for i in (1, 2, 3, 4, 5)]
         for mod in (self.classification, self.regression):
             convs += [getattr(mod, "conv%d" % i) for i in (1, 2, 3, 4)] + [mod.output]
+        if self.use_hip_template_training:
+            from .train_encoders import encoder_convs
+            convs += encoder_convs(self.template_feature_extractor_global) + encoder_convs(self.template_feature_extractor)
         plan = self.__dict__.get("_pack_plan")
         if plan is None or not plan.valid_for(convs):
             # which layouts the step asks for at finetune batch sizes (train_ops.wino_fits): the head's plain 3x3 layers run
@@ -987,25 +956,26 @@ class Network(nn.Module):
         classifications [B,A,2], regression [B,A,4], anchors [1,A,4], heat_map [B,1,hh,hw], segmentation [B,1,H,W]"""
         hip_train = image.is_cuda and self.training and torch.is_grad_enabled() and self.use_hip_training
         if hip_train and self.use_hip_template_training:
-            g = self._template_encoder_train_hip(self.template_feature_extractor_global,
-                                                 torch.cat([global_template, global_template_mask], dim=1))
-            local = self._template_encoder_train_hip(self.template_feature_extractor,
-                                                     torch.cat([template, template_mask], dim=1))
+            # each encoder = one autograd node replaying recorded launch sequences (dtoid/train_encoders.py)
+            from .train_encoders import template_encoder_train
+            enc_g = lambda: template_encoder_train(self.template_feature_extractor_global,                  # noqa: E731
+                                                   torch.cat([global_template, global_template_mask], dim=1))
+            enc_l = lambda: template_encoder_train(self.template_feature_extractor,                         # noqa: E731
+                                                   torch.cat([template, template_mask], dim=1))
         else:
-            if hip_train and self._branches_on(image.device):
-                # both encoders run on side streams, and WHEN the host enqueues them matters as much as where they run
-                # (each is ~100 small launches: 1-2 ms of host time, and autograd replays backward in reverse order of
-                # creation): the global one right behind the stem convolution that does not need it; the local one in the
-                # middle of the backbone, so that its backward is enqueued in the middle of the backbone's backward, while
-                # the host is ahead of the device, instead of as a host-bound tail behind everything else
-                lazy_g = lambda: self._fork(ENC_G_STREAM, [global_template, global_template_mask],          # noqa: E731
-                                            lambda: self.template_feature_extractor_global(
-                                                torch.cat([global_template, global_template_mask], dim=1)))
-                lazy_l = lambda: self._fork(ENC_L_STREAM, [template, template_mask],                        # noqa: E731
-                                            lambda: self.template_feature_extractor(torch.cat([template, template_mask], dim=1)))
-                return self._forward_train_hip(image, None, None, lazy_g=lazy_g, lazy_local=lazy_l)
-            g = self.template_feature_extractor_global(torch.cat([global_template, global_template_mask], dim=1))
-            local = self.template_feature_extractor(torch.cat([template, template_mask], dim=1))
+            enc_g = lambda: self.template_feature_extractor_global(                                         # noqa: E731
+                torch.cat([global_template, global_template_mask], dim=1))
+            enc_l = lambda: self.template_feature_extractor(torch.cat([template, template_mask], dim=1))    # noqa: E731
+        if hip_train and self._branches_on(image.device):
+            # both encoders run on side streams, and WHEN the host enqueues them matters as much as where they run
+            # (autograd replays backward in reverse order of creation): the global one right behind the stem convolution
+            # that does not need it; the local one in the middle of the backbone, so that its backward is enqueued in the
+            # middle of the backbone's backward, while the host is ahead of the device, instead of as a tail behind
+            # everything else
+            lazy_g = lambda: self._fork(ENC_G_STREAM, [global_template, global_template_mask], enc_g)       # noqa: E731
+            lazy_l = lambda: self._fork(ENC_L_STREAM, [template, template_mask], enc_l)                     # noqa: E731
+            return self._forward_train_hip(image, None, None, lazy_g=lazy_g, lazy_local=lazy_l)
+        g, local = enc_g(), enc_l()
         if hip_train:
             return self._forward_train_hip(image, g, local)
         if image.is_cuda and not self.training and not torch.is_grad_enabled() and self.use_fused_head:

@@ -119,14 +119,18 @@ def topk_scores(scores, k):
 _IMNORM = {}
 
 
-def im2col_stem(img, k, stride, pad, kpad, normalize=False):
+def im2col_stem(img, k, stride, pad, kpad, normalize=False, out=None):
     """ossid_im2col_stem: img [B,Cin,H,W] (NCHW) -> [B, kpad, Ho, Wo] logical tensor in channels_last memory (rows of
-    receptive fields, column (ky*k + kx)*Cin + ci), optionally with normalizeImageRange applied on the way."""
+    receptive fields, column (ky*k + kx)*Cin + ci), optionally with normalizeImageRange applied on the way. out: a
+    tensor of that shape and layout to write into (a persistent buffer of a recorded launch sequence)."""
     _lib.require_cuda(img)
     img = img.float().contiguous()
     B, Cin, H, W = img.shape
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    out = torch.empty((B, Ho, Wo, kpad), dtype=torch.float32, device=img.device).permute(0, 3, 1, 2)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, kpad), dtype=torch.float32, device=img.device).permute(0, 3, 1, 2)
+    elif tuple(out.shape) != (B, kpad, Ho, Wo) or not out.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError("im2col_stem: out must be a channels-last [B, kpad, Ho, Wo] tensor")
     mean = inv = None
     if normalize:
         key = str(img.device)
