@@ -311,6 +311,15 @@ typedef struct ossid_chan_op_desc {
  * coefficient table of a dense block's backward pass; replaces torch.zeros inside such a sequence). */
 int ossid_fill_zero(void* ptr, size_t bytes, void* stream);
 
+/* Segmentation term of DtoidNet.forward's loss and its metric (models/dtoid/__init__.py:210-232) in one pass:
+ *   prob = sigmoid(logit) [B][hw];  out[0] = BCELoss(prob, mask) (mean over B*hw, torch's clamps: log terms >= -100);
+ *   out[1 + b] = IoU of (prob > 0.5) vs (mask > 0) of image b (0 for an empty union: pl.metrics iou(ignore_index=0));
+ *   dlogit_sum [B][hw] = d(SUM of the BCE terms)/d(logit) -- the backward pass scales it by upstream / (B*hw).
+ * workspace >= ossid_seg_bce_iou_workspace_bytes(B), 8-byte aligned. Deterministic (fixed-order double sums). */
+size_t ossid_seg_bce_iou_workspace_bytes(int B);
+int ossid_seg_bce_iou_fwd(const float* logit, const float* mask, int B, long long hw, float* prob, float* dlogit_sum,
+                          float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Convolution weights [cout][cin][k][k] -> the [cout][kpad] matrix in ossid_im2col_stem's column order
  * ((ky * k + kx) * cin + c, zero-padded), or back (inverse = 1: a weight GRADIENT computed on the im2col columns returns to
  * the parameter's layout). The strided stems (7x7 / 2 of the image backbone, network.py:164-170; 3x3 / 2 of the template

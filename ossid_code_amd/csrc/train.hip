@@ -54,35 +54,47 @@ __global__ __launch_bounds__(256) void chan_op_kernel(const ChanOpArgs A) {
     const long long r0 = (long long)blockIdx.y * A.rows_per_block;
     const long long r1 = r0 + A.rows_per_block < A.n_rows ? r0 + A.rows_per_block : A.n_rows;
     if (valid) {
-        for (long long r = r0 + ty; r < r1; r += RY) {
-            const float4 gv = *(const float4*)(A.g + r * A.g_cs + c0);
-            const float4 xv = A.x ? *(const float4*)(A.x + r * A.x_cs + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float g[4] = {gv.x, gv.y, gv.z, gv.w}, x[4] = {xv.x, xv.y, xv.z, xv.w};
-            const float a4[4] = {al.x, al.y, al.z, al.w}, b4[4] = {be.x, be.y, be.z, be.w}, k4[4] = {ka.x, ka.y, ka.z, ka.w};
-            const float ms4[4] = {ms.x, ms.y, ms.z, ms.w}, mt4[4] = {mt.x, mt.y, mt.z, mt.w};
-            float res[4];
+        const float a4[4] = {al.x, al.y, al.z, al.w}, b4[4] = {be.x, be.y, be.z, be.w}, k4[4] = {ka.x, ka.y, ka.z, ka.w};
+        const float ms4[4] = {ms.x, ms.y, ms.z, ms.w}, mt4[4] = {mt.x, mt.y, mt.z, mt.w};
+        // U rows per trip with every load of the trip issued before the first use: most launches of the finetune step are a
+        // few MB (a dense layer at 30 x 40: 9 600 rows), i.e. a handful of rows per thread -- their time is the number of
+        // DEPENDENT memory round trips, not bandwidth
+        constexpr int U = 4;
+        for (long long rb = r0 + ty; rb < r1; rb += (long long)RY * U) {
+            float4 gv[U], xv[U], ov[U];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float m = 1.0f;
-                if (A.mask_mode == 1) m = (ms4[i] * x[i] + mt4[i] > 0.0f) ? 1.0f : 0.0f;
-                else if (A.mask_mode == 2) m = x[i] > 0.0f ? 1.0f : x[i] + 1.0f;
-                else if (A.mask_mode == 3) m = x[i] > 0.0f ? 1.0f : 0.0f;
-                const float gm = g[i] * m;
-                res[i] = (a4[i] * g[i] + b4[i] * x[i] + k4[i]) * m;
-                if (A.sum_mode == 1) s1[i] += gm, s2[i] += gm * x[i];
-                else if (A.sum_mode == 2) s1[i] += res[i], s2[i] += res[i] * x[i];
-                else if (A.sum_mode == 3) {      // statistics about a per-channel pivot: no E[x^2] - E[x]^2 cancellation
-                    const float dlt = g[i] - pv[i];
-                    s1[i] += dlt, s2[i] += dlt * dlt;
-                }
+            for (int u = 0; u < U; ++u) {
+                const long long r = rb + (long long)u * RY;
+                const bool live = r < r1;
+                gv[u] = live ? *(const float4*)(A.g + r * A.g_cs + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xv[u] = (live && A.x) ? *(const float4*)(A.x + r * A.x_cs + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ov[u] = (live && A.out && A.accumulate) ? *(const float4*)(A.out + r * A.out_cs + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (A.out) {
-                float* o = A.out + r * A.out_cs + c0;
-                if (A.accumulate) {
-                    const float4 ov = *(const float4*)o;
-                    res[0] += ov.x, res[1] += ov.y, res[2] += ov.z, res[3] += ov.w;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long r = rb + (long long)u * RY;
+                if (r >= r1) break;
+                const float g[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w}, x[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+                float res[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float m = 1.0f;
+                    if (A.mask_mode == 1) m = (ms4[i] * x[i] + mt4[i] > 0.0f) ? 1.0f : 0.0f;
+                    else if (A.mask_mode == 2) m = x[i] > 0.0f ? 1.0f : x[i] + 1.0f;
+                    else if (A.mask_mode == 3) m = x[i] > 0.0f ? 1.0f : 0.0f;
+                    const float gm = g[i] * m;
+                    res[i] = (a4[i] * g[i] + b4[i] * x[i] + k4[i]) * m;
+                    if (A.sum_mode == 1) s1[i] += gm, s2[i] += gm * x[i];
+                    else if (A.sum_mode == 2) s1[i] += res[i], s2[i] += res[i] * x[i];
+                    else if (A.sum_mode == 3) {      // statistics about a per-channel pivot: no E[x^2] - E[x]^2 cancellation
+                        const float dlt = g[i] - pv[i];
+                        s1[i] += dlt, s2[i] += dlt * dlt;
+                    }
                 }
-                *(float4*)o = make_float4(res[0], res[1], res[2], res[3]);
+                if (A.out) {
+                    if (A.accumulate) res[0] += ov[u].x, res[1] += ov[u].y, res[2] += ov[u].z, res[3] += ov[u].w;
+                    *(float4*)(A.out + r * A.out_cs + c0) = make_float4(res[0], res[1], res[2], res[3]);
+                }
             }
         }
     }
@@ -796,6 +808,63 @@ int launch_chan_op(const ChanOpArgs& a, int P, hipStream_t s) {
     return ossid_launch_status();
 }
 
+// Segmentation head of the loss (models/dtoid/__init__.py:210-232): p = sigmoid(logit), BCELoss(p, mask) with torch's
+// clamps (log terms >= -100; backward through input * (1 - input) clamped at 1e-12), and the foreground IoU of (p > 0.5)
+// against (mask > 0) per image -- one pass instead of ~20 elementwise / reduction launches. The un-normalised gradient
+// d(sum BCE)/d(logit) is stored in the forward pass; backward is a scale by (upstream gradient / N).
+__global__ __launch_bounds__(256) void seg_bce_iou_kernel(const float* __restrict__ logit, const float* __restrict__ mask, long long hw,
+                                                          int blocks_per_image, float* __restrict__ prob,
+                                                          float* __restrict__ dlogit, double* __restrict__ partials) {
+    const int b = blockIdx.y;
+    const long long per = (hw + blocks_per_image - 1) / blocks_per_image;
+    const long long i0 = (long long)blockIdx.x * per, i1 = i0 + per < hw ? i0 + per : hw;
+    const float* x = logit + (size_t)b * hw;
+    const float* y = mask + (size_t)b * hw;
+    double loss = 0.0;
+    float inter = 0.f, uni = 0.f;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float xv = x[i], yv = y[i];
+        const float p = 1.0f / (1.0f + expf(-xv));
+        const float lp = fmaxf(logf(p), -100.0f), l1p = fmaxf(log1pf(-p), -100.0f);
+        loss += (double)((yv - 1.0f) * l1p - yv * lp);
+        const float pq = p * (1.0f - p);
+        prob[(size_t)b * hw + i] = p;
+        dlogit[(size_t)b * hw + i] = (p - yv) / fmaxf(pq, 1e-12f) * pq;
+        const bool pr = p > 0.5f, gt = yv > 0.0f;
+        inter += (pr && gt) ? 1.f : 0.f;
+        uni += (pr || gt) ? 1.f : 0.f;
+    }
+    __shared__ double red[3][256];
+    red[0][threadIdx.x] = loss, red[1][threadIdx.x] = inter, red[2][threadIdx.x] = uni;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double* o = partials + ((size_t)b * blocks_per_image + blockIdx.x) * 3;
+        o[0] = red[0][0], o[1] = red[1][0], o[2] = red[2][0];
+    }
+}
+
+// out[0] = mean BCE over all B * hw elements, out[1 + b] = IoU of image b (0 when the union is empty)
+__global__ void seg_bce_iou_finalize_kernel(const double* __restrict__ partials, int B, int blocks_per_image, long long hw,
+                                            float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double total = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double l = 0.0, in = 0.0, un = 0.0;
+        for (int k = 0; k < blocks_per_image; ++k) {
+            const double* o = partials + ((size_t)b * blocks_per_image + k) * 3;
+            l += o[0], in += o[1], un += o[2];
+        }
+        total += l;
+        out[1 + b] = un > 0.0 ? (float)(in / un) : 0.0f;
+    }
+    out[0] = (float)(total / ((double)B * (double)hw));
+}
+
 // [cout][cin][k][k] convolution weights <-> the [cout][kpad] matrix whose columns follow ossid_im2col_stem's order
 // ((ky * k + kx) * cin + c, zero-padded to kpad): the strided stems run as im2col + a 1x1 MFMA convolution.
 __global__ void stem_weight_relayout_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int k,
@@ -832,6 +901,19 @@ int ossid_chan_op_partials(long long n_rows, int C) {
     if (P > maxP) P = maxP;
     if (P < 1) P = 1;
     return (int)P;
+}
+
+size_t ossid_seg_bce_iou_workspace_bytes(int B) { return (size_t)(B > 0 ? B : 1) * 64 * 3 * sizeof(double); }
+
+int ossid_seg_bce_iou_fwd(const float* logit, const float* mask, int B, long long hw, float* prob, float* dlogit_sum,
+                          float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!logit || !mask || !prob || !dlogit_sum || !out || !workspace || B <= 0 || B > 65535 || hw <= 0) return OSSID_EINVAL;
+    if (workspace_bytes < ossid_seg_bce_iou_workspace_bytes(B) || ((uintptr_t)workspace & 7)) return OSSID_EINVAL;
+    const int bpi = 64;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(seg_bce_iou_kernel, dim3(bpi, B), dim3(256), 0, s, logit, mask, hw, bpi, prob, dlogit_sum, (double*)workspace);
+    hipLaunchKernelGGL(seg_bce_iou_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, B, bpi, hw, out);
+    return ossid_launch_status();
 }
 
 int ossid_stem_weight_relayout(const float* src, float* dst, int cout, int cin, int k, int kpad, int inverse, void* stream) {

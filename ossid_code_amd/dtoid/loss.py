@@ -112,3 +112,37 @@ class DetectionLoss(nn.Module):
         reg = torch.where(positive[:, :, None], sl1, torch.zeros_like(sl1)).sum((1, 2))
         reg = reg / (4.0 * npos.float()).clamp(min=1.0)                      # mean over the positives' 4 coordinates
         return cls.mean(0, keepdim=True), reg.mean(0, keepdim=True)
+
+
+class SegBceIou(torch.autograd.Function):
+    """(sigmoid(logit), BCELoss(sigmoid(logit), mask), per-image foreground IoU) in one pass on the GPU
+    (ossid_seg_bce_iou_fwd; reference: models/dtoid/__init__.py:210 `torch.sigmoid`, :216 `seg_loss_func`, :228-232 the
+    IoU metric) instead of ~20 elementwise / reduction launches. Only the loss is differentiable; the probability map is
+    returned detached, as the reference only feeds it to the loss and to metrics."""
+
+    @staticmethod
+    def forward(ctx, logit, mask):
+        from .. import _lib
+        _lib.require_cuda(logit, mask)
+        x = logit.float().contiguous()
+        y = mask.to(x.device).float().contiguous()
+        B = x.shape[0]
+        hw = x.numel() // B
+        prob, dsum = torch.empty_like(x), torch.empty_like(x)
+        out = torch.empty(1 + B, dtype=torch.float32, device=x.device)
+        nbytes = _lib.fn("ossid_seg_bce_iou_workspace_bytes")(B)
+        ws = torch.empty(nbytes // 8, dtype=torch.float64, device=x.device)
+        with _lib.on_device(x.device):
+            _lib.check(_lib.fn("ossid_seg_bce_iou_fwd")(x.data_ptr(), y.data_ptr(), B, hw, prob.data_ptr(), dsum.data_ptr(),
+                                                        out.data_ptr(), ws.data_ptr(), nbytes, _lib.stream()),
+                       "ossid_seg_bce_iou_fwd")
+        ctx.save_for_backward(dsum)
+        ctx.n = x.numel()
+        iou = out[1:]
+        ctx.mark_non_differentiable(prob, iou)
+        return prob, out[0], iou
+
+    @staticmethod
+    def backward(ctx, _gprob, gloss, _giou):
+        (dsum,) = ctx.saved_tensors
+        return dsum * (gloss / ctx.n), None

@@ -171,22 +171,32 @@ class DtoidNet(nn.Module):
         cls, reg, anchors, heat_map, seg_logit = self.model(
             image_n, normalizeImageRange(template), template_mask, normalizeImageRange(global_template),
             global_template_mask)
-        segmentation = torch.sigmoid(seg_logit)
-        boxes = self.clipBoxes(self.regressBoxes(anchors, reg), image_n)
+        fused_tail = seg_logit.is_cuda and "heatmap" in input
+        if fused_tail:
+            # sigmoid + BCE + per-image IoU in one pass (loss.SegBceIou); the clipped boxes -- an output for metrics / NMS, not
+            # part of any loss (reference :206-208) -- by the decode kernel of the test-time path instead of ~15 torch ops
+            from .loss import SegBceIou
+            segmentation, loss_seg, iou = SegBceIou.apply(seg_logit, input["mask"])
+            boxes = ops.decode_clip_boxes(anchors, reg, image_n.shape[3], image_n.shape[2])
+        else:
+            segmentation = torch.sigmoid(seg_logit)
+            boxes = self.clipBoxes(self.regressBoxes(anchors, reg), image_n)
         out = {"classifications": cls, "regressions": reg, "anchors": anchors, "heat_map": heat_map,
                "segmentation": segmentation, "transformed_anchors": boxes}
         if "heatmap" in input:
             dev = cls.device
             loss_cls, loss_reg = self.det_loss_func(cls, reg, anchors, input["bbox_gt"].to(dev))
             loss_center = self.center_loss_func(input["heatmap"].to(dev), heat_map)   # float64 target promotes (:214)
-            loss_seg = self.seg_loss_func(segmentation, input["mask"].to(dev))
+            if not fused_tail:
+                loss_seg = self.seg_loss_func(segmentation, input["mask"].to(dev))
             out["loss_seg"] = self.cfg.lam_seg * loss_seg
             out["loss_center"] = self.cfg.lam_center * loss_center
             out["loss_cls"] = self.cfg.lam_cls * loss_cls
             out["loss_reg"] = self.cfg.lam_reg * loss_reg
             out["loss"] = out["loss_seg"] + out["loss_center"] + out["loss_cls"] + out["loss_reg"]
             with torch.no_grad():
-                iou = binary_iou(segmentation.detach()[:, 0] > 0.5, input["mask"].to(dev)[:, 0] > 0)
+                if not fused_tail:
+                    iou = binary_iou(segmentation.detach()[:, 0] > 0.5, input["mask"].to(dev)[:, 0] > 0)
                 out["seg_IoU"] = iou.mean()
                 out["seg_IoU_50"] = (iou > 0.5).float().mean()
                 if getattr(self, "compute_train_nms", False):   # metrics-only pass (:235); off the finetune hot path

@@ -166,3 +166,33 @@ def test_weight_gradients_when_parameters_already_hold_a_gradient(hiplib, monkey
     d = _rel(got[2], got[0])
     assert d <= max(4 * noise, 1e-6), (d, noise)
     assert float(got[2].abs().max()) > 0
+
+
+def test_fused_segmentation_loss_and_iou_match_torch(hiplib):
+    """loss.SegBceIou (ossid_seg_bce_iou_fwd) vs the reference's three steps -- torch.sigmoid, nn.BCELoss, the foreground
+    IoU of (p > 0.5) against (mask > 0) per image (models/dtoid/__init__.py:210-232) -- incl. saturated logits, where
+    torch clamps the log terms at -100 and the BCE backward's denominator at 1e-12, an all-background image (empty union
+    -> IoU 0) and the gradient w.r.t. the logits."""
+    from ossid_code_amd.dtoid.loss import SegBceIou
+    from ossid_code_amd.dtoid.model import binary_iou
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 4, 96, 130
+    logit = (torch.randn(B, 1, H, W, generator=g) * 3).cuda()
+    logit[0, 0, :4] = 200.0
+    logit[0, 0, 4:8] = -200.0
+    logit[3] = -5.0                                               # nothing predicted ...
+    mask = (torch.rand(B, 1, H, W, generator=g) > 0.6).float().cuda()
+    mask[3] = 0                                                   # ... and nothing there: empty union
+    x_ref = logit.clone().requires_grad_(True)
+    p_ref = torch.sigmoid(x_ref)
+    loss_ref = torch.nn.BCELoss()(p_ref, mask)
+    (20 * loss_ref).backward()
+    iou_ref = binary_iou(p_ref.detach()[:, 0] > 0.5, mask[:, 0] > 0)
+    x = logit.clone().requires_grad_(True)
+    p, loss, iou = SegBceIou.apply(x, mask)
+    (20 * loss).backward()
+    assert p.shape == p_ref.shape and not p.requires_grad
+    assert torch.allclose(p, p_ref.detach(), rtol=1e-6, atol=1e-7)
+    assert abs(float(loss) - float(loss_ref)) <= 2e-6 * abs(float(loss_ref))
+    assert torch.allclose(iou, iou_ref, rtol=0, atol=1e-6) and float(iou[3]) == 0.0
+    assert torch.allclose(x.grad, x_ref.grad, rtol=1e-5, atol=1e-12)
