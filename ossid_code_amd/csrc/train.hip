@@ -166,12 +166,12 @@ __device__ __forceinline__ void column_sums(const float* sums, int row_stride, c
         const int per = (P + PARTS - 1) / PARTS, p0 = part * per, p1 = min(P, p0 + per);
         const float* src = partials + c;
         int p = p0;
-        for (; p + 4 <= p1; p += 4) {
-            float a[4], b[4];
+        for (; p + 8 <= p1; p += 8) {
+            float a[8], b[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] = src[(size_t)(p + k) * 2 * C], b[k] = src[(size_t)(p + k) * 2 * C + C];
+            for (int k = 0; k < 8; ++k) a[k] = src[(size_t)(p + k) * 2 * C], b[k] = src[(size_t)(p + k) * 2 * C + C];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s0 += (double)a[k], s1 += (double)b[k];
+            for (int k = 0; k < 8; ++k) s0 += (double)a[k], s1 += (double)b[k];
         }
         for (; p < p1; ++p) s0 += (double)src[(size_t)p * 2 * C], s1 += (double)src[(size_t)p * 2 * C + C];
     }
@@ -896,7 +896,7 @@ int ossid_chan_op_partials(long long n_rows, int C) {
     const int QX = C4 <= 8 ? 8 : C4 <= 16 ? 16 : C4 <= 32 ? 32 : 64;
     const int gx = (C4 + QX - 1) / QX, RY = 256 / QX;
     long P = (1024 + gx - 1) / gx;
-    if (P > 256) P = 256;
+    if (P > 512) P = 512;          // (partials are combined by 8-16 threads per channel in the fold / finalize kernels)
     const long maxP = (long)((n_rows + 4 * RY - 1) / (4 * RY));          // at least 4 rows per thread
     if (P > maxP) P = maxP;
     if (P < 1) P = 1;

@@ -2,7 +2,7 @@
 # Collects the evidence files of a round on the GPU box into gpurun_out/<tag>/ (copied to profiles/ afterwards):
 #   tools/collect_round_evidence.sh r02
 set -e
-T=${1:-r02}
+T=${1:-r03}
 O=gpurun_out/$T/ev
 mkdir -p $O
 R=$PWD

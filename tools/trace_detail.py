@@ -19,7 +19,8 @@ def main():
     with open(a.csv) as f:
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
-                         int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0), int(r.get("Workgroup_Size_X", 256) or 256),
+                         int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) * max(1, int(r.get("Grid_Size_Y", 1) or 1)) *
+                         max(1, int(r.get("Grid_Size_Z", 1) or 1)), int(r.get("Workgroup_Size_X", 256) or 256),
                          int(r.get("LDS_Block_Size", 0) or 0)))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if a.marker in r[2].lower()]
