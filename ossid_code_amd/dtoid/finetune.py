@@ -47,6 +47,7 @@ class FlatParams:
         self.grad = torch.zeros(self.total, dtype=dt, device=dev)
         off = 0
         self.offsets = {}
+        self._views = []
         for i, (name, p) in enumerate(self.entries):
             if i == len(used):
                 off = self.n_used
@@ -54,9 +55,17 @@ class FlatParams:
             view = self.param[off:off + n].view_as(p)
             view.copy_(p.data)
             p.data = view
-            p.grad = self.grad[off:off + n].view_as(p)
+            gview = self.grad[off:off + n].view_as(p)
+            p.grad = gview
+            self._views.append(gview)
             self.offsets[name] = (off, n)
             off += n
+        # weight-gradient kernels of the hand-written training path write straight into these views when they can
+        # (train_ops.grad_home): the per-step gather then has nothing to copy for the 34 M convolution weights
+        if self.param.is_cuda:
+            from . import train_ops
+            for (_, p), v in zip(self.entries[:len(used)], self._views):
+                train_ops.register_grad_home(p, v)
 
     def zero_grad(self):
         self.grad.zero_()
@@ -70,18 +79,22 @@ class FlatParams:
             p.grad = None
 
     def gather_grads(self):
-        if not hasattr(self, "_views"):
-            self._views = [self.grad[off:off + n].view_as(p) for (name, p), (off, n) in
-                           zip(self.entries, (self.offsets[name] for name, _ in self.entries))]
-        dst, src, missing = [], [], False
-        for (_, p), v in zip(self.entries, self._views):
-            if p.grad is None:
-                missing = True
-            else:
+        """After backward with p.grad = None: every gradient into its slice of the flat buffer (multi-tensor copies; nothing
+        to do for a gradient a kernel already wrote in place, train_ops.grad_home), zeros for a USED parameter that got
+        none this step (rare: an unused branch), then p.grad = the flat views again. The never-used parameters in the
+        buffer's tail are left alone: the optimizer does not read them."""
+        dst, src, zero = [], [], []
+        n_used_entries = sum(1 for name, _ in self.entries if self.offsets[name][0] < self.n_used)
+        for i, ((_, p), v) in enumerate(zip(self.entries, self._views)):
+            g = p.grad
+            if g is None:
+                if i < n_used_entries:
+                    zero.append(v)
+            elif g.data_ptr() != v.data_ptr():
                 dst.append(v)
-                src.append(p.grad)
-        if missing:
-            self.grad.zero_()          # a parameter without a gradient this step contributes zero (rare: unused branches)
+                src.append(g)
+        if zero:
+            torch._foreach_zero_(zero)
         if dst:
             torch._foreach_copy_(dst, src)
         for (_, p), v in zip(self.entries, self._views):

@@ -775,6 +775,9 @@ class Network(nn.Module):
         from . import train_ops
         side = train_ops.side_streams(dev)["b%d" % (k & 1)]     # two branch slots (train_ops.side_streams: probed once)
         side.wait_stream(torch.cuda.current_stream(dev))
+        ev = self.__dict__.get("_pack_event")
+        if ev is not None:                                       # this step's packed weights (packed beside the stem, below)
+            side.wait_event(ev)
         for t in inputs:
             t.record_stream(side)
         with torch.cuda.stream(side):
@@ -795,7 +798,21 @@ class Network(nn.Module):
         from . import train_ops as T
         from .backbones import DenseBlock, Transition
         ife = self.image_feature_extractor
-        self._train_pack_plan().run()                            # every conv weight -> MFMA layouts, one launch
+        # every conv weight -> MFMA layouts, one launch (0.64 ms: 136 MB read, 272 MB written). Nothing needs it before the
+        # first dense block and the template encoders, so with side streams on it runs on the weight-gradient stream (idle
+        # at the start of a step: the previous step's weight gradients were joined before its optimizer ran) beside the stem
+        pack_event = None
+        if self._branches_on(image.device):
+            main = torch.cuda.current_stream(image.device)
+            ps = T.side_streams(image.device)["wgrad"]
+            ps.wait_stream(main)                                 # behind the optimizer step that wrote the weights
+            with torch.cuda.stream(ps):
+                self._train_pack_plan().run()
+            pack_event = torch.cuda.Event()
+            pack_event.record(ps)
+        else:
+            self._train_pack_plan().run()
+        self.__dict__["_pack_event"] = pack_event
         seq = list(ife.backdense_1) + list(ife.backdense_2)      # norm0 relu0 pool0 block1 | trans1 block2 ... norm5
         if self.use_hip_stem_training:
             # stem on this repo's kernels, channels-last from the first one: im2col -> 1x1 MFMA conv (weight gradient
@@ -817,6 +834,8 @@ class Network(nn.Module):
             for m in seq[:3]:                                    # stem: 64 channels at 240x320, on torch
                 x = m(x)
             x = T.nhwc(x)
+        if pack_event is not None:
+            torch.cuda.current_stream(image.device).wait_event(pack_event)
         norm5 = None
         join_local, n_blocks = None, 0
         for m in seq[3:]:

@@ -228,7 +228,7 @@ def _encoder_forward(mod, cols):
     return out, sv
 
 
-def _encoder_backward(mod, gout, sv, side):
+def _encoder_backward(mod, gout, sv, side, direct=False):
     """Backward launches of one encoder given gout = dL/d(output) in a persistent buffer (raw ops only).
     Returns the parameter gradients in encoder_params order."""
     dev = gout.device
@@ -241,7 +241,7 @@ def _encoder_backward(mod, gout, sv, side):
     deferred, grads = [], {}
 
     def wgrad_later(conv, x, dy, Bh, Hh, Wh, cin, cout, taps, pre=None, in_cs=0, dy_cs=0, key=None):
-        dw = new_buf((cout, cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1), dev)
+        dw = T.grad_home(conv.weight, direct) if conv is not None else new_buf((cout, cin, 1, 1), dev)
         deferred.append(dict(x=x, dy=dy, B=Bh, H=Hh, W=Wh, cin=cin, cout=cout, taps=taps, dw=dw, pre=pre, pre_relu=False,
                              in_cs=in_cs, dy_cs=dy_cs))
         grads[key if key is not None else conv.weight] = dw
@@ -322,7 +322,7 @@ def _encoder_backward(mod, gout, sv, side):
     sums = chan_op(flat(g), B * H0 * W0, 64, x=flat(x0), out=flat(g), mask_mode=3, sum_mode=2)
     grads[stem.bias] = sums[0]
     dw_cols = wgrad_later(None, cols, g, B, H0, W0, STEM_KPAD, 64, 1, key="stem")
-    dw_stem = new_buf(stem.weight.shape, dev)
+    dw_stem = T.grad_home(stem.weight, direct)
     touched = [it["dw"] for it in deferred] + [dw_stem]
 
     def weight_gradients():            # one grouped launch, then the stem's from im2col column order back to [64, 4, 3, 3]
@@ -373,6 +373,7 @@ class TemplateEncoderTrain(torch.autograd.Function):
         dev = gout.device
         weights = [p for p in params if p.dim() == 4]
         side = T._wgrad_side_ok(dev, weights)
+        direct = all(w.grad is None for w in weights)
         if plan is not None and ctx.gen != plan.gen:
             raise RuntimeError("TemplateEncoderTrain: this encoder ran another training forward since the one being "
                                "differentiated; its persistent buffers hold the later pass")
@@ -380,16 +381,16 @@ class TemplateEncoderTrain(torch.autograd.Function):
             plan = None
         if plan is None:
             g = gout.float().clone(memory_format=torch.channels_last)
-            grads = _encoder_backward(mod, g, sv, side)
+            grads = _encoder_backward(mod, g, sv, side, direct)
         else:
             if "gout" not in plan.t:
                 plan.t["gout"] = torch.empty_like(gout, dtype=torch.float32, memory_format=torch.channels_last)
             plan.t["gout"].copy_(gout)
-            if plan.bwd is None or plan.side != side:
+            if plan.bwd is None or plan.side != (side, direct):
                 seq = _lib.Seq()
                 with _lib.record(seq):
-                    plan.t["grads"] = _encoder_backward(mod, plan.t["gout"], sv, side)
-                plan.bwd, plan.side = seq, side
+                    plan.t["grads"] = _encoder_backward(mod, plan.t["gout"], sv, side, direct)
+                plan.bwd, plan.side = seq, (side, direct)
             else:
                 T._run_seq(plan.bwd, dev)
             grads = plan.t["grads"]

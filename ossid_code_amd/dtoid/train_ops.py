@@ -63,6 +63,30 @@ def _scratch(name, nbytes, device):
     return t
 
 
+# Where a parameter's gradient finally lives (finetune.FlatParams' slice of the flat gradient buffer), by the parameter's
+# address. A weight-gradient kernel may write there directly -- saving the per-step copy of the 34 M convolution weights'
+# gradients into the flat buffer -- exactly when autograd will TAKE the returned tensor as p.grad without reading it, i.e.
+# while p.grad is None (the finetune_step protocol); with a gradient already in place (`p.grad += dw` on the very same
+# memory) it must not. Weak values: the views die with their FlatParams.
+import weakref                                                        # noqa: E402
+
+_GRAD_HOME = weakref.WeakValueDictionary()
+
+
+def register_grad_home(param, view):
+    _GRAD_HOME[(param.data_ptr(), tuple(param.shape))] = view
+
+
+def grad_home(w, direct):
+    """The tensor a weight-gradient kernel for parameter `w` should write: w's slice of the flat gradient buffer when
+    `direct` (the caller established that w.grad is None, see above) and one is registered, else a fresh buffer."""
+    if direct:
+        v = _GRAD_HOME.get((w.data_ptr(), tuple(w.shape)))
+        if v is not None and v.device == w.device:
+            return v
+    return new_buf(w.shape, w.device)
+
+
 def new_buf(shape, device, zero=False, channels_last=False):
     """A float32 work buffer of the raw ops. Inside a recorded launch sequence (_lib.record) the sequence keeps it alive --
     its address is baked into the recorded arguments -- and `zero` becomes a recorded ossid_fill_zero, so that every
@@ -574,10 +598,11 @@ class FusedConv(torch.autograd.Function):
         # 2. weight gradient on the (prologue'd, up-sampled) input
         dw = None
         if need[1]:
-            dw = torch.empty_like(w)
-            _wgrad_async([x, dv, ps, pt, dw], lambda: wgrad_raw(x, dv, B, H, W, Cin, Cout, taps, dw, pre=pre, pre_relu=pre_relu,
-                                                                src_hw=(Hs, Ws) if (H, W) != (Hs, Ws) else (0, 0)), dev,
+            dwb = grad_home(w, w.grad is None)            # straight into the flat gradient buffer when autograd will take it over
+            _wgrad_async([x, dv, ps, pt, dwb], lambda: wgrad_raw(x, dv, B, H, W, Cin, Cout, taps, dwb, pre=pre, pre_relu=pre_relu,
+                                                                 src_hw=(Hs, Ws) if (H, W) != (Hs, Ws) else (0, 0)), dev,
                          weights=(w,))
+            dw = _alias(dwb)
         # 3. data gradient
         dx = dps = dpt = None
         if need[0] or (pre is not None and (need[3] or need[4])):
@@ -702,7 +727,7 @@ def _dense_forward(buf, table, block, params, C0):
     return saved
 
 
-def _dense_backward(G, buf, saved, block, params, C0, side):
+def _dense_backward(G, buf, saved, block, params, C0, side, direct=False):
     """The backward launches of a dense block whose output gradient already sits in G (ours to accumulate into); raw ops
     only. Returns (dx [B,C0,H,W] compact, parameter gradients in `params` order). side: the block's grouped weight-gradient
     launch goes to the weight-gradient stream (decided by the caller: _wgrad_side_ok)."""
@@ -728,7 +753,7 @@ def _dense_backward(G, buf, saved, block, params, C0, side):
                 kappa=coef[1, c:c + growth])
         # 3x3: weight gradient on relu(bn2(y1)) (deferred: this slice of G is final from here on), data gradient
         # to the bottleneck (reads the strided slice: in_cs = Ct)
-        dw2 = new_buf(w2.shape, dev)
+        dw2 = grad_home(w2, direct)
         deferred.append(dict(x=y1, dy=gs, B=B, H=H, W=W, cin=mid, cout=growth, taps=9, dw=dw2, pre=(f2[0], f2[1]),
                              pre_relu=True, dy_cs=Ct))
         wino = wino_fits(B, H, W, growth, mid, 9)
@@ -740,7 +765,7 @@ def _dense_backward(G, buf, saved, block, params, C0, side):
         bn_fold_bwd(None, None, g2, f2[2], f2[3], mid, N, r2[0], r2[1], r2[2], r2[3], partials=s)
         chan_op(db, N, mid, x=y1, out=db, beta=r2[2], kappa=r2[3])          # dz = scale*db*mask + coef_x*y1 + coef_1
         # 1x1: weight gradient on relu(bn1(buf[:, :c])) (deferred), data gradient to the c input channels
-        dw1 = new_buf(w1.shape, dev)
+        dw1 = grad_home(w1, direct)
         deferred.append(dict(x=buf, dy=db, B=B, H=H, W=W, cin=c, cout=mid, taps=1, dw=dw1, pre=(f1[0], f1[1]),
                              pre_relu=True, in_cs=Ct))
         # ... then one pass that masks with relu(bn1(buf)), scales, ACCUMULATES onto the gradient buffer's channel prefix
@@ -836,6 +861,7 @@ class DenseBlockTrain(torch.autograd.Function):
         dev = buf.device
         weights = [params[6 * li + k] for li in range(block.nlayers) for k in (2, 5)]
         side = _wgrad_side_ok(dev, weights)
+        direct = all(w.grad is None for w in weights)              # (the plan's `side` slot holds the pair)
         if plan is not None and ctx.gen != plan.gen:
             raise RuntimeError("DenseBlockTrain: this block ran another training forward since the one being differentiated; "
                                "its persistent buffers hold the later pass (run backward before the next forward, or set "
@@ -844,18 +870,18 @@ class DenseBlockTrain(torch.autograd.Function):
             plan = None                                                    # (forward outside, backward inside a capture)
         if plan is None:
             G = gbuf.float().clone(memory_format=torch.channels_last)      # ours to accumulate into
-            dx, grads = _dense_backward(G, buf, saved, block, params, C0, side)
+            dx, grads = _dense_backward(G, buf, saved, block, params, C0, side, direct)
             ctx.saved = None
-            return (dx, None) + tuple(grads)
+            return (dx, None) + tuple(_alias(g) if g is not None else None for g in grads)
         if "G" not in plan.t:
             plan.t["G"] = empty_nhwc(B, Ct, H, W, dev)
         G = plan.t["G"]
         G.copy_(gbuf)
-        if plan.bwd is None or plan.side != side:
+        if plan.bwd is None or plan.side != (side, direct):
             seq = _lib.Seq()
             with _lib.record(seq):
-                plan.t["dx"], plan.t["grads"] = _dense_backward(G, buf, saved, block, params, C0, side)
-            plan.bwd, plan.side = seq, side
+                plan.t["dx"], plan.t["grads"] = _dense_backward(G, buf, saved, block, params, C0, side, direct)
+            plan.bwd, plan.side = seq, (side, direct)
         else:
             _run_seq(plan.bwd, dev)
         ctx.saved = None
