@@ -214,6 +214,13 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* desc_host, void* stream);
 size_t ossid_conv_wino_packed_floats(int Cout, int Cin);
 int ossid_conv_pack_weights_wino(const float* w, int Cout, int Cin, int dgrad, float* wpk, void* stream);
 int ossid_conv3x3_wino_fwd(const ossid_conv_desc* desc_host, void* stream);
+/* Scratch the Winograd launch wants for cutting the TAIL of its grid along the reduction (csrc/wino.hip: the last, partial
+ * round of resident workgroups runs as ks slices per workgroup + a finishing launch; 1 576 workgroups on 512 slots cost
+ * ~3.3 rounds instead of 4). 0 = no split planned for this shape. Pass the buffer in desc->epi_partials and its size in
+ * BYTES in desc->epi_partials_rows (for the pair entry: in the first descriptor); without it the launch runs whole
+ * workgroups. Results are bit-reproducible either way (fixed summation order), but differ in rounding between the two forms. */
+size_t ossid_conv3x3_wino_workspace_bytes(const ossid_conv_desc* desc);
+size_t ossid_conv3x3_wino_pair_workspace_bytes(const ossid_conv_desc* d0, const ossid_conv_desc* d1);
 /* two independent layers (the i-th convolutions of the classification and the regression trunk, network.py:113-121 /
  * :146-154) in ONE grid: their workgroups fill the chip's slots together instead of each launch ending in a ragged round */
 int ossid_conv3x3_wino_fwd_pair(const ossid_conv_desc* desc0_host, const ossid_conv_desc* desc1_host, void* stream);

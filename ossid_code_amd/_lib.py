@@ -97,6 +97,8 @@ _PROTOS = {
     "ossid_conv_wino_packed_floats": (C.c_size_t, [_i, _i]),
     "ossid_conv_pack_weights_wino": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ossid_conv3x3_wino_fwd": (_i, [_vp, _vp]),
+    "ossid_conv3x3_wino_workspace_bytes": (_sz, [_vp]),
+    "ossid_conv3x3_wino_pair_workspace_bytes": (_sz, [_vp, _vp]),
     "ossid_conv3x3_wino_fwd_pair": (_i, [_vp, _vp, _vp]),
     "ossid_fill_zero": (_i, [_vp, _sz, _vp]),
     "ossid_seg_bce_iou_workspace_bytes": (_sz, [_i]),
@@ -191,7 +193,8 @@ RECORDABLE = frozenset((
 _QUERIES = frozenset((
     "ossid_conv_packed_floats", "ossid_conv_wino_packed_floats", "ossid_chan_op_partials", "ossid_conv_wgrad_workspace_bytes",
     "ossid_conv_wgrad_group_workspace_bytes", "ossid_dw_bwd_k_workspace_floats", "ossid_conv_last_partial_rows",
-    "ossid_conv3x3_wgrad_splits", "ossid_abi_version"))
+    "ossid_conv3x3_wgrad_splits", "ossid_abi_version", "ossid_conv3x3_wino_workspace_bytes",
+    "ossid_conv3x3_wino_pair_workspace_bytes"))
 
 
 class Seq:

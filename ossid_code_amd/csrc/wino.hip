@@ -55,7 +55,90 @@ struct WinoArgs {
 
 constexpr int KCH = 16, F4 = 4, VBUF = 16 * 32 * F4;      // float4 per LDS buffer
 
-__device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int block) {
+// `block` is the VIRTUAL block id of the launch geometry below. slice / ks / partial: the tail of the grid (its last,
+// partial round of resident workgroups) is cut along the reduction -- workgroup (block, slice) walks channel chunks
+// [slice * n / ks, (slice + 1) * n / ks) and stores its share of the OUTPUT-TRANSFORMED sums raw to `partial`; a finishing
+// launch adds the ks shares in a fixed order and runs the epilogue (wino_finish_kernel). ks = 1, partial = nullptr: the
+// whole reduction and the epilogue here.
+struct WinoTail {
+    int lcut, ks;          // virtual blocks [0, lcut) run whole; block lcut + t / ks, slice t % ks for t = blockIdx - lcut
+    float* partial;        // [tail blocks][ks][4 waves][2][16][64] floats
+};
+constexpr int WINO_PARTIAL_FLOATS = 4 * 2 * 16 * 64;
+
+__device__ __forceinline__ bool wino_block_map(const WinoArgs& A, const int L, int& bx, int& by) {
+    const int P = A.gx;
+    int pt;
+#ifdef OSSID_WINO_MAP_TILES      // A/B: an XCD owns tile groups (all channel groups of each) instead of one channel group
+    if (true) {
+        const int xcd = L & 7, idx = L >> 3;
+        by = idx % A.gy;
+        pt = (idx / A.gy) * 8 + xcd;
+    } else
+#endif
+    if (A.gy <= 8 && (8 % A.gy) == 0) {
+        const int k = L & 7, R = 8 / A.gy, per = (P + R - 1) / R;
+        by = k % A.gy;
+        pt = (L >> 3) < per ? (k / A.gy) * per + (L >> 3) : P;
+    } else if ((A.gy & 7) == 0) {
+        const int j = L >> 3;
+        by = (L & 7) + 8 * (j / P);
+        pt = j % P;
+    } else {
+        by = L % A.gy;
+        pt = L / A.gy;
+    }
+    bx = pt;
+    return pt < P;
+}
+
+// bias -> (ELU / ReLU) -> per-channel affine -> 16-byte stores of output row 2 ty + wx of the block's 32 tiles
+__device__ __forceinline__ void wino_epilogue(const WinoArgs& A, const int bx, const int co_tile, const int wx, const int c,
+                                              const int h, const v16f (&keep)[2], const int q0 = 0, const int q1 = 4) {
+    const int H = A.H, W = A.W, TPI = A.TH * A.TW;
+    const int gt = bx * 32 + c;
+    const bool tile_ok = gt < A.T;
+    const int b = tile_ok ? gt / TPI : 0, rem = tile_ok ? gt - b * TPI : 0, ty = rem / A.TW, tx = rem - ty * A.TW;
+    const int oy = 2 * ty + wx;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!tile_ok || oy >= H) break;
+        if (q < q0 || q >= q1) continue;
+        const int co = co_tile * 32 + 8 * q + 4 * h;
+        float bi[4], sc[4], sh[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = co + i < A.Cout;
+            bi[i] = (A.bias && in) ? A.bias[co + i] : 0.0f;
+            sc[i] = (A.bn_scale && in) ? A.bn_scale[co + i] : 1.0f;
+            sh[i] = (A.bn_shift && in) ? A.bn_shift[co + i] : 0.0f;
+        }
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+            const int ox = 2 * tx + b2;
+            if (ox >= W) continue;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float u = keep[b2][4 * q + i] + bi[i];
+                if (A.act == 1) u = u > 0.0f ? u : expm1f(u);
+                else if (A.act == 2) u = fmaxf(u, 0.0f);
+                v[i] = u * sc[i] + sh[i];
+            }
+            float* o = A.out + ((size_t)b * H * W + (size_t)oy * W + ox) * A.out_cs + A.out_coff + co;
+            if (co + 3 < A.Cout) {
+                *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (co + i < A.Cout) o[i] = v[i];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int block, const int slice = 0, const int ks = 1,
+                                               float* __restrict__ partial = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float4 vb[];   // [2][16 xi][32 tiles][4 quads]
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform TO THE COMPILER: weight addresses become scalar
@@ -84,31 +167,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     // ---- logical block (bx = tile group, by = channel group) from the 1-D launch id, XCD-aware as in conv.hip: every
     // XCD streams the transformed weights of ONE channel group (64 x Cin x 16 floats: 2.6 MB at Cin = 640) through its L2
     int bx, by;
-    {
-        const int L = block, P = A.gx;
-        int pt;
-#ifdef OSSID_WINO_MAP_TILES      // A/B: an XCD owns tile groups (all channel groups of each) instead of one channel group
-        if (true) {
-            const int xcd = L & 7, idx = L >> 3;
-            by = idx % A.gy;
-            pt = (idx / A.gy) * 8 + xcd;
-        } else
-#endif
-        if (A.gy <= 8 && (8 % A.gy) == 0) {
-            const int k = L & 7, R = 8 / A.gy, per = (P + R - 1) / R;
-            by = k % A.gy;
-            pt = (L >> 3) < per ? (k / A.gy) * per + (L >> 3) : P;
-        } else if ((A.gy & 7) == 0) {
-            const int j = L >> 3;
-            by = (L & 7) + 8 * (j / P);
-            pt = j % P;
-        } else {
-            by = L % A.gy;
-            pt = L / A.gy;
-        }
-        if (pt >= P) return;
-        bx = pt;
-    }
+    if (!wino_block_map(A, block, bx, by)) return;
     const int H = A.H, W = A.W, TPI = A.TH * A.TW;
 #ifdef OSSID_WINO_STAGGER
     // the second workgroup a CU receives (ids 256..511 of a round-robin deal) starts half a chunk late, so that the two
@@ -219,23 +278,24 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
         for (int r = 0; r < 16; ++r) acc[e][r] = 0.0f;
 
     const int nchunks = A.Cin / KCH;
-    stage_load(0);
-    transform_write(0);
+    const int ch0 = (int)((long long)slice * nchunks / ks), ch1 = (int)((long long)(slice + 1) * nchunks / ks);
+    stage_load(ch0 * KCH);
+    transform_write(ch0 & 1);
     // weight quads: ONE register set, refilled in place -- the load of the quad four steps ahead (the next group's) is
     // issued right behind the four MFMAs that consumed this one, so every quad still has 16 MFMAs of cover
     float4 cur[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cur[i] = W4[(size_t)quad_of(0, i) * 64 + lane];
+    for (int i = 0; i < 4; ++i) cur[i] = W4[(size_t)quad_of(4 * ch0, i) * 64 + lane];
     __syncthreads();
 #ifdef OSSID_TIMING
     tstamp[1] = tnow();
     cstamp[0] = cnow();
 #endif
 
-    int gi = 0;
+    int gi = 4 * ch0;
 #pragma unroll 1
-    for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch + 1 < nchunks) stage_load((ch + 1) * KCH);         // in flight under this chunk's MFMAs
+    for (int ch = ch0; ch < ch1; ++ch) {
+        if (ch + 1 < ch1) stage_load((ch + 1) * KCH);             // in flight under this chunk's MFMAs
         const float4* pb = vb + (size_t)(ch & 1) * VBUF + (size_t)(8 * wx * 32 + c) * F4 + h;
         float4 bq = pb[0];
 #pragma unroll
@@ -260,7 +320,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
             }
             ++gi;
         }
-        if (ch + 1 < nchunks) transform_write((ch + 1) & 1);
+        if (ch + 1 < ch1) transform_write((ch + 1) & 1);
         __syncthreads();
     }
 
@@ -298,45 +358,14 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     if (!active) { tstamp[3] = tnow(); tdump(); return; }
 #endif
     if (!active) return;
-    // ---- epilogue: bias -> (ELU / ReLU) -> per-channel affine -> 16-byte stores of output row 2 ty + wx --------------
-    const int gt = bx * 32 + c;
-    const bool tile_ok = gt < A.T;
-    const int b = tile_ok ? gt / TPI : 0, rem = tile_ok ? gt - b * TPI : 0, ty = rem / A.TW, tx = rem - ty * A.TW;
-    const int oy = 2 * ty + wx;
+    if (partial) {            // a slice of the reduction: raw sums for the finishing launch
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (!tile_ok || oy >= H) break;
-        const int co = co_tile * 32 + 8 * q + 4 * h;
-        float bi[4], sc[4], sh[4];
+        for (int b2 = 0; b2 < 2; ++b2)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool in = co + i < A.Cout;
-            bi[i] = (A.bias && in) ? A.bias[co + i] : 0.0f;
-            sc[i] = (A.bn_scale && in) ? A.bn_scale[co + i] : 1.0f;
-            sh[i] = (A.bn_shift && in) ? A.bn_shift[co + i] : 0.0f;
-        }
-#pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2) {
-            const int ox = 2 * tx + b2;
-            if (ox >= W) continue;
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float u = keep[b2][4 * q + i] + bi[i];
-                if (A.act == 1) u = u > 0.0f ? u : expm1f(u);
-                else if (A.act == 2) u = fmaxf(u, 0.0f);
-                v[i] = u * sc[i] + sh[i];
-            }
-            float* o = A.out + ((size_t)b * H * W + (size_t)oy * W + ox) * A.out_cs + A.out_coff + co;
-            if (co + 3 < A.Cout) {
-                *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (co + i < A.Cout) o[i] = v[i];
-            }
-        }
+            for (int r = 0; r < 16; ++r) partial[((size_t)(wave * 2 + b2) * 16 + r) * 64 + lane] = keep[b2][r];
+        return;
     }
+    wino_epilogue(A, bx, co_tile, wx, c, h, keep);
 #ifdef OSSID_TIMING
     __builtin_amdgcn_s_waitcnt(0);
     tstamp[3] = tnow();
@@ -344,7 +373,59 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
 #endif
 }
 
-__global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs A) { wino_conv_body(A, blockIdx.x); }
+__global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs A, const WinoTail T) {
+    const int b = blockIdx.x;
+    if (T.ks <= 1 || b < T.lcut) {
+        wino_conv_body(A, b);
+    } else {
+        const int t = b - T.lcut, j = t / T.ks, sl = t - j * T.ks;
+        wino_conv_body(A, T.lcut + j, sl, T.ks, T.partial + ((size_t)j * T.ks + sl) * WINO_PARTIAL_FLOATS);
+    }
+}
+
+// The tail's second half: one workgroup per tail block adds the ks shares (fixed order: bit-reproducible) and runs the epilogue.
+// (grid: tail blocks x 4 -- blockIdx.y takes one channel quad-row of the tile, so that the handful of tail blocks becomes a
+// few hundred workgroups whose 8 * ks loads per thread are all independent)
+__device__ __forceinline__ void wino_finish_body(const WinoArgs& A, const int L, const float* __restrict__ part, const int ks,
+                                                 const int q) {
+    int bx, by;
+    if (!wino_block_map(A, L, bx, by)) return;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31, wave = tid >> 6;
+    const int wm = wave & 1, wx = wave >> 1;
+    const int co_tile = by * 2 + wm;
+    if (co_tile >= A.n_cotiles) return;
+    v16f keep[2];
+    float s[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int k = 0; k < ks; ++k) {
+        const float* src = part + (size_t)k * WINO_PARTIAL_FLOATS + ((size_t)(wave * 2) * 16 + 4 * q) * 64 + lane;
+        float v[2][4];
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[b2][i] = src[((size_t)b2 * 16 + i) * 64];
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[b2][i] += v[b2][i];
+    }
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep[b2][r] = 0.0f;
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (q == 0) keep[b2][i] = s[b2][i];
+            else if (q == 1) keep[b2][4 + i] = s[b2][i];
+            else if (q == 2) keep[b2][8 + i] = s[b2][i];
+            else keep[b2][12 + i] = s[b2][i];
+        }
+    wino_epilogue(A, bx, co_tile, wx, c, h, keep, q, q + 1);
+}
+__global__ __launch_bounds__(256) void wino_finish_kernel(const WinoArgs A, const WinoTail T) {
+    wino_finish_body(A, T.lcut + blockIdx.x, T.partial + (size_t)blockIdx.x * T.ks * WINO_PARTIAL_FLOATS, T.ks, blockIdx.y);
+}
 
 // Two independent layers in ONE grid (the classification and the regression trunk's i-th convolution, network.py:113-121 /
 // :146-154: same shapes, different inputs and weights): 2 x 788 workgroups fill the chip's 512 slots in 3.08 rounds
@@ -352,10 +433,24 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs A) { w
 struct WinoPair {
     WinoArgs a, b;
     int n0;
+    WinoTail t;           // over the COMBINED virtual ids [0, n0 + n1)
 };
 __global__ __launch_bounds__(256, 2) void wino_conv_pair_kernel(const WinoPair G) {
-    if ((int)blockIdx.x < G.n0) wino_conv_body(G.a, blockIdx.x);
-    else wino_conv_body(G.b, blockIdx.x - G.n0);
+    int v = blockIdx.x, sl = 0, ks = 1;
+    float* part = nullptr;
+    if (G.t.ks > 1 && v >= G.t.lcut) {
+        const int t = v - G.t.lcut, j = t / G.t.ks;
+        sl = t - j * G.t.ks, ks = G.t.ks, v = G.t.lcut + j;
+        part = G.t.partial + ((size_t)j * ks + sl) * WINO_PARTIAL_FLOATS;
+    }
+    if (v < G.n0) wino_conv_body(G.a, v, sl, ks, part);
+    else wino_conv_body(G.b, v - G.n0, sl, ks, part);
+}
+__global__ __launch_bounds__(256) void wino_finish_pair_kernel(const WinoPair G) {
+    const int v = G.t.lcut + blockIdx.x;
+    const float* part = G.t.partial + (size_t)blockIdx.x * G.t.ks * WINO_PARTIAL_FLOATS;
+    if (v < G.n0) wino_finish_body(G.a, v, part, G.t.ks, blockIdx.y);
+    else wino_finish_body(G.b, v - G.n0, part, G.t.ks, blockIdx.y);
 }
 
 // U = G g G^T packed as the kernel streams it. dgrad != 0: the weights of the data gradient (the transposed layer:
@@ -425,14 +520,68 @@ static int wino_args(const ossid_conv_desc* d, WinoArgs& a, long& nwg) {
     return nwg > 0x3fffffffL ? OSSID_EINVAL : OSSID_OK;
 }
 
+// How to cut the tail of a grid of `nwg` equal workgroups on the chip's 512 slots (two per CU). Time goes in whole rounds of
+// resident workgroups: 1 576 workgroups (768 -> 512 at 21 templates) cost four rounds for 3.08 rounds of work. The last,
+// partial round is therefore cut along the reduction into ks slices per workgroup (one more, shorter round of `tail * ks`
+// workgroups + a finishing launch) whenever that fits the slots and the reduction is long enough to split.
+static void wino_plan_tail(long nwg, int nchunks, WinoTail& t) {
+    const long S = 512;
+    t.lcut = (int)((nwg / S) * S), t.ks = 1, t.partial = nullptr;
+    const long tail = nwg - t.lcut;
+    if (tail == 0) return;
+    // modelled time in units of one whole workgroup: full rounds + rounds of tail slices, each 1/ks of the reduction plus
+    // a fixed share (staging ramp, output transform, raw store) + the finishing launch; calibrated on 768 -> 512 at 21
+    // templates (1 576 workgroups: 0.924 ms whole = 4 rounds, 0.743 ms with the 40-workgroup tail in 12 slices)
+    double best = (double)(t.lcut / S) + 1.0;
+    const int cand[] = {2, 3, 4, 6, 8, 12};
+    for (int ks : cand) {
+        if (ks > nchunks / 4) break;                           // at least four 16-channel chunks per slice
+        const double rounds = (double)((tail * ks + S - 1) / S);
+        const double tm = (double)(t.lcut / S) + rounds * (1.0 / ks + 0.08) + 0.05;
+        if (tm < best - 0.03) best = tm, t.ks = ks;
+    }
+}
+
+size_t ossid_conv3x3_wino_workspace_bytes(const ossid_conv_desc* d) {
+    WinoArgs a;
+    long nwg = 0;
+    if (wino_args(d, a, nwg) != OSSID_OK) return 0;
+    WinoTail t;
+    wino_plan_tail(nwg, a.Cin / KCH, t);
+    return t.ks > 1 ? (size_t)(nwg - t.lcut) * t.ks * WINO_PARTIAL_FLOATS * sizeof(float) : 0;
+}
+
+size_t ossid_conv3x3_wino_pair_workspace_bytes(const ossid_conv_desc* d0, const ossid_conv_desc* d1) {
+    WinoArgs a, b;
+    long n0 = 0, n1 = 0;
+    if (wino_args(d0, a, n0) != OSSID_OK || wino_args(d1, b, n1) != OSSID_OK || a.Cin != b.Cin) return 0;
+    WinoTail t;
+    wino_plan_tail(n0 + n1, a.Cin / KCH, t);
+    return t.ks > 1 ? (size_t)(n0 + n1 - t.lcut) * t.ks * WINO_PARTIAL_FLOATS * sizeof(float) : 0;
+}
+
 int ossid_conv3x3_wino_fwd(const ossid_conv_desc* d, void* stream) {
     WinoArgs a;
     long nwg = 0;
     const int rc = wino_args(d, a, nwg);
     if (rc != OSSID_OK) return rc;
+    WinoTail t;
+    wino_plan_tail(nwg, a.Cin / KCH, t);
+#ifndef OSSID_TIMING
+    // the tail split needs scratch for the slices' raw sums (desc->epi_partials, epi_partials_rows = its size in bytes);
+    // without it the launch simply runs whole workgroups
+    const size_t need = t.ks > 1 ? (size_t)(nwg - t.lcut) * t.ks * WINO_PARTIAL_FLOATS * sizeof(float) : 0;
+    if (need && d->epi_partials && (size_t)d->epi_partials_rows >= need) t.partial = d->epi_partials;
+    else t.ks = 1;
+#else
+    t.ks = 1;
+#endif
+    const long grid = t.ks > 1 ? t.lcut + (nwg - t.lcut) * t.ks : nwg;
     const size_t lds = (size_t)2 * VBUF * 16;
     OSSID_ENSURE_LDS(wino_conv_kernel, lds);
-    hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)nwg), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a, t);
+    if (t.ks > 1)
+        hipLaunchKernelGGL(wino_finish_kernel, dim3((unsigned)(nwg - t.lcut), 4), dim3(256), 0, (hipStream_t)stream, a, t);
     return ossid_launch_status();
 }
 
@@ -444,9 +593,21 @@ int ossid_conv3x3_wino_fwd_pair(const ossid_conv_desc* d0, const ossid_conv_desc
     rc = wino_args(d1, g.b, n1);
     if (rc != OSSID_OK) return rc;
     g.n0 = (int)n0;
+    wino_plan_tail(n0 + n1, g.a.Cin / KCH, g.t);
+#ifndef OSSID_TIMING
+    // scratch for the tail slices: d0->epi_partials / epi_partials_rows (bytes), see ossid_conv3x3_wino_pair_workspace_bytes
+    const size_t need = g.t.ks > 1 ? (size_t)(n0 + n1 - g.t.lcut) * g.t.ks * WINO_PARTIAL_FLOATS * sizeof(float) : 0;
+    if (need && g.a.Cin == g.b.Cin && d0->epi_partials && (size_t)d0->epi_partials_rows >= need) g.t.partial = d0->epi_partials;
+    else g.t.ks = 1;
+#else
+    g.t.ks = 1;
+#endif
+    const long tail = n0 + n1 - g.t.lcut;
+    const long grid = g.t.ks > 1 ? g.t.lcut + tail * g.t.ks : n0 + n1;
     const size_t lds = (size_t)2 * VBUF * 16;
     OSSID_ENSURE_LDS(wino_conv_pair_kernel, lds);
-    hipLaunchKernelGGL(wino_conv_pair_kernel, dim3((unsigned)(n0 + n1)), dim3(256), lds, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(wino_conv_pair_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, g);
+    if (g.t.ks > 1) hipLaunchKernelGGL(wino_finish_pair_kernel, dim3((unsigned)tail, 4), dim3(256), 0, (hipStream_t)stream, g);
     return ossid_launch_status();
 }
 

@@ -239,6 +239,28 @@ USE_WINO = os.environ.get("OSSID_WINO", "1") != "0"
 WINO_MIN_WGS = int(os.environ.get("OSSID_WINO_MIN_WGS", "256"))
 
 
+_WINO_WS = {}
+
+
+def wino_workspace(descs, device):
+    """Scratch for the Winograd launch's tail split (include/ossid_hip.h ossid_conv3x3_wino_workspace_bytes), one grow-only
+    buffer per (device, stream); sets it in the (first) descriptor. descs: one ConvDesc, or two for the pair entry."""
+    if len(descs) == 1:
+        n = _lib.fn("ossid_conv3x3_wino_workspace_bytes")(C_byref(descs[0]))
+    else:
+        n = _lib.fn("ossid_conv3x3_wino_pair_workspace_bytes")(C_byref(descs[0]), C_byref(descs[1]))
+    if not n:
+        return
+    key = (str(device), _lib.stream())
+    buf = _WINO_WS.get(key)
+    if buf is None or buf.numel() < n:
+        buf = _WINO_WS[key] = torch.empty(max(int(n), 16 << 20), dtype=torch.uint8, device=device)
+    rec = _lib.recording()
+    if rec is not None:
+        rec.keep(buf)
+    descs[0].epi_partials, descs[0].epi_partials_rows = buf.data_ptr(), buf.numel()
+
+
 class PackedConv:
     """One nn.Conv2d (3x3 / stride 1 / padding 1, or 1x1) in the MFMA operand layout of csrc/conv.hip with its fused
     neighbours: `pre_bn` (+ReLU) = eval-mode BatchNorm in FRONT of the conv (DenseNet's BN-ReLU-Conv), `act` = ELU and
@@ -335,6 +357,8 @@ class PackedConv:
         the whole batch; pre = (scale [B,Cin], shift [B,Cin]): a per-image input affine instead of the stored one."""
         d, name = self._desc(x_nhwc, B, H, W, out_nhwc, in_cs, out_cs, out_coff, src_hw, in_bs, pre)
         with _lib.on_device(out_nhwc.device):
+            if name == "ossid_conv3x3_wino_fwd":
+                wino_workspace((d,), out_nhwc.device)
             _lib.check(_lib.fn(name)(C_byref(d), _lib.stream()), name)
         return out_nhwc
 
@@ -347,11 +371,14 @@ class PackedConv:
         dev = args0[0][4].device
         with _lib.on_device(dev):
             if n0 == n1 == "ossid_conv3x3_wino_fwd":
+                wino_workspace((d0, d1), dev)
                 _lib.check(_lib.fn("ossid_conv3x3_wino_fwd_pair")(C_byref(d0), C_byref(d1), _lib.stream()),
                            "ossid_conv3x3_wino_fwd_pair")
             else:
-                _lib.check(_lib.fn(n0)(C_byref(d0), _lib.stream()), n0)
-                _lib.check(_lib.fn(n1)(C_byref(d1), _lib.stream()), n1)
+                for d, n in ((d0, n0), (d1, n1)):
+                    if n == "ossid_conv3x3_wino_fwd":
+                        wino_workspace((d,), dev)
+                    _lib.check(_lib.fn(n)(C_byref(d), _lib.stream()), n)
 
     def __call__(self, x, size=None):
         """x: logical [B,Cin,Hs,Ws] tensor (any memory format; channels_last is consumed in place) -> logical

@@ -282,6 +282,9 @@ def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_rel
         d.post_scale, d.post_shift = post[0].data_ptr(), post[1].data_ptr()
     name = "ossid_conv3x3_wino_fwd" if wino else "ossid_conv_nhwc_fwd"       # wino: wpk is the Winograd layout
     with _lib.on_device(out.device):
+        if wino and d.epi_partials is None:
+            from .ops import wino_workspace
+            wino_workspace((d,), out.device)                                  # scratch for the launch's tail split
         _lib.check(_lib.fn(name)(_byref(d), _lib.stream()), name)
     return out
 
