@@ -182,24 +182,11 @@ typedef struct ossid_conv_desc {
                                    0 = ONE image shared by the whole batch (a per-image pre-affine then makes each
                                    batch entry a different affine view of it: image_feat * avg_t, image_feat - avg_t
                                    of network.py:344-347 without materialising them) */
-    /* epilogue extras of the TRAINING step (all optional; taps 9 / 1 only). With v = the value after act/post and
-     * a = epi_aux[pixel][channel] (channels-last, epi_aux_channel_stride floats per pixel, 0 = cout):
-     *   epi_mask_mode 1: m = [epi_mask_scale[c] * a + epi_mask_shift[c] > 0], else m = 1;   r = epi_alpha[c] * v * m
-     *   epi_accumulate != 0: out += r instead of out = r (DenseNet's gradient accumulation in the data gradient)
-     *   epi_sum_mode 1: column sums of (v*m, v*m*a) = (d shift, d scale) of the folded BatchNorm+ReLU the data gradient
-     *                   runs back through; 2: column sums of (v, v*v) = batch statistics of this layer's output.
-     * Column sums are written as per-wave partial rows epi_partials [rows][2][cout] (capacity epi_partials_rows rows;
-     * B * (H + 4) * ceil(W / 32) + 8 always suffices); ossid_conv_last_partial_rows() returns the row count of the calling thread's
-     * last launch, and ossid_bn_fold_fwd / _bwd (n_partials = rows) add the rows in a fixed order. */
-    const float* epi_aux;
-    const float* epi_alpha;
-    const float* epi_mask_scale;
-    const float* epi_mask_shift;
-    float* epi_partials;
-    int64_t epi_partials_rows;
-    int32_t epi_aux_channel_stride, epi_mask_mode, epi_accumulate, epi_sum_mode;
+    /* Scratch a launch may use (optional): the Winograd entry's tail split (ossid_conv3x3_wino_workspace_bytes) keeps the
+     * raw sums of its slices here; -DOSSID_TIMING diagnostic builds write per-wave time stamps. scratch_bytes = its size. */
+    void* scratch;
+    int64_t scratch_bytes;
 } ossid_conv_desc;
-long long ossid_conv_last_partial_rows(void);
 size_t ossid_conv_packed_floats(int Cout, int Cin, int taps);
 int ossid_conv_pack_weights(const float* w, int Cout, int Cin, int taps, float* wpk, void* stream);
 int ossid_conv_nhwc_fwd(const ossid_conv_desc* desc_host, void* stream);
@@ -216,8 +203,8 @@ int ossid_conv_pack_weights_wino(const float* w, int Cout, int Cin, int dgrad, f
 int ossid_conv3x3_wino_fwd(const ossid_conv_desc* desc_host, void* stream);
 /* Scratch the Winograd launch wants for cutting the TAIL of its grid along the reduction (csrc/wino.hip: the last, partial
  * round of resident workgroups runs as ks slices per workgroup + a finishing launch; 1 576 workgroups on 512 slots cost
- * ~3.3 rounds instead of 4). 0 = no split planned for this shape. Pass the buffer in desc->epi_partials and its size in
- * BYTES in desc->epi_partials_rows (for the pair entry: in the first descriptor); without it the launch runs whole
+ * ~3.3 rounds instead of 4). 0 = no split planned for this shape. Pass the buffer in desc->scratch and its size in
+ * desc->scratch_bytes (for the pair entry: in the first descriptor); without it the launch runs whole
  * workgroups. Results are bit-reproducible either way (fixed summation order), but differ in rounding between the two forms. */
 size_t ossid_conv3x3_wino_workspace_bytes(const ossid_conv_desc* desc);
 size_t ossid_conv3x3_wino_pair_workspace_bytes(const ossid_conv_desc* d0, const ossid_conv_desc* d1);
@@ -357,7 +344,7 @@ int ossid_bn_fold_bwd(const float* dscale, const float* dshift, const float* par
                       float* coef_1, int accumulate, void* stream);
 
 /* sums[c], sums[sums_row_stride + c] = the column sums left as n_partials partial rows [n][2][C] by ossid_chan_op
- * (defer_finalize) or by a convolution's epilogue (epi_sum_mode), combined in a fixed order in double. */
+ * (defer_finalize), combined in a fixed order in double. */
 int ossid_colsum_finalize(const float* partials, int n_partials, int C, float* sums, int sums_row_stride, void* stream);
 
 /* D16  all convolution weights of a training step re-packed in ONE launch (they change every optimizer step): a device

@@ -26,9 +26,7 @@ class ConvDesc(C.Structure):
                [(n, C.c_int32) for n in ("batch", "height", "width", "cin", "cout", "taps", "act", "pre_relu",
                                          "src_height", "src_width", "in_channel_stride", "out_channel_stride",
                                          "out_channel_offset", "pre_batch_stride")] + [("in_batch_stride", C.c_int64)] + \
-               [(n, _vp) for n in ("epi_aux", "epi_alpha", "epi_mask_scale", "epi_mask_shift", "epi_partials")] + \
-               [("epi_partials_rows", C.c_int64)] + \
-               [(n, C.c_int32) for n in ("epi_aux_channel_stride", "epi_mask_mode", "epi_accumulate", "epi_sum_mode")]
+               [("scratch", _vp), ("scratch_bytes", C.c_int64)]
 
 
 class WgradDesc(C.Structure):
@@ -82,7 +80,6 @@ _PROTOS = {
     "ossid_conv_packed_floats": (_sz, [_i, _i, _i]),
     "ossid_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ossid_conv_nhwc_fwd": (_i, [_vp, _vp]),
-    "ossid_conv_last_partial_rows": (C.c_longlong, []),
     "ossid_seg_tail_packed_floats": (_sz, []),
     "ossid_seg_tail_pack_weights": (_i, [_vp, _vp, _vp]),
     "ossid_seg_tail_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -192,7 +189,7 @@ RECORDABLE = frozenset((
 # entry points that only compute sizes / return static data: called through, never stored
 _QUERIES = frozenset((
     "ossid_conv_packed_floats", "ossid_conv_wino_packed_floats", "ossid_chan_op_partials", "ossid_conv_wgrad_workspace_bytes",
-    "ossid_conv_wgrad_group_workspace_bytes", "ossid_dw_bwd_k_workspace_floats", "ossid_conv_last_partial_rows",
+    "ossid_conv_wgrad_group_workspace_bytes", "ossid_dw_bwd_k_workspace_floats",
     "ossid_conv3x3_wgrad_splits", "ossid_abi_version", "ossid_conv3x3_wino_workspace_bytes",
     "ossid_conv3x3_wino_pair_workspace_bytes"))
 

@@ -50,10 +50,7 @@ __device__ __forceinline__ v16f mfma(float a, float b, v16f c) {
 #define OSSID_MEDIUM_WGS 600
 #endif
 
-thread_local long g_partial_rows = 0;      // rows of e_partials the last launch of this thread wrote (host side)
-
 struct ConvArgs {
-    long buf_pos_rows_cap;                 // capacity of e_partials in rows (host-side check only)
     const float* x;
     const float4* wpk;
     const float *bias, *bn_scale, *bn_shift, *pre_scale, *pre_shift;
@@ -63,10 +60,7 @@ struct ConvArgs {
     int pre_bs;               // floats between consecutive images' pre_scale / pre_shift rows (0: one row for all)
     int gx, gy, gz;   // logical grid: pixel blocks x channel-tile groups x images (the launch itself is 1-D)
     float scale_h, scale_w;
-    // training epilogue (include/ossid_hip.h, ossid_conv_desc "epilogue extras")
-    const float *aux, *e_alpha, *e_ms, *e_mt;
-    float* e_partials;
-    int aux_cs, e_mask, e_acc, e_sum;
+    float* e_partials;        // -DOSSID_TIMING builds: per-wave time stamps (desc->scratch)
 };
 
 // Workgroup = 4 waves = WM (channel tiles) x WK (split of the reduction) x WN (pixel groups), each wave NT pixel tiles.
@@ -77,7 +71,7 @@ struct ConvArgs {
 // source pixels (i+a-1, i+a) x (j+b-1, j+b), so each of the four phases (a,b) is a 2x2 convolution of the SOURCE with
 // row/column-merged weights -- 4/9 of the multiply-adds of convolving the up-sampled image (network.py:354-356). Geometry
 // (H, W, pixel tiles, patch) is the source's; a block's group index carries the phase; outputs go to [2H][2W].
-template <int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH, bool EPI>
+template <int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
 __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     constexpr int WN = 4 / (WM * WK);
     constexpr int BPX = WN * NT * 32;
@@ -316,21 +310,13 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     int gi = 0;
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
-#ifndef OSSID_ABL_NOSTAGE
         if (ch + 1 < nchunks) stage_load((ch + 1) * KCH);     // in flight under this chunk's MFMAs
-#endif
         const float4* pb = patch + (size_t)(ch & 1) * A.buf_pos * F4P + h;
 #pragma unroll
         for (int g = 0; g < GPC; ++g) {
 #pragma unroll
-#ifndef OSSID_ABL_NOW
             for (int i = 0; i < GQ; ++i) wq[PF][i] = W4[(size_t)quad_of(gi + PF, i) * 64 + lane];
-#else
-            for (int i = 0; i < GQ; ++i) wq[PF][i] = wq[0][i];
-#endif
-#ifndef OSSID_ABL_NOFENCE
             __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
             for (int i = 0; i < GQ; ++i) {
                 // (a workgroup's spare waves -- channel tiles past the last -- run the same MFMAs on tile 0's weights and
@@ -341,20 +327,14 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
                 const float4 a = wq[0][i];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-#ifndef OSSID_ABL_NOB
                     const float4 bq = pb[(size_t)(pos0[t] + toff) * F4P + 2 * kb];
-#else
-                    const float4 bq = make_float4(a.y, a.x, a.w, a.z);
-#endif
                     acc[t] = mfma(a.x, bq.x, acc[t]);
                     acc[t] = mfma(a.y, bq.y, acc[t]);
                     acc[t] = mfma(a.z, bq.z, acc[t]);
                     acc[t] = mfma(a.w, bq.w, acc[t]);
                 }
             }
-#ifndef OSSID_ABL_NOFENCE
             __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
             for (int d = 0; d < PF; ++d)
 #pragma unroll
@@ -395,35 +375,17 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     if (!active) { tstamp[3] = tnow(); tdump(); return; }
 #endif
     if (!active) return;
-    // ---- epilogue: (ELU) -> (per-channel affine) -> [training extras] -> 16-byte stores --------------------------------
-    // Training extras (one pass less over the output each): v = the value so far, a = aux[pixel][channel]
-    //   e_mask 1: m = [e_ms[c] * a + e_mt[c] > 0] (ReLU behind a folded BatchNorm), else m = 1;  r = e_alpha[c] * v * m
-    //   e_acc:    r += out (DenseNet's gradient accumulation onto the block's gradient buffer)
-    //   e_sum 1:  column sums of (v*m, v*m*a)   -- (d shift, d scale) of the folded BatchNorm
-    //   e_sum 2:  column sums of (v, v*v)        -- batch statistics of this layer's output
-    // The sums of this wave's pixels go to row (pixel block, image, pixel group) of e_partials [rows][2][Cout]; every
-    // (row, channel) has exactly one writer, a later kernel adds the rows in a fixed order.
-    // (EPI is a template parameter: the extras cost ~60 registers, which the test-time instantiation must not pay)
-    float cs1[EPI ? 16 : 1], cs2[EPI ? 16 : 1];
-    if (EPI) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cs1[r] = cs2[r] = 0.0f;
-    }
+    // ---- epilogue: (ELU) -> (per-channel affine) -> 16-byte stores ----------------------------------------------------
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (WK > 1 && (q * WK) / 4 != wk) continue;               // with split-K the quads are shared out over the waves
         const int co = co_tile * 32 + 8 * q + 4 * h;
-        float sc[4], sh[4], ea[EPI ? 4 : 1], ems[EPI ? 4 : 1], emt[EPI ? 4 : 1];
+        float sc[4], sh[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool in = co + i < A.Cout;
             sc[i] = (A.bn_scale && in) ? A.bn_scale[co + i] : 1.0f;
             sh[i] = (A.bn_shift && in) ? A.bn_shift[co + i] : 0.0f;
-            if (EPI) {
-                ea[i] = (A.e_alpha && in) ? A.e_alpha[co + i] : 1.0f;
-                ems[i] = (A.e_ms && in) ? A.e_ms[co + i] : 1.0f;
-                emt[i] = (A.e_mt && in) ? A.e_mt[co + i] : 0.0f;
-            }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -438,42 +400,6 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
             }
             float* o = A.out + (size_t)opx[t] * A.out_cs + A.out_coff + co;
             const bool full = co + 3 < A.Cout;
-            if (EPI) {
-                float av[4] = {0.f, 0.f, 0.f, 0.f};
-                if (A.aux) {
-                    const float* ap = A.aux + (size_t)opx[t] * A.aux_cs + co;
-                    if (full) {
-                        const float4 a4 = *(const float4*)ap;
-                        av[0] = a4.x, av[1] = a4.y, av[2] = a4.z, av[3] = a4.w;
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (co + i < A.Cout) av[i] = ap[i];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (co + i >= A.Cout) continue;
-                    if (A.e_sum == 2) {
-                        cs1[4 * q + i] += v[i], cs2[4 * q + i] += v[i] * v[i];
-                    } else {
-                        const float m = (A.e_mask == 1) ? ((ems[i] * av[i] + emt[i] > 0.0f) ? 1.0f : 0.0f) : 1.0f;
-                        const float gm = v[i] * m;
-                        if (A.e_sum == 1) cs1[4 * q + i] += gm, cs2[4 * q + i] += gm * av[i];
-                        v[i] = ea[i] * gm;
-                    }
-                }
-                if (A.e_acc) {
-                    if (full) {
-                        const float4 o4 = *(const float4*)o;
-                        v[0] += o4.x, v[1] += o4.y, v[2] += o4.z, v[3] += o4.w;
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (co + i < A.Cout) v[i] += o[i];
-                    }
-                }
-            }
             if (full) {
                 *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -488,37 +414,6 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     tstamp[3] = tnow();
     tdump();
 #endif
-    if (EPI && A.e_sum) {
-        // Sum over the 32 pixels (lanes) of each half-wave as a butterfly REDUCE-SCATTER: at each of four steps a lane
-        // hands half of its remaining values to its partner and adds the partner's to the half it keeps (8+4+2+1
-        // exchanges), one last exchange pairs the even / odd lanes: 16 shuffles per sum instead of 5 x 16. Lane c (even)
-        // ends up with the total of register r(c) = 8*bit4(c) + 4*bit3(c) + 2*bit2(c) + bit1(c).
-#pragma unroll
-        for (int m = 16, n = 16; m >= 2; m >>= 1, n >>= 1) {
-            const bool up = (c & m) != 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j >= n / 2) break;
-                const float k1 = up ? cs1[j + n / 2] : cs1[j], s1 = up ? cs1[j] : cs1[j + n / 2];
-                const float k2 = up ? cs2[j + n / 2] : cs2[j], s2 = up ? cs2[j] : cs2[j + n / 2];
-                cs1[j] = k1 + __shfl_xor(s1, m);
-                cs2[j] = k2 + __shfl_xor(s2, m);
-            }
-        }
-        cs1[0] += __shfl_xor(cs1[0], 1);
-        cs2[0] += __shfl_xor(cs2[0], 1);
-        const int r = ((c >> 4) & 1) * 8 + ((c >> 3) & 1) * 4 + ((c >> 2) & 1) * 2 + ((c >> 1) & 1);
-        const int q = r >> 2;
-        if (!(c & 1) && !(WK > 1 && (q * WK) / 4 != wk)) {
-            const size_t row = (size_t)(bx + A.gx * b) * WN + wn;
-            const int co = co_tile * 32 + 8 * q + 4 * h + (r & 3);
-            if (co < A.Cout) {
-                float* p1 = A.e_partials + row * 2 * A.Cout;
-                p1[co] = cs1[0];
-                p1[A.Cout + co] = cs2[0];
-            }
-        }
-    }
 }
 
 // weight repack on the device: w [Cout][Cin][taps] (torch layout, taps = kh*kw) -> wpk (see the file header)
@@ -568,20 +463,9 @@ int launch_conv(ConvArgs a, int B, hipStream_t s) {
     size_t lds = (size_t)2 * a.buf_pos * (F4 + OSSID_LDS_PAD) * 16;
     const size_t red = WK > 1 ? (size_t)WK * (WM * WN) * NT * 16 * 64 * 4 : 0;
     if (red > lds) lds = red;
-    const bool epi = (a.e_mask | a.e_acc | a.e_sum) != 0;
-    auto kern0 = conv_nhwc_kernel<WM, WK, NT, ROWSEG, NLD, TAPS, KCH, false>;
-    auto kern1 = conv_nhwc_kernel<WM, WK, NT, ROWSEG, NLD, TAPS, KCH, (TAPS != 4)>;     // (the phase form has no extras)
-    if (epi) {
-        OSSID_ENSURE_LDS(kern1, lds);
-    } else {
-        OSSID_ENSURE_LDS(kern0, lds);
-    }
+    auto kern0 = conv_nhwc_kernel<WM, WK, NT, ROWSEG, NLD, TAPS, KCH>;
+    OSSID_ENSURE_LDS(kern0, lds);
     a.gx = nblk, a.gy = (a.n_cotiles + WM - 1) / WM * (TAPS == 4 ? 4 : 1), a.gz = B;
-    if (a.e_sum) {
-        if (TAPS == 4) return OSSID_EINVAL;
-        g_partial_rows = (long)nblk * B * WN;
-        if (g_partial_rows > a.buf_pos_rows_cap) return OSSID_EINVAL;
-    }
     const long P = (long)a.gx * a.gz;
     long nwg;
     if (a.gy <= 8 && 8 % a.gy == 0)
@@ -589,10 +473,7 @@ int launch_conv(ConvArgs a, int B, hipStream_t s) {
     else
         nwg = P * a.gy;          // gy a multiple of 8 (exact) or the plain mapping
     if (nwg > 0x7fffffffL) return OSSID_EINVAL;
-    if (epi)
-        hipLaunchKernelGGL(kern1, dim3((unsigned)nwg), dim3(256), lds, s, a);
-    else
-        hipLaunchKernelGGL(kern0, dim3((unsigned)nwg), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern0, dim3((unsigned)nwg), dim3(256), lds, s, a);
     return ossid_launch_status();
 }
 
@@ -611,8 +492,6 @@ int ossid_conv_pack_weights(const float* w, int Cout, int Cin, int taps, float* 
                        Cout, Cin, taps, (float4*)wpk, total);
     return ossid_launch_status();
 }
-
-long long ossid_conv_last_partial_rows(void) { return g_partial_rows; }
 
 int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
     if (!d) return OSSID_EINVAL;
@@ -635,14 +514,7 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
         (a.out_coff % 4) || (a.pre_scale && !a.pre_shift) || (a.in_bs % 4) || a.pre_bs < 0 || (a.pre_bs % 4) || (d->taps == 1 && (a.Hs != H || a.Ws != W)))
         return OSSID_EINVAL;
     a.scale_h = (float)a.Hs / (float)H, a.scale_w = (float)a.Ws / (float)W;
-    a.aux = d->epi_aux, a.aux_cs = d->epi_aux_channel_stride > 0 ? d->epi_aux_channel_stride : Cout;
-    a.e_alpha = d->epi_alpha, a.e_ms = d->epi_mask_scale, a.e_mt = d->epi_mask_shift, a.e_partials = d->epi_partials;
-    a.e_mask = d->epi_mask_mode, a.e_acc = d->epi_accumulate, a.e_sum = d->epi_sum_mode;
-    a.buf_pos_rows_cap = d->epi_partials_rows;
-    if (a.e_mask < 0 || a.e_mask > 1 || a.e_sum < 0 || a.e_sum > 2 || (a.e_sum && (!a.e_partials || a.buf_pos_rows_cap <= 0)) ||
-        ((a.e_mask == 1 || a.e_sum == 1) && !a.aux) || (a.aux_cs % 4) || ((a.e_mask | a.e_sum | a.e_acc) && d->taps == 4))
-        return OSSID_EINVAL;
-    g_partial_rows = 0;
+    a.e_partials = (float*)d->scratch;       // (-DOSSID_TIMING builds only: per-wave time stamps)
     hipStream_t s = (hipStream_t)stream;
     const int tiles = a.n_cotiles;
     const long px = (long)B * H * W;

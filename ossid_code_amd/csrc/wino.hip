@@ -69,13 +69,6 @@ constexpr int WINO_PARTIAL_FLOATS = 4 * 2 * 16 * 64;
 __device__ __forceinline__ bool wino_block_map(const WinoArgs& A, const int L, int& bx, int& by) {
     const int P = A.gx;
     int pt;
-#ifdef OSSID_WINO_MAP_TILES      // A/B: an XCD owns tile groups (all channel groups of each) instead of one channel group
-    if (true) {
-        const int xcd = L & 7, idx = L >> 3;
-        by = idx % A.gy;
-        pt = (idx / A.gy) * 8 + xcd;
-    } else
-#endif
     if (A.gy <= 8 && (8 % A.gy) == 0) {
         const int k = L & 7, R = 8 / A.gy, per = (P + R - 1) / R;
         by = k % A.gy;
@@ -169,11 +162,6 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     int bx, by;
     if (!wino_block_map(A, block, bx, by)) return;
     const int H = A.H, W = A.W, TPI = A.TH * A.TW;
-#ifdef OSSID_WINO_STAGGER
-    // the second workgroup a CU receives (ids 256..511 of a round-robin deal) starts half a chunk late, so that the two
-    // co-resident workgroups do not meet in their transform phases
-    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(OSSID_WINO_STAGGER);
-#endif
 
     // ---- staging role: (tile tl, channel quad j, transform half ih) -> 3 patch rows x 4 columns ------------------
     const int j = tid & 3, tl = (tid >> 2) & 31, ih = __builtin_amdgcn_readfirstlane(tid >> 7);   // (wave-uniform)
@@ -231,11 +219,6 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     // rows of B^T d for this half (loaded patch rows p, q, s = rows ih, ih+1, ih+2 of d), then the column transform
     auto transform_write = [&](int buf) {
         v4f* o = (v4f*)(vb + (size_t)buf * VBUF + (size_t)tl * F4 + j);
-#ifdef OSSID_WABL_NOTRANSFORM
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[(size_t)(8 * ih + k) * 32 * F4] = st[k % 3][k & 3];
-        return;
-#endif
         // a - b as fma(b, -1, a): exact, and one v_pk_fma_f32 per two floats where a plain subtraction is scalarised
         const v4f m1 = {-1.f, -1.f, -1.f, -1.f};
         auto sub = [&](v4f x, v4f y) { return __builtin_elementwise_fma(y, m1, x); };
@@ -313,9 +296,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
                 acc[e] = mfma(a.y, b4.y, acc[e]);
                 acc[e] = mfma(a.z, b4.z, acc[e]);
                 acc[e] = mfma(a.w, b4.w, acc[e]);
-#ifndef OSSID_WABL_NOW
                 cur[i] = W4[(size_t)quad_of(gi + 1, i) * 64 + lane];
-#endif
                 __builtin_amdgcn_sched_barrier(0);      // keep this order: the compiler would sink the load to its use
             }
             ++gi;
@@ -484,8 +465,6 @@ static int wino_args(const ossid_conv_desc* d, WinoArgs& a, long& nwg) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 16 || d->taps != 9 || d->act < 0 || d->act > 2)
         return OSSID_EINVAL;
     if ((d->src_height > 0 && d->src_height != H) || (d->src_width > 0 && d->src_width != W)) return OSSID_EINVAL;   // no fused up-sampling
-    if (d->epi_aux || d->epi_alpha || d->epi_mask_scale || d->epi_mask_shift || d->epi_mask_mode || d->epi_accumulate || d->epi_sum_mode)
-        return OSSID_EINVAL;                                                                                          // no training extras
     a.x = d->x, a.wpk = (const float4*)d->wpk, a.bias = d->bias, a.bn_scale = d->post_scale, a.bn_shift = d->post_shift;
     a.pre_scale = d->pre_scale, a.pre_shift = d->pre_shift, a.out = d->out, a.pre_relu = d->pre_relu;
     a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout, a.n_cotiles = (Cout + 31) / 32, a.act = d->act;
@@ -494,7 +473,7 @@ static int wino_args(const ossid_conv_desc* d, WinoArgs& a, long& nwg) {
     a.pre_bs = d->pre_batch_stride;
     a.out_cs = d->out_channel_stride > 0 ? d->out_channel_stride : Cout;
     a.out_coff = d->out_channel_offset;
-    a.dbg = d->epi_partials;
+    a.dbg = (float*)d->scratch;
     {
         const long long xb = (a.in_bs == 0 ? (long long)H * W * a.in_cs : (long long)B * a.in_bs) * 4;
         if (xb > 0x7fffffffLL) return OSSID_EINVAL;       // 32-bit byte offsets in the staging loads
@@ -509,14 +488,10 @@ static int wino_args(const ossid_conv_desc* d, WinoArgs& a, long& nwg) {
     a.T = (int)T;
     a.gx = (int)((T + 31) / 32), a.gy = (a.n_cotiles + 1) / 2;
     const long P = a.gx;
-#ifdef OSSID_WINO_MAP_TILES
-    nwg = ((P + 7) / 8) * 8 * a.gy;
-#else
     if (a.gy <= 8 && 8 % a.gy == 0)
         nwg = 8 * ((P + 8 / a.gy - 1) / (8 / a.gy));
     else
         nwg = P * a.gy;
-#endif
     return nwg > 0x3fffffffL ? OSSID_EINVAL : OSSID_OK;
 }
 
@@ -568,10 +543,10 @@ int ossid_conv3x3_wino_fwd(const ossid_conv_desc* d, void* stream) {
     WinoTail t;
     wino_plan_tail(nwg, a.Cin / KCH, t);
 #ifndef OSSID_TIMING
-    // the tail split needs scratch for the slices' raw sums (desc->epi_partials, epi_partials_rows = its size in bytes);
+    // the tail split needs scratch for the slices' raw sums (desc->scratch, scratch_bytes);
     // without it the launch simply runs whole workgroups
     const size_t need = t.ks > 1 ? (size_t)(nwg - t.lcut) * t.ks * WINO_PARTIAL_FLOATS * sizeof(float) : 0;
-    if (need && d->epi_partials && (size_t)d->epi_partials_rows >= need) t.partial = d->epi_partials;
+    if (need && d->scratch && (size_t)d->scratch_bytes >= need) t.partial = (float*)d->scratch;
     else t.ks = 1;
 #else
     t.ks = 1;
@@ -595,9 +570,9 @@ int ossid_conv3x3_wino_fwd_pair(const ossid_conv_desc* d0, const ossid_conv_desc
     g.n0 = (int)n0;
     wino_plan_tail(n0 + n1, g.a.Cin / KCH, g.t);
 #ifndef OSSID_TIMING
-    // scratch for the tail slices: d0->epi_partials / epi_partials_rows (bytes), see ossid_conv3x3_wino_pair_workspace_bytes
+    // scratch for the tail slices: d0->scratch / scratch_bytes, see ossid_conv3x3_wino_pair_workspace_bytes
     const size_t need = g.t.ks > 1 ? (size_t)(n0 + n1 - g.t.lcut) * g.t.ks * WINO_PARTIAL_FLOATS * sizeof(float) : 0;
-    if (need && g.a.Cin == g.b.Cin && d0->epi_partials && (size_t)d0->epi_partials_rows >= need) g.t.partial = d0->epi_partials;
+    if (need && g.a.Cin == g.b.Cin && d0->scratch && (size_t)d0->scratch_bytes >= need) g.t.partial = (float*)d0->scratch;
     else g.t.ks = 1;
 #else
     g.t.ks = 1;

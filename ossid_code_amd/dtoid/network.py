@@ -1022,17 +1022,6 @@ class Network(nn.Module):
             template_global = template_global.expand(image.shape[0], -1, -1, -1)
         return self.image_feature_extractor(image, template_global)
 
-    # measured (round 2, 21 templates, graph replay): 9.02 ms with the three branches on three streams vs 8.53 ms on one --
-    # the captured graph does not run the branches side by side to any profit; kept as an opt-in for eager experiments
-    use_branch_streams = os.environ.get("OSSID_HEAD_STREAMS", "0") != "0"
-
-    def _branch_streams(self, device):
-        key = str(device)
-        c = self.__dict__.setdefault("_branch_stream_cache", {})
-        if key not in c:
-            c[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
-        return c[key]
-
     def _dense_head(self, features, template_features, sides=None):
         """Head of ONE image (features [1,640,h,w]) per template chunk -> dense (cls [n_t,A,2], reg [n_t,A,4],
         seg [n_t,1,H,W], heat [n_t,1,hh,hw], feature-map shape)."""
@@ -1040,20 +1029,7 @@ class Network(nn.Module):
         cls_out, reg_out, seg_out, heat_out = [], [], [], []
         frame = {}
         for ci, chunk in enumerate(template_features):
-            if fused is not None and self.use_branch_streams:
-                # the detection trunks and the segmentation decoder only share their input: two HIP streams, so the ragged
-                # last round of workgroups of one branch's launches is filled by the other's instead of leaving CUs idle
-                xc, heat, _ = fused.correlation(features, chunk, None if sides is None else sides[ci], frame, decoder=False)
-                cur = torch.cuda.current_stream(features.device)
-                sa, _sb = self._branch_streams(features.device)
-                sa.wait_stream(cur)
-                with torch.cuda.stream(sa):
-                    c, r = fused.detection(xc)
-                cls_out.append(c)
-                reg_out.append(r)
-                seg = fused.decoder(xc)
-                cur.wait_stream(sa)
-            elif fused is not None:
+            if fused is not None:
                 xc, heat, seg = fused.correlation(features, chunk, None if sides is None else sides[ci], frame)
                 c, r = fused.detection(xc)
                 cls_out.append(c)

@@ -258,7 +258,7 @@ def wino_workspace(descs, device):
     rec = _lib.recording()
     if rec is not None:
         rec.keep(buf)
-    descs[0].epi_partials, descs[0].epi_partials_rows = buf.data_ptr(), buf.numel()
+    descs[0].scratch, descs[0].scratch_bytes = buf.data_ptr(), buf.numel()
 
 
 class PackedConv:

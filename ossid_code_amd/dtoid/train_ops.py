@@ -277,12 +277,12 @@ def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_rel
     d.src_height, d.src_width = int(src_hw[0]), int(src_hw[1])
     d.in_channel_stride, d.out_channel_stride, d.out_channel_offset = int(in_cs), int(out_cs), int(out_coff)
     if epi is not None and epi.get("timing_buf") is not None:
-        d.epi_partials, d.epi_partials_rows = epi["timing_buf"].data_ptr(), 1 << 30
+        d.scratch, d.scratch_bytes = epi["timing_buf"].data_ptr(), 1 << 30
     if post is not None:
         d.post_scale, d.post_shift = post[0].data_ptr(), post[1].data_ptr()
     name = "ossid_conv3x3_wino_fwd" if wino else "ossid_conv_nhwc_fwd"       # wino: wpk is the Winograd layout
     with _lib.on_device(out.device):
-        if wino and d.epi_partials is None:
+        if wino and d.scratch is None:
             from .ops import wino_workspace
             wino_workspace((d,), out.device)                                  # scratch for the launch's tail split
         _lib.check(_lib.fn(name)(_byref(d), _lib.stream()), name)
