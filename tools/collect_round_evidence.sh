@@ -10,6 +10,7 @@ python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp && cd $R
 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 > $O/bench_under_profiler.json 2> $O/stats.err
 cp $O/stats/*/*kernel_stats.csv $O/kernel_stats.csv
+python tools/stats_by_pass.py $O/stats/*/*kernel_trace.csv --steps 20 --warmup 5 > $O/kernel_stats_by_pass.txt
 rocprofv3 --kernel-trace -d $O/ft --output-format csv -- python3 tools/bench_finetune.py --reps 3 --no-graph > $O/ft.log 2>&1
 python tools/trace_step.py $O/ft/*/*kernel_trace.csv --top 45 > $O/finetune_step_kernels.txt
 rocprofv3 --kernel-trace -d $O/fw --output-format csv -- python3 tools/bench_dtoid.py --what forward > $O/fw.log 2>&1
