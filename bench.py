@@ -90,7 +90,7 @@ def dtoid_flops(nt, hw=(29, 39), img=(480, 640)):
     """(nominal, executed) f32 flops (2 x MAC) of one test-time frame with nt templates. Nominal = the reference's forward
     (39.7 G backbone + 45.96 G per (image, template) pair). Executed = what this build's kernels do after
     the exact reassociations of DESIGN.md 5: conv(image - avg_t) once per frame instead of per template; conv(image *
-    avg_t) as G once per frame + a [nt x 640] GEMM from 16 templates on; the three decoder convs behind a 2x nearest
+    avg_t) as G once per frame + a [nt x 640] GEMM from 40 templates on; the three decoder convs behind a 2x nearest
     up-sampling as four 2x2 phase convs (4/9); the decoder tail's first conv with merged kernel rows (2/3)."""
     px = hw[0] * hw[1]
     conv640 = 2.0 * px * 256 * 640 * 9                      # one 640->256 3x3 conv at 29x39: 3.336 G
@@ -99,7 +99,7 @@ def dtoid_flops(nt, hw=(29, 39), img=(480, 640)):
     s5 = 2.0 * img[0] * img[1] * 16 * 32 * 9
     per_t = 45.96e9 - conv640 - dec * (5.0 / 9.0) - s5 / 3.0
     per_frame = 39.7e9 + conv640
-    if nt >= 16:
+    if nt >= 40:
         per_t -= conv640 - 2.0 * 640 * px * 256
         per_frame += conv640
     return nominal, per_frame + per_t * nt

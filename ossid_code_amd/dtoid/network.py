@@ -392,8 +392,10 @@ class FusedHead:
             pk.refresh()
         self._fill_derived()
 
-    # from this many templates on the channel-contraction-last form of `dot` wins (0.74 GB of G per frame)
-    DOT_GEMM_MIN_TEMPLATES = int(os.environ.get("OSSID_DOT_GEMM_MIN", "16"))
+    # from this many templates on the channel-contraction-last form of `dot` wins: G costs 0.30 ms per frame (0.74 GB) and
+    # the GEMM ~0.010 ms per template, against 0.0174 ms per template for the Winograd convolution it replaces since that
+    # kernel's tail split (round 3: 0.37 ms at 21 templates) -- the crossover moved from 16 to ~40 templates
+    DOT_GEMM_MIN_TEMPLATES = int(os.environ.get("OSSID_DOT_GEMM_MIN", "40"))
 
     def _fill_derived(self):
         """Weight re-layouts the linearity tricks need, (re)written IN PLACE (a captured graph reads `_dot_wcto`):
