@@ -881,7 +881,7 @@ class Network(nn.Module):
                     convs += [layer.conv1, layer.conv2]
             elif isinstance(m, Transition):
                 convs.append(m.conv)
-        convs += [ife.c1, corr.corr_conv_dot, corr.corr_conv_sub, corr.corr_conv_dot3x3, corr.cf] + \
+        convs += [ife.c1, corr.c1, corr.c2, corr.corr_conv_dot, corr.corr_conv_sub, corr.corr_conv_dot3x3, corr.cf] + \
             [getattr(corr, "s%d" % i) for i in (1, 2, 3, 4, 5)]
         for mod in (self.classification, self.regression):
             convs += [getattr(mod, "conv%d" % i) for i in (1, 2, 3, 4)] + [mod.output]
@@ -919,7 +919,13 @@ class Network(nn.Module):
             sc, sh = T.bn_fold(sums, u.shape[0] * u.shape[2] * u.shape[3], bn)
             return u, sc, sh
 
-        t2 = corr._cab(corr.c2, corr.n2, corr._cab(corr.c1, corr.n1, local))      # 7x7 -> 5x5 -> 3x3 (tiny: torch)
+        # 7x7 -> 5x5 -> 3x3: the two VALID 3x3 convolutions on the template features as padded convolutions on this repo's
+        # kernel whose interior is kept (an interior output never touches the padding), ELU in the epilogue, training
+        # BatchNorm by the generic passes (round 3; MIOpen's igemm kernels + layout transposes for them were ~0.8 ms of GPU
+        # time per step in front of the head)
+        t2 = local
+        for conv, bn in ((corr.c1, corr.n1), (corr.c2, corr.n2)):
+            t2 = T.bn_act_train(T.fused_conv(t2, conv, act_elu=True)[:, :, 1:-1, 1:-1], bn)
         dot3x3 = ops.dw_xcorr(feat, t2)
         avg = F.avg_pool2d(local, 7)
         par = self._branches_on(feat.device)
@@ -965,7 +971,7 @@ class Network(nn.Module):
         anchors = self.anchors([[u2.size(2), u2.size(3)]], device=u2.device)
         ts = self.__dict__.get("_folded_bn_counters_head")
         if ts is None:
-            mods = [corr.norm_corr_dot, corr.norm_corr_sub, corr.norm_corr_dot3x3, corr.nf] + \
+            mods = [corr.norm_corr_dot, corr.norm_corr_sub, corr.norm_corr_dot3x3, corr.nf, corr.n1, corr.n2] + \
                 [getattr(corr, "ns%d" % i) for i in (1, 2, 3, 4, 5)]
             ts = [m.num_batches_tracked for m in mods]
             self.__dict__["_folded_bn_counters_head"] = ts
