@@ -314,6 +314,16 @@ size_t ossid_seg_bce_iou_workspace_bytes(int B);
 int ossid_seg_bce_iou_fwd(const float* logit, const float* mask, int B, long long hw, float* prob, float* dlogit_sum,
                           float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* 3x3 / pad 1 convolution with ONE output channel in training -- the decoder's `seg_final` (nn.Conv2d(16, 1, 3, padding=1),
+ * models/dtoid/network.py:326, :362): x [B][H][W][C] channels-last (C % 4 == 0), w [C][3][3] = the parameter's layout,
+ * out / g [B][H][W]. Forward (+ bias), data gradient, weight + bias gradient (fixed-order sums through `workspace` >=
+ * ossid_conv3x3_c1_wgrad_workspace_bytes()). Vector-ALU kernels: a one-row output is no matrix-core shape. */
+int ossid_conv3x3_c1_fwd(const float* x, int B, int H, int W, int C, const float* w, const float* bias, float* out, void* stream);
+int ossid_conv3x3_c1_dgrad(const float* g, int B, int H, int W, int C, const float* w, float* dx, void* stream);
+size_t ossid_conv3x3_c1_wgrad_workspace_bytes(void);
+int ossid_conv3x3_c1_wgrad(const float* x, const float* g, int B, int H, int W, int C, void* workspace, size_t workspace_bytes,
+                           float* dw, float* db, void* stream);
+
 /* Convolution weights [cout][cin][k][k] -> the [cout][kpad] matrix in ossid_im2col_stem's column order
  * ((ky * k + kx) * cin + c, zero-padded), or back (inverse = 1: a weight GRADIENT computed on the im2col columns returns to
  * the parameter's layout). The strided stems (7x7 / 2 of the image backbone, network.py:164-170; 3x3 / 2 of the template

@@ -100,6 +100,10 @@ _PROTOS = {
     "ossid_fill_zero": (_i, [_vp, _sz, _vp]),
     "ossid_seg_bce_iou_workspace_bytes": (_sz, [_i]),
     "ossid_seg_bce_iou_fwd": (_i, [_vp, _vp, _i, C.c_longlong, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ossid_conv3x3_c1_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ossid_conv3x3_c1_dgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ossid_conv3x3_c1_wgrad_workspace_bytes": (_sz, []),
+    "ossid_conv3x3_c1_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "ossid_stem_weight_relayout": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ossid_chan_op_partials": (_i, [C.c_longlong, _i]),
     "ossid_chan_op": (_i, [_vp, _vp]),

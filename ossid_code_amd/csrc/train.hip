@@ -865,6 +865,147 @@ __global__ void seg_bce_iou_finalize_kernel(const double* __restrict__ partials,
     out[0] = (float)(total / ((double)B * (double)hw));
 }
 
+// =====================================================================================================================
+// 3x3 / pad 1 convolution with ONE output channel (the decoder's seg_final 16 -> 1 at 480 x 640, network.py:362) in training:
+// a per-pixel dot product of 9 x C inputs -- vector-ALU work bounded by the 157 MB of input, not a matrix-core shape (a 32-row
+// MFMA tile would be 31/32 padding). x [B][H][W][C] channels-last, w [C][3][3] (= nn.Conv2d(C, 1, 3).weight), out / g [B][H][W].
+__global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float4* __restrict__ x, int H, int W, int C4, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, size_t total, float* __restrict__ out) {
+    extern __shared__ float wl[];                  // [9][C]: tap-major, so that a tap's weights are float4-contiguous over channels
+    const int C = C4 * 4;
+    for (int i = threadIdx.x; i < 9 * C; i += 256) wl[i] = w[(i % C) * 9 + i / C];
+    __syncthreads();
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const int xx = (int)(p % W), yy = (int)((p / W) % H);
+    const size_t b = p / ((size_t)W * H);
+    float acc = bias ? bias[0] : 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int y = yy + ky - 1;
+        if (y < 0 || y >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xc = xx + kx - 1;
+            if (xc < 0 || xc >= W) continue;
+            const float4* px = x + ((b * H + y) * W + xc) * C4;
+            const float4* wt = (const float4*)(wl + (ky * 3 + kx) * C);
+            for (int c = 0; c < C4; ++c) {
+                const float4 v = px[c], q = wt[c];
+                acc += v.x * q.x + v.y * q.y + v.z * q.z + v.w * q.w;
+            }
+        }
+    }
+    out[p] = acc;
+}
+
+// dx[b][y][x][c] = sum_taps g[b][y - ky + 1][x - kx + 1] * w[c][ky][kx]
+__global__ __launch_bounds__(256) void conv3x3_c1_dgrad_kernel(const float* __restrict__ g, int H, int W, int C4, const float* __restrict__ w,
+                                                               size_t total, float4* __restrict__ dx) {
+    extern __shared__ float wl[];                  // [9][C]
+    const int C = C4 * 4;
+    for (int i = threadIdx.x; i < 9 * C; i += 256) wl[i] = w[(i % C) * 9 + i / C];
+    __syncthreads();
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const int xx = (int)(p % W), yy = (int)((p / W) % H);
+    const size_t b = p / ((size_t)W * H);
+    float gv[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int y = yy - ky + 1, xc = xx - kx + 1;
+            gv[ky * 3 + kx] = (y >= 0 && y < H && xc >= 0 && xc < W) ? g[(b * H + y) * W + xc] : 0.0f;
+        }
+    for (int c = 0; c < C4; ++c) {
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 q = *(const float4*)(wl + t * C + 4 * c);
+            r.x += gv[t] * q.x, r.y += gv[t] * q.y, r.z += gv[t] * q.z, r.w += gv[t] * q.w;
+        }
+        dx[p * C4 + c] = r;
+    }
+}
+
+// dw[c][tap] = sum_pixels g[pixel] * x[pixel + tap][c], db = sum g: every thread walks a strided set of pixels with 9 x 16
+// accumulators (C <= 16 per pass), waves reduce by shuffles and store one partial row each; a second launch adds the rows in a
+// fixed order (bit-reproducible).
+__global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float4* __restrict__ x, const float* __restrict__ g, int H, int W,
+                                                               int C4, int c4_0, size_t total, float* __restrict__ partials, int row_len) {
+    float acc[9][16];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[t][c] = 0.0f;
+    float gs = 0.0f;
+    const int nc4 = C4 - c4_0 < 4 ? C4 - c4_0 : 4;
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (size_t)gridDim.x * 256) {
+        const float gp = g[p];
+        gs += gp;
+        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        const size_t b = p / ((size_t)W * H);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int y = yy + ky - 1;
+            if (y < 0 || y >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xc = xx + kx - 1;
+                if (xc < 0 || xc >= W) continue;
+                const float4* px = x + ((b * H + y) * W + xc) * C4 + c4_0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c >= nc4) break;
+                    const float4 v = px[c];
+                    acc[ky * 3 + kx][4 * c + 0] += gp * v.x, acc[ky * 3 + kx][4 * c + 1] += gp * v.y;
+                    acc[ky * 3 + kx][4 * c + 2] += gp * v.z, acc[ky * 3 + kx][4 * c + 3] += gp * v.w;
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float v = acc[t][c];
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+            acc[t][c] = v;
+        }
+    for (int m = 32; m >= 1; m >>= 1) gs += __shfl_xor(gs, m);
+    if (lane == 0) {
+        float* o = partials + ((size_t)blockIdx.x * 4 + wave) * row_len;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) o[c * 9 + t] = acc[t][c];           // [c][tap], as the parameter
+        o[144] = gs;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv3x3_c1_wgrad_finalize_kernel(const float* __restrict__ partials, int rows, int row_len, int n_valid,
+                                                                        float* __restrict__ dw, float* __restrict__ db, int write_db) {
+    __shared__ double red[256];
+    const int j = blockIdx.x;                        // one output value per block: 0..143 = dw (this 16-channel pass), 144 = db
+    double s = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) s += (double)partials[(size_t)r * row_len + j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (j < 144) {
+            if (j < n_valid) dw[j] = (float)red[0];
+        } else if (write_db && db) {
+            db[0] = (float)red[0];
+        }
+    }
+}
+
 // [cout][cin][k][k] convolution weights <-> the [cout][kpad] matrix whose columns follow ossid_im2col_stem's order
 // ((ky * k + kx) * cin + c, zero-padded to kpad): the strided stems run as im2col + a 1x1 MFMA convolution.
 __global__ void stem_weight_relayout_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int k,
@@ -913,6 +1054,42 @@ int ossid_seg_bce_iou_fwd(const float* logit, const float* mask, int B, long lon
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(seg_bce_iou_kernel, dim3(bpi, B), dim3(256), 0, s, logit, mask, hw, bpi, prob, dlogit_sum, (double*)workspace);
     hipLaunchKernelGGL(seg_bce_iou_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, B, bpi, hw, out);
+    return ossid_launch_status();
+}
+
+int ossid_conv3x3_c1_fwd(const float* x, int B, int H, int W, int C, const float* w, const float* bias, float* out, void* stream) {
+    if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || C > 1024 || ((uintptr_t)x & 15)) return OSSID_EINVAL;
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(conv3x3_c1_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), (size_t)9 * C * 4, (hipStream_t)stream,
+                       (const float4*)x, H, W, C / 4, w, bias, total, out);
+    return ossid_launch_status();
+}
+
+int ossid_conv3x3_c1_dgrad(const float* g, int B, int H, int W, int C, const float* w, float* dx, void* stream) {
+    if (!g || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || C > 1024 || ((uintptr_t)dx & 15)) return OSSID_EINVAL;
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(conv3x3_c1_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), (size_t)9 * C * 4, (hipStream_t)stream,
+                       g, H, W, C / 4, w, total, (float4*)dx);
+    return ossid_launch_status();
+}
+
+static const int C1_WGRAD_BLOCKS = 1024, C1_WGRAD_ROW = 160;       // 4 waves x 1024 blocks partial rows of 145 (padded) floats
+size_t ossid_conv3x3_c1_wgrad_workspace_bytes(void) { return (size_t)C1_WGRAD_BLOCKS * 4 * C1_WGRAD_ROW * sizeof(float); }
+
+int ossid_conv3x3_c1_wgrad(const float* x, const float* g, int B, int H, int W, int C, void* workspace, size_t workspace_bytes,
+                           float* dw, float* db, void* stream) {
+    if (!x || !g || !dw || !workspace || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || C > 1024 || ((uintptr_t)x & 15))
+        return OSSID_EINVAL;
+    if (workspace_bytes < ossid_conv3x3_c1_wgrad_workspace_bytes()) return OSSID_EINVAL;
+    const size_t total = (size_t)B * H * W;
+    hipStream_t s = (hipStream_t)stream;
+    for (int c4_0 = 0; c4_0 < C / 4; c4_0 += 4) {           // 16 channels per pass (the decoder's layer has 16)
+        hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3(C1_WGRAD_BLOCKS), dim3(256), 0, s, (const float4*)x, g, H, W, C / 4, c4_0, total,
+                           (float*)workspace, C1_WGRAD_ROW);
+        const int n_valid = (C / 4 - c4_0 < 4 ? C / 4 - c4_0 : 4) * 4 * 9;
+        hipLaunchKernelGGL(conv3x3_c1_wgrad_finalize_kernel, dim3(145), dim3(256), 0, s, (const float*)workspace, C1_WGRAD_BLOCKS * 4,
+                           C1_WGRAD_ROW, n_valid, dw + (size_t)c4_0 * 4 * 9, db, c4_0 == 0 ? 1 : 0);
+    }
     return ossid_launch_status();
 }
 

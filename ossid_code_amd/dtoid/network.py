@@ -959,7 +959,7 @@ class Network(nn.Module):
             u, sc, sh = cab(u, getattr(corr, "s%d" % i), getattr(corr, "ns%d" % i), pre=(sc, sh),
                             size=(2 * u.shape[2], 2 * u.shape[3]))
         u, sc, sh = cab(u, corr.s5, corr.ns5, pre=(sc, sh), size=corr.img_size)
-        segmentation = corr.seg_final(T.AffineAct.apply(u, sc, sh, False))
+        segmentation = T.conv3x3_c1(T.AffineAct.apply(u, sc, sh, False), corr.seg_final)      # 16 -> 1: vector-ALU kernels
         if par:
             self._join(s_a, [cls_raw])
             self._join(s_b, [reg_raw])

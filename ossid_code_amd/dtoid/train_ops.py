@@ -987,6 +987,55 @@ class AffineAct(torch.autograd.Function):
         return dx, s[1], s[0], None
 
 
+class Conv3x3C1(torch.autograd.Function):
+    """nn.Conv2d(C, 1, 3, padding=1) on a channels-last x [B,C,H,W] -> [B,1,H,W] (the decoder's seg_final, network.py:362) on the
+    vector-ALU kernels of csrc/train.hip (ossid_conv3x3_c1_*): MIOpen's implicit-GEMM kernels for this one-row layer plus
+    their layout transposes were ~0.7 ms of the step around the loss."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = nhwc(x)
+        B, C, H, W = x.shape
+        wc = w.detach().contiguous()
+        out = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+        with _lib.on_device(x.device):
+            _lib.check(_lib.fn("ossid_conv3x3_c1_fwd")(x.data_ptr(), B, H, W, C, wc.data_ptr(), _p(None if bias is None else bias.detach()),
+                                                       out.data_ptr(), _lib.stream()), "ossid_conv3x3_c1_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dev = x.device
+        g = g.float().contiguous()
+        dx = dw = db = None
+        with _lib.on_device(dev):
+            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                dwb = grad_home(w, w.grad is None)
+                dbb = torch.empty(1, dtype=torch.float32, device=dev)
+                nbytes = _lib.fn("ossid_conv3x3_c1_wgrad_workspace_bytes")()
+
+                def run():
+                    ws = _scratch("c1_wgrad", nbytes, dev)
+                    _lib.check(_lib.fn("ossid_conv3x3_c1_wgrad")(x.data_ptr(), g.data_ptr(), B, H, W, C, ws.data_ptr(), nbytes,
+                                                                 dwb.data_ptr(), dbb.data_ptr(), _lib.stream()), "ossid_conv3x3_c1_wgrad")
+                _wgrad_async([x, g, dwb, dbb], run, dev, weights=(w,))
+                dw, db = _alias(dwb), (dbb if ctx.has_bias else None)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _lib.check(_lib.fn("ossid_conv3x3_c1_dgrad")(g.data_ptr(), B, H, W, C, w.detach().contiguous().data_ptr(), dx.data_ptr(),
+                                                             _lib.stream()), "ossid_conv3x3_c1_dgrad")
+        return dx, dw, db
+
+
+def conv3x3_c1(x, conv):
+    """Apply an nn.Conv2d(C, 1, 3, padding=1) through Conv3x3C1."""
+    return Conv3x3C1.apply(x, conv.weight, conv.bias)
+
+
 def bn_act_train(x, bn, relu=False):
     """Training-mode BatchNorm (+ReLU) with a materialised output, on this repo's passes: column sums -> fold -> apply."""
     B, C, H, W = x.shape

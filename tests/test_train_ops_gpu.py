@@ -2,6 +2,8 @@
 (ossid_code_amd/dtoid/train_ops.py), each against a plain PyTorch restatement of the same op (float64 on the CPU where a
 sum is long). fp32 throughout; summation orders differ (MFMA tiles / split-K slabs vs torch), tolerances are stated at
 each check, relative to the largest magnitude of the expected tensor."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -352,3 +354,32 @@ def test_side_stream_probe_returns_streams_that_run_beside_the_main_one(hiplib):
     ev_s.synchronize()
     assert not ev_m.query()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 16, 37, 45), (1, 16, 480, 640), (3, 8, 5, 7), (2, 32, 9, 11), (1, 4, 1, 3)])
+def test_one_output_channel_conv3x3_matches_torch(hiplib, B, C, H, W):
+    """nn.Conv2d(C, 1, 3, padding=1) in training (the decoder's seg_final 16 -> 1, network.py:362) on ossid_conv3x3_c1_*:
+    output, input gradient, weight and bias gradient against torch autograd in float64 (the kernels sum in a fixed order:
+    two runs are bit-identical)."""
+    torch.manual_seed(B * 1000 + C)
+    conv = torch.nn.Conv2d(C, 1, 3, padding=1).cuda()
+    x = cl(torch.randn(B, C, H, W))
+    go = torch.randn(B, 1, H, W, device="cuda")
+    xr = x.double().detach().requires_grad_(True)
+    ref = copy.deepcopy(conv).double()
+    yr = ref(xr)
+    yr.backward(go.double())
+    outs = []
+    for _ in range(2):
+        conv.weight.grad = conv.bias.grad = None
+        xm = x.clone().requires_grad_(True)
+        y = T.conv3x3_c1(xm, conv)
+        y.backward(go)
+        torch.cuda.synchronize()
+        outs.append((y.detach().clone(), xm.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()))
+    y, dx, dw, db = outs[0]
+    assert y.shape == (B, 1, H, W) and dw.shape == conv.weight.shape and db.shape == (1,)
+    assert rel(y, yr) < 2e-6 and rel(dx, xr.grad) < 2e-6
+    assert rel(dw, ref.weight.grad) < 1e-5 and rel(db, ref.bias.grad) < 1e-5
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
