@@ -38,34 +38,61 @@ static inline int ossid_ensure_dyn_lds(const void* fn, size_t bytes, OssidLdsAtt
         if (rc_ != OSSID_OK) return rc_;                                          \
     } while (0)
 
-// Winograd F(2x2, 3x3) filter transform U = G g G^T (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]) for the packed layout of
-// csrc/wino.hip, [ceil(M/32)][K/8][16 xi][64 lanes][4]: element i -> lane (c,h) of (mt, kb, xi) holds
-// U_xi[32mt+c][8kb+4h+0..3]. w is the forward weight [Cout][Cin][3][3]; dgrad != 0 packs the data gradient's layer
-// (M = Cin output channels, K = Cout reduction channels, filter rotated by 180 degrees).
+// Winograd F(2x2, 3x3) filter transform U = G g G^T (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]) in the packed layout of
+// csrc/wino.hip. w is the forward weight [Cout][Cin][3][3]; dgrad != 0 packs the data gradient's layer (M = Cin output
+// channels, K = Cout reduction channels, filter rotated by 180 degrees). Element i is one 16-byte unit.
+//   split-bf16 form (default):  [ceil(M/32)][K/16][16 xi][2 parts][64 lanes][8 bf16] -- lane (c,h) of (mt, chunk, xi, part)
+//       holds U_xi[32mt+c][16chunk+8h+0..7] as bf16: part 0 = hi = bf16(U), part 1 = lo = bf16(U - hi); the kernel forms
+//       U*V ~ hi*vh + hi*vl + lo*vh on v_mfma_f32_32x32x16_bf16 (the dropped lo*vl term is ~2^-16 of the product)
+//   exact-f32 form (-DOSSID_WINO_F32): [ceil(M/32)][K/8][16 xi][64 lanes][4 floats] -- lane (c,h) of (mt, kb, xi) holds
+//       U_xi[32mt+c][8kb+4h+0..3]
+// Both have the same size (ossid_conv_wino_packed_floats).
+__device__ __forceinline__ float ossid_wino_u(const float* __restrict__ w, int Cout, int Cin, int dgrad, int m, int k, int xi) {
+    const int ti = xi >> 2, tj = xi & 3;
+    const float* g = dgrad ? w + ((size_t)k * Cin + m) * 9 : w + ((size_t)m * Cin + k) * 9;
+    float t[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const float g0 = dgrad ? g[8 - b] : g[b], g1 = dgrad ? g[5 - b] : g[3 + b], g2 = dgrad ? g[2 - b] : g[6 + b];
+        t[b] = ti == 0 ? g0 : (ti == 1 ? 0.5f * (g0 + g1 + g2) : (ti == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+    }
+    return tj == 0 ? t[0] : (tj == 1 ? 0.5f * (t[0] + t[1] + t[2]) : (tj == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2]));
+}
+
 __device__ __forceinline__ float4 ossid_wino_pack_quad(const float* __restrict__ w, int Cout, int Cin, int dgrad, size_t i) {
     const int lane = (int)(i & 63);
     size_t r = i >> 6;
+    const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
+#ifndef OSSID_WINO_F32
+    const int part = (int)(r & 1);
+    r >>= 1;
     const int xi = (int)(r & 15);
     r >>= 4;
-    const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout, KB = K / 8;
+    const int KC = K / 16;
+    const int ch = (int)(r % KC), mt = (int)(r / KC);
+    const int m = mt * 32 + (lane & 31), k0 = ch * 16 + 8 * (lane >> 5);
+    union {
+        __bf16 hv[8];
+        float4 f;
+    } o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float u = m < M ? ossid_wino_u(w, Cout, Cin, dgrad, m, k0 + e, xi) : 0.0f;
+        const __bf16 hi = (__bf16)u;
+        o.hv[e] = part == 0 ? hi : (__bf16)(u - (float)hi);
+    }
+    return o.f;
+#else
+    const int xi = (int)(r & 15);
+    r >>= 4;
+    const int KB = K / 8;
     const int kb = (int)(r % KB), mt = (int)(r / KB);
     const int m = mt * 32 + (lane & 31), k0 = kb * 8 + 4 * (lane >> 5);
-    const int ti = xi >> 2, tj = xi & 3;
     float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        v[e] = 0.0f;
-        if (m >= M) continue;
-        const float* g = dgrad ? w + ((size_t)(k0 + e) * Cin + m) * 9 : w + ((size_t)m * Cin + k0 + e) * 9;
-        float t[3];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const float g0 = dgrad ? g[8 - b] : g[b], g1 = dgrad ? g[5 - b] : g[3 + b], g2 = dgrad ? g[2 - b] : g[6 + b];
-            t[b] = ti == 0 ? g0 : (ti == 1 ? 0.5f * (g0 + g1 + g2) : (ti == 2 ? 0.5f * (g0 - g1 + g2) : g2));
-        }
-        v[e] = tj == 0 ? t[0] : (tj == 1 ? 0.5f * (t[0] + t[1] + t[2]) : (tj == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2]));
-    }
+    for (int e = 0; e < 4; ++e) v[e] = m < M ? ossid_wino_u(w, Cout, Cin, dgrad, m, k0 + e, xi) : 0.0f;
     return make_float4(v[0], v[1], v[2], v[3]);
+#endif
 }
 
 // 64-lane wave reductions (xor butterfly; every lane ends with the result)

@@ -33,6 +33,8 @@ namespace {
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));      // (vector arithmetic lowers to v_pk_add_f32 with neg modifiers)
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ v16f mfma(float a, float b, v16f c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -222,12 +224,33 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
         // a - b as fma(b, -1, a): exact, and one v_pk_fma_f32 per two floats where a plain subtraction is scalarised
         const v4f m1 = {-1.f, -1.f, -1.f, -1.f};
         auto sub = [&](v4f x, v4f y) { return __builtin_elementwise_fma(y, m1, x); };
+#ifndef OSSID_WINO_F32
+        // split-bf16: V = vh + vl with vh = bf16(V), vl = bf16(V - vh). LDS unit (xi, tile) = 4 x 16 bytes: slot part * 2 + khalf
+        // holds channels 8 khalf .. 8 khalf + 7 of part (hi / lo) as bf16 -- one ds_read_b128 per MFMA operand. This thread
+        // owns channels 4j .. 4j + 3: 8 bytes at (j & 1) * 8 of slots (0, j >> 1) and (1, j >> 1).
+        char* ob = (char*)(vb + (size_t)buf * VBUF + (size_t)tl * F4) + (j >> 1) * 16 + (j & 1) * 8;
+        auto put = [&](int xi, v4f v) {
+            const v4bf hi = __builtin_convertvector(v, v4bf);
+            const v4f hf = __builtin_convertvector(hi, v4f);
+            const v4bf lo = __builtin_convertvector(v - hf, v4bf);
+            char* p = ob + (size_t)xi * 32 * F4 * 16;
+            *(v4bf*)p = hi;
+            *(v4bf*)(p + 32) = lo;
+        };
+        auto cols = [&](int i, const v4f (&R)[4]) {
+            put(i * 4 + 0, sub(R[0], R[2]));
+            put(i * 4 + 1, R[1] + R[2]);
+            put(i * 4 + 2, sub(R[2], R[1]));
+            put(i * 4 + 3, sub(R[1], R[3]));
+        };
+#else
         auto cols = [&](int i, const v4f (&R)[4]) {
             o[(size_t)(i * 4 + 0) * 32 * F4] = sub(R[0], R[2]);
             o[(size_t)(i * 4 + 1) * 32 * F4] = R[1] + R[2];
             o[(size_t)(i * 4 + 2) * 32 * F4] = sub(R[2], R[1]);
             o[(size_t)(i * 4 + 3) * 32 * F4] = sub(R[1], R[3]);
         };
+#endif
         v4f Ra[4], Rb[4];
         if (ih == 0) {            // (two code paths, not selects: ih is wave-uniform)
             asm volatile("" ::: "memory");
@@ -247,13 +270,8 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     // ---- MFMA role: channel tile wm of the group, transform rows i in {2wx, 2wx+1}, the group's 32 tiles -----------
     const int co_tile = by * 2 + wm;
     const bool active = co_tile < A.n_cotiles;
-    const int nq = (A.Cin / 8) * 16;                              // weight quads per channel tile
+    const int nq = (A.Cin / 8) * 16;                              // 16-byte weight units per channel tile (either layout)
     const float4* W4 = A.wpk + (size_t)(active ? co_tile : 0) * nq * 64;      // (scalar; + lane at the load)
-    // prefetch group gi = (chunk, 8-channel block kb, half xh of the wave's 8 positions): 4 quads, 16 MFMAs
-    auto quad_of = [&](int gi, int i) {
-        const int q = ((gi >> 1) * 16) + 8 * wx + 4 * (gi & 1) + i;
-        return q < nq ? q : nq - 1;
-    };
     v16f acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -264,6 +282,56 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     const int ch0 = (int)((long long)slice * nchunks / ks), ch1 = (int)((long long)(slice + 1) * nchunks / ks);
     stage_load(ch0 * KCH);
     transform_write(ch0 & 1);
+#ifndef OSSID_WINO_F32
+    // ---- split-bf16 core: per 16-channel chunk and transform position ONE v_mfma_f32_32x32x16_bf16 triple
+    // (lo*vh + hi*vl + hi*vh, small terms first) instead of eight v_mfma_f32_32x32x2_f32. Weight units of position xi of
+    // chunk ch: ((ch * 16 + xi) * 2 + part) * 64 + lane. ONE register set of two positions (hi and lo of each: four 16-byte
+    // loads), refilled in place: the pair of the position two steps ahead is requested right behind the three MFMAs that
+    // consumed this one (the accumulators, the staged patch and the operands leave room for no more: 256 registers).
+    auto unit_of = [&](int p, int part) {       // p = running position index (8 per chunk)
+        const int ch = p >> 3, xi = 8 * wx + (p & 7);
+        const int u = (ch * 16 + xi) * 2 + part;
+        return u < nq ? u : nq - 1;
+    };
+    float4 wq[2][2];                            // [position parity][hi, lo]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) wq[i][k] = W4[(size_t)unit_of(8 * ch0 + i, k) * 64 + lane];
+    __syncthreads();
+#ifdef OSSID_TIMING
+    tstamp[1] = tnow();
+    cstamp[0] = cnow();
+#endif
+    int p0 = 8 * ch0;
+#pragma unroll 1
+    for (int ch = ch0; ch < ch1; ++ch) {
+        if (ch + 1 < ch1) stage_load((ch + 1) * KCH);             // in flight under this chunk's MFMAs
+        const float4* pb = vb + (size_t)(ch & 1) * VBUF + (size_t)(8 * wx * 32 + c) * F4 + h;
+        float4 bh = pb[0], bl = pb[2];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const v8bf ahi = __builtin_bit_cast(v8bf, wq[e & 1][0]), alo = __builtin_bit_cast(v8bf, wq[e & 1][1]);
+            const v8bf vh = __builtin_bit_cast(v8bf, bh), vl = __builtin_bit_cast(v8bf, bl);
+            const int en = e < 7 ? e + 1 : e;               // next position's operands are read under this one's MFMAs
+            bh = pb[(size_t)en * 32 * F4], bl = pb[(size_t)en * 32 * F4 + 2];
+            acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, vh, acc[e], 0, 0, 0);
+            acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, vl, acc[e], 0, 0, 0);
+            acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, vh, acc[e], 0, 0, 0);
+            wq[e & 1][0] = W4[(size_t)unit_of(p0 + e + 2, 0) * 64 + lane];
+            wq[e & 1][1] = W4[(size_t)unit_of(p0 + e + 2, 1) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);      // keep this order: the compiler would sink the loads to their use
+        }
+        p0 += 8;
+        if (ch + 1 < ch1) transform_write((ch + 1) & 1);
+        __syncthreads();
+    }
+#else
+    // prefetch group gi = (chunk, 8-channel block kb, half xh of the wave's 8 positions): 4 quads, 16 MFMAs
+    auto quad_of = [&](int gi, int i) {
+        const int q = ((gi >> 1) * 16) + 8 * wx + 4 * (gi & 1) + i;
+        return q < nq ? q : nq - 1;
+    };
     // weight quads: ONE register set, refilled in place -- the load of the quad four steps ahead (the next group's) is
     // issued right behind the four MFMAs that consumed this one, so every quad still has 16 MFMAs of cover
     float4 cur[4];
@@ -304,6 +372,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
         if (ch + 1 < ch1) transform_write((ch + 1) & 1);
         __syncthreads();
     }
+#endif
 
 #ifdef OSSID_TIMING
     cstamp[1] = cnow();
