@@ -172,7 +172,7 @@ def dtoid_leg(a, dev, dist, world):
             else:
                 m.model.use_graph = old
         torch.cuda.synchronize()
-        return c.flops
+        return c.flops, c.pipe
     mf_fwd = counted(lambda: m.forwardTestTime(test))
     mf_b32 = counted(lambda: m.forwardTestTimeBatch(test32))
     mf_pairs = counted(run_pairs)
@@ -237,7 +237,7 @@ def dtoid_leg(a, dev, dist, world):
     with oslib.count_mfma() as c_ft:
         finetune.finetune_step(m, batch, opt, sync)
     torch.cuda.synchronize()
-    mf_ft = c_ft.flops
+    mf_ft = (c_ft.flops, c_ft.pipe)
     # the nn.Module path (MIOpen convolutions / BatchNorm, torch elementwise) on the same batch, for comparison
     m.model.use_hip_training = False
     try:
@@ -245,10 +245,13 @@ def dtoid_leg(a, dev, dist, world):
     finally:
         m.model.use_hip_training = True
     nominal, executed = dtoid_flops(nt)
-    note = ("frac_mfma = matrix-core multiply-adds the leg ISSUES (counted at the launch sites of one eager pass, "
-            "ossid_code_amd._lib.count_mfma: Winograd layers at their 16 multiplies per 2x2 tile, reassociated layers at "
-            "what they run, weight gradients included) / wall time / 157.3 TFLOP/s: the pipe's own fraction over the "
-            "whole call incl. top-k / NMS / host latency, <= 1 by construction. frac = the reference's NOMINAL flops "
+    note = ("frac_mfma = the MFMA pipe's busy fraction: matrix-core multiply-adds the leg ISSUES (counted at the launch "
+            "sites of one eager pass, ossid_code_amd._lib.count_mfma: Winograd layers at their 16 multiplies per 2x2 tile, "
+            "reassociated layers at what they run, weight gradients included), each launch in units of f32-pipe time -- "
+            "layers on v_mfma_f32_32x32x2_f32 1:1, the split-bf16 Winograd layers (three v_mfma_f32_32x32x16_bf16 per f32 "
+            "product, an instruction with 16x the f32 one's rate) 3/16 -- / wall time / 157.3 TFLOP/s, over the whole "
+            "call incl. top-k / NMS / host latency: <= 1 by construction. achieved_mfma = the same multiply-adds as f32 "
+            "arithmetic / time (mfma_gflop_per_call; pipe-weighted: mfma_pipe_gflop_per_call). frac = the reference's NOMINAL flops "
             "(39.7 + 45.96 n_t GFLOP per frame; 258 GFLOP per finetune sample) / time / peak: a throughput in the "
             "reference's units that can exceed 1 because Winograd and the exact reassociations of DESIGN.md 5 execute "
             "fewer multiplies. frac_executed = nominal minus the reassociations only (kept from round 2). peak = the "
@@ -256,14 +259,17 @@ def dtoid_leg(a, dev, dist, world):
             "(profiles/r02_conv_timeline.txt) -- a property of their LDS / L2 traffic per MFMA, not an external ceiling: "
             "the operands-in-registers probe holds 2.32 GHz (profiles/r02_split_bf16_probe.txt)")
 
+    def mfma_fields(counted_pair, t):
+        arith, pipe = counted_pair
+        return {"achieved_mfma": arith / t / 1e12, "frac_mfma": pipe / t / 1e12 / PEAK_F32_MATRIX_TFLOPS,
+                "mfma_gflop_per_call": arith / 1e9, "mfma_pipe_gflop_per_call": pipe / 1e9}
+
     def roof(flops_nom, flops_exec, t, flops_mfma=None):
         r = {"bound": "mfma", "achieved": flops_nom / t / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
              "frac": flops_nom / t / 1e12 / PEAK_F32_MATRIX_TFLOPS, "achieved_executed": flops_exec / t / 1e12,
              "frac_executed": flops_exec / t / 1e12 / PEAK_F32_MATRIX_TFLOPS, "note": note}
         if flops_mfma is not None:
-            r["achieved_mfma"] = flops_mfma / t / 1e12
-            r["frac_mfma"] = flops_mfma / t / 1e12 / PEAK_F32_MATRIX_TFLOPS
-            r["mfma_gflop_per_call"] = flops_mfma / 1e9
+            r.update(mfma_fields(flops_mfma, t))
         return r
     pair_flops = (39.7e9 + 45.96e9 + 0.36e9) * B32          # + the two template encoders per pair
     # per-pair images: only the decoder reassociations apply (phase convs 4/9, tail rows 2/3)
@@ -299,9 +305,7 @@ def dtoid_leg(a, dev, dist, world):
                          "cpu_baseline": cpu_ft,
                          "roofline": {"bound": "mfma", "achieved": B * 258e9 / t_ft / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
                                       "unit": "TFLOP/s", "frac": B * 258e9 / t_ft / 1e12 / PEAK_F32_MATRIX_TFLOPS,
-                                      "achieved_mfma": mf_ft / t_ft / 1e12,
-                                      "frac_mfma": mf_ft / t_ft / 1e12 / PEAK_F32_MATRIX_TFLOPS,
-                                      "mfma_gflop_per_call": mf_ft / 1e9,
+                                      **mfma_fields(mf_ft, t_ft),
                                       "note": "frac: nominal 258 GFLOP per sample (3 x the 86 GFLOP forward, SURVEY.md 8d) over "
                                               "the whole step incl. losses and optimizer; frac_mfma: the matrix-core work "
                                               "the step issues (forward, data and weight gradients; Winograd layers at 16/36), "

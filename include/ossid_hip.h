@@ -149,7 +149,8 @@ int ossid_dw_xcorr_bwd_x(const float* dout, const float* k, int planes, int H, i
 int ossid_dw_xcorr_bwd_k(const float* x, const float* dout, int planes, int H, int W, float* dk, void* stream);
 
 /* D4, D6-D8  the dense convolutions at test time: the head's 3x3 layers (network.py:102-110, :135-143, :288-326)
- * and the DenseNet-121 blocks of the image backbone (network.py:164-184), channels-last, exact f32 on the matrix cores.
+ * and the DenseNet-121 blocks of the image backbone (network.py:164-184), channels-last, f32 in and out, on the matrix cores
+ * (arithmetic of the reduction: `exact`, below).
  *   out[b][y][x][out_channel_offset + co] = post( act( bias[co] + sum_{ci,tap} w[co][ci][tap] * pre(x)[b][y+dy][x+dx][ci] ) )
  * taps 9: 3x3 / stride 1 / padding 1 (zero halo);  taps 1: 1x1.
  * pre  = x * pre_scale[ci] + pre_shift[ci] (then ReLU if pre_relu) on real pixels only -- eval-mode BatchNorm(+ReLU)
@@ -186,8 +187,23 @@ typedef struct ossid_conv_desc {
      * raw sums of its slices here; -DOSSID_TIMING diagnostic builds write per-wave time stamps. scratch_bytes = its size. */
     void* scratch;
     int64_t scratch_bytes;
+    /* Arithmetic of the reduction in ossid_conv_nhwc_fwd (csrc/conv.hip). 0 (default): every f32 product w*x is formed as
+     * three bf16 matrix-core products (w = hi + lo, x = hi + lo as bf16 pairs; w_lo*x_hi + w_hi*x_lo + w_hi*x_hi accumulated
+     * in f32; the dropped lo*lo term is ~2^-16 of a product): ~5e-6 of the output scale against float64, tests hold 2e-5.
+     * 1: v_mfma_f32_32x32x2_f32, exact f32 products (~1e-6), 3-5x the matrix-pipe time -- for layers whose output feeds a
+     * hard decision that a later pass repeats (the training forward of the ReLU / max-pool networks: a pre-activation that
+     * lands on the other side of zero changes which units the gradient flows through). wpk must be packed for the same
+     * form (ossid_conv_pack_weights_form). A library built with -DOSSID_CONV_F32 runs every launch exact;
+     * ossid_conv_split_bf16() says whether the split form exists. The Winograd entry ignores the field (its own build
+     * switch, below). */
+    int32_t exact;
 } ossid_conv_desc;
+int ossid_conv_split_bf16(void);
 size_t ossid_conv_packed_floats(int Cout, int Cin, int taps);
+/* w [Cout][Cin][taps] -> the operand layout of ossid_conv_nhwc_fwd (common.h, ossid_conv_pack_quad). dgrad != 0: the layer
+ * of the DATA gradient (Cin output channels, Cout reduction channels, taps reversed; needs ossid_conv_packed_floats(Cin,
+ * Cout, taps) floats). exact: the form of the launches that will read it. ossid_conv_pack_weights = (dgrad 0, exact 0). */
+int ossid_conv_pack_weights_form(const float* w, int Cout, int Cin, int taps, int dgrad, int exact, float* wpk, void* stream);
 int ossid_conv_pack_weights(const float* w, int Cout, int Cin, int taps, float* wpk, void* stream);
 int ossid_conv_nhwc_fwd(const ossid_conv_desc* desc_host, void* stream);
 
@@ -197,7 +213,12 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* desc_host, void* stream);
  * layers (network.py:102-110, :135-143, :288-326) and their data gradients in the finetune step. desc->wpk must be the
  * layout of ossid_conv_pack_weights_wino: U = G g G^T of w [Cout][Cin][3][3]; dgrad != 0 packs the data gradient's layer
  * (Cin output channels, Cout reduction channels, filter rotated by 180 degrees; the desc then carries cin = Cout,
- * cout = Cin). The reduction channel count must be a multiple of 16. */
+ * cout = Cin). The reduction channel count must be a multiple of 16.
+ * Arithmetic of the channel reduction: by default every f32 product U*V is formed as three bf16 matrix-core products
+ * (U = hi + lo, V = vh + vl as bf16 pairs; lo*vh + hi*vl + hi*vh accumulated in f32; the dropped lo*vl term is ~2^-16 of
+ * a product): measured 7e-6 of the output scale against float64, tests hold <= 2e-5. A library built with
+ * -DOSSID_WINO_F32 runs the same layout on v_mfma_f32_32x32x2_f32 (1e-6). ossid_conv_wino_split_bf16 says which. */
+int ossid_conv_wino_split_bf16(void);
 size_t ossid_conv_wino_packed_floats(int Cout, int Cin);
 int ossid_conv_pack_weights_wino(const float* w, int Cout, int Cin, int dgrad, float* wpk, void* stream);
 int ossid_conv3x3_wino_fwd(const ossid_conv_desc* desc_host, void* stream);
@@ -359,7 +380,8 @@ int ossid_colsum_finalize(const float* partials, int n_partials, int C, float* s
 
 /* D16  all convolution weights of a training step re-packed in ONE launch (they change every optimizer step): a device
  * table with one row per (layer, layout): kind 0 = the forward layout of ossid_conv_pack_weights, 1 = the data-gradient
- * layout of ossid_conv_pack_weights_dgrad, 2 / 3 = ossid_conv_pack_weights_wino with dgrad = 0 / 1 (taps = 9); first_block = prefix sum of ceil(packed float4 / 256) over the rows before. */
+ * layout of ossid_conv_pack_weights_dgrad, 2 / 3 = ossid_conv_pack_weights_wino with dgrad = 0 / 1 (taps = 9), 4 / 5 = kinds
+ * 0 / 1 for exact launches (ossid_conv_desc::exact); first_block = prefix sum of ceil(packed float4 / 256) over the rows before. */
 typedef struct ossid_pack_row {
     const float* w;
     float* wpk;

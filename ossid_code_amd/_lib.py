@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
                [(n, C.c_int32) for n in ("batch", "height", "width", "cin", "cout", "taps", "act", "pre_relu",
                                          "src_height", "src_width", "in_channel_stride", "out_channel_stride",
                                          "out_channel_offset", "pre_batch_stride")] + [("in_batch_stride", C.c_int64)] + \
-               [("scratch", _vp), ("scratch_bytes", C.c_int64)]
+               [("scratch", _vp), ("scratch_bytes", C.c_int64), ("exact", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -52,6 +52,8 @@ class PackRow(C.Structure):
 
 _PROTOS = {
     "ossid_abi_version": (_i, [C.c_char_p, _i]),
+    "ossid_conv_wino_split_bf16": (_i, []),
+    "ossid_conv_split_bf16": (_i, []),
     "ossid_zephyr_prep_frame_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ossid_zephyr_prep_frame_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ossid_zephyr_prep_model": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
@@ -79,6 +81,7 @@ _PROTOS = {
     "ossid_dw_xcorr_bwd_k": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ossid_conv_packed_floats": (_sz, [_i, _i, _i]),
     "ossid_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "ossid_conv_pack_weights_form": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ossid_conv_nhwc_fwd": (_i, [_vp, _vp]),
     "ossid_seg_tail_packed_floats": (_sz, []),
     "ossid_seg_tail_pack_weights": (_i, [_vp, _vp, _vp]),
@@ -165,7 +168,7 @@ def fn(name):
     f = getattr(lib(), name, None)
     if f is None:
         raise RuntimeError("libossid_hip.so does not export %s -- rebuild the library" % name)
-    g = _counting(f, _MFMA_RULES[name]) if (_MFMA_COUNT is not None and name in _MFMA_RULES) else f
+    g = _counting(f, _MFMA_RULES[name], name) if (_MFMA_COUNT is not None and name in _MFMA_RULES) else f
     if _REC is not None:
         return _REC.wrap(name, f, g)
     return g
@@ -187,7 +190,7 @@ RECORDABLE = frozenset((
     "ossid_conv_nhwc_fwd", "ossid_conv3x3_wino_fwd", "ossid_chan_op", "ossid_bn_fold_fwd", "ossid_bn_fold_bwd",
     "ossid_colsum_finalize", "ossid_conv_wgrad", "ossid_conv_wgrad_group", "ossid_avgpool2_nhwc",
     "ossid_upsample_nearest_bwd_nhwc", "ossid_maxpool_idx_nhwc", "ossid_maxpool_bwd_nhwc", "ossid_dw_add_nhwc",
-    "ossid_dw_bwd_k_nhwc", "ossid_im2col_stem", "ossid_conv_pack_weights", "ossid_conv_pack_weights_dgrad",
+    "ossid_dw_bwd_k_nhwc", "ossid_im2col_stem", "ossid_conv_pack_weights", "ossid_conv_pack_weights_dgrad", "ossid_conv_pack_weights_form",
     "ossid_conv_pack_weights_wino", "ossid_fill_zero", "ossid_resample_taps_nhwc",
     "ossid_stem_weight_relayout"))
 # entry points that only compute sizes / return static data: called through, never stored
@@ -220,8 +223,7 @@ class Seq:
             if rc:
                 raise RuntimeError("%s failed with status %d (replayed sequence)" % (op[3], rc))
             if cnt is not None and op[3] in _MFMA_RULES:
-                cnt.flops += _MFMA_RULES[op[3]](op[1])
-                cnt.launches += 1
+                cnt._add(op[3], _MFMA_RULES[op[3]](op[1]), op[1])
 
 
 class record:
@@ -270,9 +272,21 @@ def recording():
 # matrix-core kernel of this library, the multiply-adds the launch asks the MFMA pipe for on real (unpadded) operands:
 # direct / phase convolutions 2*B*px*Cout*Cin*taps, the Winograd form 16 multiplies per 2x2 output tile and channel pair
 # (not the 36 of the convolution it replaces), weight gradients 2*B*px*Cout*Cin*taps, the decoder tail's first convolution
-# with its merged kernel rows. bench.py divides by the measured time for `roofline.frac_mfma`: the pipe's own fraction, which
-# cannot exceed 1 -- unlike a fraction on the reference's nominal flop count.
+# with its merged kernel rows. Two sums: `.flops` = those multiply-adds as f32 arithmetic, `.pipe` = the same launches in
+# units of the f32 MFMA pipe's TIME: a layer on v_mfma_f32_32x32x2_f32 counts 1:1, a layer on the split-bf16 form (three
+# v_mfma_f32_32x32x16_bf16 products per f32 product, each 16x the f32 instruction's rate: csrc/wino.hip) counts 3/16 -- what it
+# occupies the pipe for. bench.py divides `.pipe` by the measured time and the f32 matrix peak for `roofline.frac_mfma`: the
+# pipe's own busy fraction, which cannot exceed 1 -- unlike a fraction on the reference's nominal flop count.
 _MFMA_COUNT = None
+SPLIT_BF16_PIPE_WEIGHT = 3.0 / 16.0
+
+
+def _pipe_weight(name, args=None):
+    if name in ("ossid_conv3x3_wino_fwd", "ossid_conv3x3_wino_fwd_pair") and lib().ossid_conv_wino_split_bf16():
+        return SPLIT_BF16_PIPE_WEIGHT
+    if name == "ossid_conv_nhwc_fwd" and lib().ossid_conv_split_bf16() and not (args and args[0]._obj.exact):
+        return SPLIT_BF16_PIPE_WEIGHT
+    return 1.0
 
 
 def _conv_flops(args):
@@ -300,21 +314,20 @@ _MFMA_RULES = {
 }
 
 
-def _counting(f, rule):
+def _counting(f, rule, name):
     def call(*args):
         if _MFMA_COUNT is not None:
-            _MFMA_COUNT.flops += rule(args)
-            _MFMA_COUNT.launches += 1
+            _MFMA_COUNT._add(name, rule(args), args)
         return f(*args)
     return call
 
 
 class count_mfma:
-    """Context manager: .flops / .launches of the matrix-core launches issued inside (see above)."""
+    """Context manager: .flops / .pipe / .launches of the matrix-core launches issued inside (see above)."""
 
     def __enter__(self):
         global _MFMA_COUNT
-        self.flops, self.launches, self._outer = 0.0, 0, _MFMA_COUNT
+        self.flops, self.pipe, self.launches, self._outer = 0.0, 0.0, 0, _MFMA_COUNT
         _MFMA_COUNT = self
         return self
 
@@ -323,12 +336,16 @@ class count_mfma:
         _MFMA_COUNT = self._outer
         return False
 
+    def _add(self, name, flops, args=None):
+        self.flops += flops
+        self.pipe += flops * _pipe_weight(name, args)
+        self.launches += 1
+
     @staticmethod
     def add(flops):
         """For matrix-core work this library does not launch itself (a library GEMM on the product path)."""
         if _MFMA_COUNT is not None:
-            _MFMA_COUNT.flops += flops
-            _MFMA_COUNT.launches += 1
+            _MFMA_COUNT._add("", flops)
 
 
 def check(rc, what):

@@ -95,6 +95,58 @@ __device__ __forceinline__ float4 ossid_wino_pack_quad(const float* __restrict__
 #endif
 }
 
+// Direct-convolution weights (csrc/conv.hip): element i = one 16-byte unit of the packed layout of a layer with M output and
+// K reduction channels. Forward (dgrad == 0): M = Cout, K = Cin, value w[m][k][tap]; data gradient: M = Cin, K = Cout,
+// value w[k][m][taps-1-tap] (transposed, rotated by 180 degrees). w is [Cout][Cin][taps].
+//   split-bf16 form (default):  [ceil(M/32)][K/16][taps][2 parts][64 lanes][8 bf16] -- lane (c,h) of (mt, u, tap, part) holds
+//       W[32mt+c][16u+8h+0..7][tap]: part 0 = hi = bf16(W), part 1 = lo = bf16(W - hi)
+//   exact-f32 form (exact != 0; every layer of a -DOSSID_CONV_F32 build): [ceil(M/32)][K/8][taps][64 lanes][4 floats] --
+//       lane (c,h) holds W[32mt+c][8kb+4h+0..3][tap]
+// Both have the same size (ossid_conv_packed_floats).
+#ifdef OSSID_CONV_F32
+#define OSSID_CONV_SB 0
+#else
+#define OSSID_CONV_SB 1
+#endif
+__device__ __forceinline__ float4 ossid_conv_pack_quad(const float* __restrict__ w, int Cout, int Cin, int taps, int dgrad, int exact,
+                                                       size_t i) {
+    const int lane = (int)(i & 63);
+    size_t r = i >> 6;
+    const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
+    auto at = [&](int m, int k, int tap) {
+        return dgrad ? w[((size_t)k * Cin + m) * taps + (taps - 1 - tap)] : w[((size_t)m * Cin + k) * taps + tap];
+    };
+    if (OSSID_CONV_SB && !exact) {
+        const int part = (int)(r & 1);
+        r >>= 1;
+        const int tap = (int)(r % taps);
+        r /= taps;
+        const int KU = K / 16;
+        const int u = (int)(r % KU), mt = (int)(r / KU);
+        const int m = mt * 32 + (lane & 31), k0 = u * 16 + 8 * (lane >> 5);
+        union {
+            __bf16 hv[8];
+            float4 f;
+        } o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = m < M ? at(m, k0 + e, tap) : 0.0f;
+            const __bf16 hi = (__bf16)v;
+            o.hv[e] = part == 0 ? hi : (__bf16)(v - (float)hi);
+        }
+        return o.f;
+    }
+    const int tap = (int)(r % taps);
+    r /= taps;
+    const int KB = K / 8;
+    const int kb = (int)(r % KB), mt = (int)(r / KB);
+    const int m = mt * 32 + (lane & 31), k0 = kb * 8 + 4 * (lane >> 5);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = m < M ? at(m, k0 + e, tap) : 0.0f;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // 64-lane wave reductions (xor butterfly; every lane ends with the result)
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll

@@ -30,9 +30,24 @@
 namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ v16f mfma(float a, float b, v16f c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Split-bf16 arithmetic (kernel template argument SB; chosen per launch, see ossid_conv_desc::exact): every f32 operand is a pair
+// of bf16 values, x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 significant bits together), and a 16-channel slice
+// of the reduction is three v_mfma_f32_32x32x16_bf16 -- w_lo*x_hi + w_hi*x_lo + w_hi*x_hi, accumulated in f32 -- instead of
+// eight v_mfma_f32_32x32x2_f32: 96 pipe cycles instead of 512. The dropped w_lo*x_lo term is ~2^-16 of a product; measured
+// against float64 the results sit at ~5e-6 of the output scale (exact form: ~1e-6), tests hold 2e-5. Weights are split when
+// they are packed (common.h, ossid_conv_pack_quad), activations when they are staged into LDS.
+__device__ __forceinline__ v16f mfma3(const float4& whi, const float4& wlo, const float4& xhi, const float4& xlo, v16f c) {
+    const v8bf ah = __builtin_bit_cast(v8bf, whi), al = __builtin_bit_cast(v8bf, wlo);
+    const v8bf bh = __builtin_bit_cast(v8bf, xhi), bl = __builtin_bit_cast(v8bf, xlo);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
 }
 
 #ifndef OSSID_WPF
@@ -61,6 +76,7 @@ struct ConvArgs {
     int gx, gy, gz;   // logical grid: pixel blocks x channel-tile groups x images (the launch itself is 1-D)
     float scale_h, scale_w;
     float* e_partials;        // -DOSSID_TIMING builds: per-wave time stamps (desc->scratch)
+    int split;                // 1: split-bf16 products (wpk in that layout), 0: exact f32
 };
 
 // Workgroup = 4 waves = WM (channel tiles) x WK (split of the reduction) x WN (pixel groups), each wave NT pixel tiles.
@@ -71,17 +87,19 @@ struct ConvArgs {
 // source pixels (i+a-1, i+a) x (j+b-1, j+b), so each of the four phases (a,b) is a 2x2 convolution of the SOURCE with
 // row/column-merged weights -- 4/9 of the multiply-adds of convolving the up-sampled image (network.py:354-356). Geometry
 // (H, W, pixel tiles, patch) is the source's; a block's group index carries the phase; outputs go to [2H][2W].
-template <int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
+template <bool SB, int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
 __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     constexpr int WN = 4 / (WM * WK);
     constexpr int BPX = WN * NT * 32;
     constexpr int F4 = KCH / 4;                 // float4 per patch position
     constexpr int F4P = F4 + OSSID_LDS_PAD;     // ... and its stride in LDS
-    constexpr int NKB = KCH / 8 / WK;           // 8-channel blocks of a chunk handled by one wave
+    constexpr int UNIT = SB ? 16 : 8;           // reduction channels per weight unit (one float4 per lane; hi + lo: two)
+    constexpr int WPQ = SB ? 2 : 1;             // float4 per weight unit and lane
+    constexpr int NKB = KCH / UNIT / WK;        // units of a chunk handled by one wave
     constexpr int KY = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1);   // prefetch groups per channel block (one kernel row each)
     constexpr int GQ = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : (NKB >= 2 ? 2 : 1));   // weight quads per prefetch group
     constexpr int GPC = TAPS == 9 ? NKB * 3 : (TAPS == 4 ? NKB * 2 : NKB / GQ);   // groups per chunk per wave
-    static_assert(WM * WK * WN == 4 && KCH % (8 * WK) == 0 && 256 % F4 == 0, "bad tiling");
+    static_assert(WM * WK * WN == 4 && KCH % (UNIT * WK) == 0 && 256 % F4 == 0, "bad tiling");
     extern __shared__ __attribute__((aligned(16))) float4 patch[];   // [2][buf_pos][F4P]
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     // the wave id is uniform, and the compiler must KNOW it: the weight-quad index (channel tile, chunk, tap) is then scalar
@@ -191,7 +209,10 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
             const int sx = (A.Ws == W) ? xx : min((int)floorf((float)xx * A.scale_w), A.Ws - 1);
             goff[e] = ok ? ((sy * A.Ws + sx) * A.in_cs + 4 * j) : -1;
         }
-        lidx[e] = pos < npos ? pos * F4P + j : -1;
+        // LDS slot of the staged quad. f32: float4 j of the position. Split form: per position and 16-channel unit 64
+        // bytes [hi ch 0-7][hi ch 8-15][lo ch 0-7][lo ch 8-15] (an MFMA operand = one ds_read_b128); this thread's four
+        // channels are half of one of those pieces: index in 8-byte units of its hi half, the lo half sits 4 further
+        lidx[e] = pos >= npos ? -1 : (SB ? pos * F4P * 2 + (j >> 2) * 8 + ((j >> 1) & 1) * 2 + (j & 1) : pos * F4P + j);
     }
 
     // this lane's pixel in each of its NT tiles: patch position of tap (0,0), output pixel index (or -1)
@@ -222,8 +243,8 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
 
     const int co_tile = by * WM + wm;
     const bool active = co_tile < A.n_cotiles;
-    const int nq = (A.Cin / 8) * TAPS;                          // weight quads per channel tile
-    const float4* W4 = A.wpk + ((size_t)phase * A.n_cotiles + (active ? co_tile : 0)) * nq * 64;     // (+ lane at the load)
+    const int nq = (A.Cin / UNIT) * TAPS;                       // weight units per channel tile
+    const float4* W4 = A.wpk + ((size_t)phase * A.n_cotiles + (active ? co_tile : 0)) * nq * WPQ * 64;     // (+ lane at the load)
 
     v16f acc[NT];
     {
@@ -269,9 +290,29 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
                 st[e] = v;
             }
         }
+        if constexpr (SB) {
+            uint2* p2 = (uint2*)(patch + (size_t)buf * A.buf_pos * F4P);
 #pragma unroll
-        for (int e = 0; e < NLD; ++e)
-            if (lidx[e] >= 0) patch[(size_t)buf * A.buf_pos * F4P + lidx[e]] = st[e];
+            for (int e = 0; e < NLD; ++e) {
+                if (lidx[e] < 0) continue;
+                const float v[4] = {st[e].x, st[e].y, st[e].z, st[e].w};
+                union {
+                    __bf16 b[4];
+                    uint2 u;
+                } hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    hi.b[i] = (__bf16)v[i];
+                    lo.b[i] = (__bf16)(v[i] - (float)hi.b[i]);
+                }
+                p2[lidx[e]] = hi.u;
+                p2[lidx[e] + 4] = lo.u;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NLD; ++e)
+                if (lidx[e] >= 0) patch[(size_t)buf * A.buf_pos * F4P + lidx[e]] = st[e];
+        }
     };
 
     // weight quads of prefetch group gi (a per-wave linear counter over (chunk, channel block, kernel row))
@@ -279,13 +320,13 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         int q;
         if (TAPS == 9) {
             const int ky = gi % 3, kbl = (gi / 3) % NKB, ch = gi / (3 * NKB);
-            q = ((ch * (KCH / 8) + wk * NKB + kbl) * 9) + ky * 3 + i;
+            q = ((ch * (KCH / UNIT) + wk * NKB + kbl) * 9) + ky * 3 + i;
         } else if (TAPS == 4) {
             const int r = gi % 2, kbl = (gi / 2) % NKB, ch = gi / (2 * NKB);
-            q = ((ch * (KCH / 8) + wk * NKB + kbl) * 4) + r * 2 + i;
+            q = ((ch * (KCH / UNIT) + wk * NKB + kbl) * 4) + r * 2 + i;
         } else {
             const int g = gi % GPC, ch = gi / GPC;
-            q = ch * (KCH / 8) + wk * NKB + g * GQ + i;
+            q = ch * (KCH / UNIT) + wk * NKB + g * GQ + i;
         }
         return q < nq ? q : nq - 1;
     };
@@ -295,12 +336,17 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     stage_write(0);
     // weight quads ride PF prefetch groups ahead of their MFMAs in a register ring (loads return in issue order, so
     // a wait on a weight quad also waits for every staging load issued before it: PF groups of MFMAs cover both)
-    constexpr int PF = OSSID_WPF;
-    float4 wq[PF + 1][GQ];
+    // (split form: a group's MFMAs take 96 cycles per unit and pixel tile instead of 512, so the ring is deeper where a
+    // group is short -- the distance has to cover an L2 round trip either way)
+    constexpr int GROUP_CYCLES = GQ * NT * (SB ? 96 : 512);
+    constexpr int PF = !SB ? OSSID_WPF : (GROUP_CYCLES >= 768 ? 1 : (GROUP_CYCLES >= 384 ? 2 : 3));
+    float4 wq[PF + 1][GQ][WPQ];
 #pragma unroll
     for (int d = 0; d < PF; ++d)
 #pragma unroll
-        for (int i = 0; i < GQ; ++i) wq[d][i] = W4[(size_t)quad_of(d, i) * 64 + lane];
+        for (int i = 0; i < GQ; ++i)
+#pragma unroll
+            for (int k = 0; k < WPQ; ++k) wq[d][i][k] = W4[((size_t)quad_of(d, i) * WPQ + k) * 64 + lane];
     __syncthreads();
 #ifdef OSSID_TIMING
     tstamp[1] = tnow();
@@ -315,30 +361,42 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
 #pragma unroll
         for (int g = 0; g < GPC; ++g) {
 #pragma unroll
-            for (int i = 0; i < GQ; ++i) wq[PF][i] = W4[(size_t)quad_of(gi + PF, i) * 64 + lane];
+            for (int i = 0; i < GQ; ++i)
+#pragma unroll
+                for (int k = 0; k < WPQ; ++k) wq[PF][i][k] = W4[((size_t)quad_of(gi + PF, i) * WPQ + k) * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < GQ; ++i) {
                 // (a workgroup's spare waves -- channel tiles past the last -- run the same MFMAs on tile 0's weights and
                 // store nothing: a per-wave branch here would put the accumulators through VGPR<->AGPR copies and a
                 // matrix-pipe drain around every group)
-                const int kb = wk * NKB + (TAPS == 9 ? g / 3 : (TAPS == 4 ? g / 2 : g * GQ + i));   // 8-channel block inside the chunk
+                const int kb = wk * NKB + (TAPS == 9 ? g / 3 : (TAPS == 4 ? g / 2 : g * GQ + i));   // unit inside the chunk
                 const int toff = TAPS == 9 ? (g % 3) * PW + i : (TAPS == 4 ? (ph_a + g % 2) * PW + ph_b + i : 0);
-                const float4 a = wq[0][i];
+                if constexpr (SB) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float4 bq = pb[(size_t)(pos0[t] + toff) * F4P + 2 * kb];
-                    acc[t] = mfma(a.x, bq.x, acc[t]);
-                    acc[t] = mfma(a.y, bq.y, acc[t]);
-                    acc[t] = mfma(a.z, bq.z, acc[t]);
-                    acc[t] = mfma(a.w, bq.w, acc[t]);
+                    for (int t = 0; t < NT; ++t) {
+                        const float4* px = pb + (size_t)(pos0[t] + toff) * F4P + 4 * kb;
+                        acc[t] = mfma3(wq[0][i][0], wq[0][i][WPQ - 1], px[0], px[2], acc[t]);
+                    }
+                } else {
+                    const float4 a = wq[0][i][0];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float4 bq = pb[(size_t)(pos0[t] + toff) * F4P + 2 * kb];
+                        acc[t] = mfma(a.x, bq.x, acc[t]);
+                        acc[t] = mfma(a.y, bq.y, acc[t]);
+                        acc[t] = mfma(a.z, bq.z, acc[t]);
+                        acc[t] = mfma(a.w, bq.w, acc[t]);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int d = 0; d < PF; ++d)
 #pragma unroll
-                for (int i = 0; i < GQ; ++i) wq[d][i] = wq[d + 1][i];
+                for (int i = 0; i < GQ; ++i)
+#pragma unroll
+                    for (int k = 0; k < WPQ; ++k) wq[d][i][k] = wq[d + 1][i][k];
             ++gi;
         }
         if (ch + 1 < nchunks) stage_write((ch + 1) & 1);
@@ -417,25 +475,15 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
 }
 
 // weight repack on the device: w [Cout][Cin][taps] (torch layout, taps = kh*kw) -> wpk (see the file header)
-__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, int Cout, int Cin, int taps,
-                                                        float4* __restrict__ wpk, size_t total) {
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, int dgrad,
+                                                        int exact, float4* __restrict__ wpk, size_t total) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int lane = i & 63;
-    size_t r = i >> 6;
-    const int tap = r % taps;
-    r /= taps;
-    const int kb = r % (Cin / 8);
-    const int mt = r / (Cin / 8);
-    const int co = mt * 32 + (lane & 31), ci = kb * 8 + 4 * (lane >> 5);
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (co < Cout) ? w[((size_t)co * Cin + ci + e) * taps + tap] : 0.0f;
-    wpk[i] = make_float4(v[0], v[1], v[2], v[3]);
+    wpk[i] = ossid_conv_pack_quad(w, Cout, Cin, taps, dgrad, exact, i);
 }
 
-template <int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
-int launch_conv(ConvArgs a, int B, hipStream_t s) {
+template <bool SB, int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
+int launch_conv_form(ConvArgs a, int B, hipStream_t s) {
     constexpr int WN = 4 / (WM * WK), BPX = WN * NT * 32, F4 = KCH / 4;
     // a ragged last chunk (Cin no multiple of KCH) stages zeros past Cin and clamps the weight quads: any variant, Cin % 8 == 0
     if (a.Cin % KCH && (a.Cin % 8 != 0 || KCH < 32)) return OSSID_EINVAL;
@@ -463,7 +511,7 @@ int launch_conv(ConvArgs a, int B, hipStream_t s) {
     size_t lds = (size_t)2 * a.buf_pos * (F4 + OSSID_LDS_PAD) * 16;
     const size_t red = WK > 1 ? (size_t)WK * (WM * WN) * NT * 16 * 64 * 4 : 0;
     if (red > lds) lds = red;
-    auto kern0 = conv_nhwc_kernel<WM, WK, NT, ROWSEG, NLD, TAPS, KCH>;
+    auto kern0 = conv_nhwc_kernel<SB, WM, WK, NT, ROWSEG, NLD, TAPS, KCH>;
     OSSID_ENSURE_LDS(kern0, lds);
     a.gx = nblk, a.gy = (a.n_cotiles + WM - 1) / WM * (TAPS == 4 ? 4 : 1), a.gz = B;
     const long P = (long)a.gx * a.gz;
@@ -477,20 +525,36 @@ int launch_conv(ConvArgs a, int B, hipStream_t s) {
     return ossid_launch_status();
 }
 
+// a.split picks the arithmetic; every tiling exists in both forms except where a wave's share of a chunk would be half a
+// 16-channel unit (KCH / WK == 8: the caller names the split form's tiling separately)
+template <int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
+int launch_conv(const ConvArgs& a, int B, hipStream_t s) {
+    if constexpr (KCH % (16 * WK) == 0) {
+        if (a.split) return launch_conv_form<true, WM, WK, NT, ROWSEG, NLD, TAPS, KCH>(a, B, s);
+    }
+    return launch_conv_form<false, WM, WK, NT, ROWSEG, NLD, TAPS, KCH>(a, B, s);
+}
+
 }  // namespace
 
 extern "C" {
+
+int ossid_conv_split_bf16(void) { return OSSID_CONV_SB; }
 
 size_t ossid_conv_packed_floats(int Cout, int Cin, int taps) {
     return (size_t)((Cout + 31) / 32) * (Cin / 8) * taps * 64 * 4;
 }
 
-int ossid_conv_pack_weights(const float* w, int Cout, int Cin, int taps, float* wpk, void* stream) {
-    if (!w || !wpk || Cout <= 0 || Cin <= 0 || Cin % 16 || (taps != 1 && taps != 9 && taps != 4)) return OSSID_EINVAL;
-    const size_t total = ossid_conv_packed_floats(Cout, Cin, taps) / 4;
+int ossid_conv_pack_weights_form(const float* w, int Cout, int Cin, int taps, int dgrad, int exact, float* wpk, void* stream) {
+    if (!w || !wpk || Cout <= 0 || Cin <= 0 || (dgrad ? Cout : Cin) % 16 || (taps != 1 && taps != 9 && taps != 4)) return OSSID_EINVAL;
+    const size_t total = (dgrad ? ossid_conv_packed_floats(Cin, Cout, taps) : ossid_conv_packed_floats(Cout, Cin, taps)) / 4;
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       Cout, Cin, taps, (float4*)wpk, total);
+                       Cout, Cin, taps, dgrad ? 1 : 0, exact ? 1 : 0, (float4*)wpk, total);
     return ossid_launch_status();
+}
+
+int ossid_conv_pack_weights(const float* w, int Cout, int Cin, int taps, float* wpk, void* stream) {
+    return ossid_conv_pack_weights_form(w, Cout, Cin, taps, 0, 0, wpk, stream);
 }
 
 int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
@@ -515,6 +579,7 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
         return OSSID_EINVAL;
     a.scale_h = (float)a.Hs / (float)H, a.scale_w = (float)a.Ws / (float)W;
     a.e_partials = (float*)d->scratch;       // (-DOSSID_TIMING builds only: per-wave time stamps)
+    a.split = (OSSID_CONV_SB && !d->exact) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int tiles = a.n_cotiles;
     const long px = (long)B * H * W;
@@ -588,6 +653,7 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
         // two channel tiles x 32 pixels, the reduction split over two waves: measured 5-8 % faster than one tile split
         // over four on the batch-8 head layers (256..640 -> 256/512 at 29x39), fewer partial tiles through LDS
         if (exp_variant != 5 && tiles >= 2) return launch_conv<2, 2, 1, false, 6, 9, 32>(a, B, s);
+        if (a.split) return launch_conv<1, 4, 1, false, 12, 9, 64>(a, B, s);   // a wave's share of a chunk must be a whole 16-channel unit
         return launch_conv<1, 4, 1, false, 6, 9, 32>(a, B, s);
     }
 #define OSSID_CONV(WM_, NT_)                                                                                         \

@@ -334,33 +334,13 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float4* __restr
     dsrc[i] = s;
 }
 
-// =====================================================================================================================
-// weights for the data gradient: the convolution dx = conv(dy, W') with W'[ci][co][tap] = W[co][ci][taps-1-tap]
-// (transposed, rotated by 180 degrees), packed exactly as pack_conv_kernel packs a [Cout' = Cin][Cin' = Cout] layer
-__global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict__ w, int Cout, int Cin, int taps,
-                                                         float4* __restrict__ wpk, size_t total) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int lane = i & 63;
-    size_t r = i >> 6;
-    const int tap = r % taps;
-    r /= taps;
-    const int kb = r % (Cout / 8);                  // blocks of 8 "input" channels of the transposed layer = co
-    const int mt = r / (Cout / 8);                  // tiles of 32 "output" channels = ci
-    const int ci = mt * 32 + (lane & 31), co = kb * 8 + 4 * (lane >> 5);
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (ci < Cin) ? w[((size_t)(co + e) * Cin + ci) * taps + (taps - 1 - tap)] : 0.0f;
-    wpk[i] = make_float4(v[0], v[1], v[2], v[3]);
-}
-
 // every convolution weight of the training step packed in ONE launch (forward and data-gradient layouts): `table` has
 // one row per (layer, layout): {w, wpk, first block, Cout, Cin, taps, kind}; a block finds its row by binary search
 struct PackRow {
     const float* w;
     float4* wpk;
     long long first_block;      // prefix sum of blocks (256 float4 each)
-    int Cout, Cin, taps, kind;  // kind 0: forward layout, 1: data-gradient layout, 2 / 3: their Winograd forms
+    int Cout, Cin, taps, kind;  // kind 0: forward layout, 1: data-gradient layout, 2 / 3: their Winograd forms, 4 / 5: 0 / 1 for exact-f32 launches
 };
 
 __global__ __launch_bounds__(256) void pack_all_kernel(const PackRow* __restrict__ table, int n_rows) {
@@ -372,32 +352,18 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackRow* __restrict
     }
     const PackRow R = table[lo];
     const size_t i = (size_t)(b - R.first_block) * 256 + threadIdx.x;
-    if (R.kind >= 2) {      // Winograd layouts (csrc/wino.hip): 16 transform positions per (channel tile, 8-channel block)
+    if (R.kind == 2 || R.kind == 3) {      // Winograd layouts (csrc/wino.hip): 16 transform positions per (channel tile, 8-channel block)
         const int K8 = (R.kind == 2 ? R.Cin : R.Cout) / 8, M32 = ((R.kind == 2 ? R.Cout : R.Cin) + 31) / 32;
         if (i < (size_t)M32 * K8 * 16 * 64) R.wpk[i] = ossid_wino_pack_quad(R.w, R.Cout, R.Cin, R.kind == 3, i);
         return;
     }
-    const int KB = (R.kind == 0 ? R.Cin : R.Cout) / 8;
-    const int MT = ((R.kind == 0 ? R.Cout : R.Cin) + 31) / 32;
+    if (R.kind < 0 || R.kind > 5) return;
+    const int dgrad = R.kind & 1, exact = R.kind >= 4;
+    const int KB = (dgrad ? R.Cout : R.Cin) / 8;
+    const int MT = ((dgrad ? R.Cin : R.Cout) + 31) / 32;
     const size_t total = (size_t)MT * KB * R.taps * 64;
     if (i >= total) return;
-    const int lane = i & 63;
-    size_t r = i >> 6;
-    const int tap = r % R.taps;
-    r /= R.taps;
-    const int kb = r % KB, mt = r / KB;
-    float v[4];
-    if (R.kind == 0) {
-        const int co = mt * 32 + (lane & 31), ci = kb * 8 + 4 * (lane >> 5);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (co < R.Cout) ? R.w[((size_t)co * R.Cin + ci + e) * R.taps + tap] : 0.0f;
-    } else {
-        const int ci = mt * 32 + (lane & 31), co = kb * 8 + 4 * (lane >> 5);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            v[e] = (ci < R.Cin) ? R.w[((size_t)(co + e) * R.Cin + ci) * R.taps + (R.taps - 1 - tap)] : 0.0f;
-    }
-    R.wpk[i] = make_float4(v[0], v[1], v[2], v[3]);
+    R.wpk[i] = ossid_conv_pack_quad(R.w, R.Cout, R.Cin, R.taps, dgrad, exact, i);
 }
 
 // =====================================================================================================================
@@ -1218,11 +1184,8 @@ int ossid_upsample_nearest_bwd_nhwc(const float* dup, int B, int Hs, int Ws, int
 }
 
 int ossid_conv_pack_weights_dgrad(const float* w, int Cout, int Cin, int taps, float* wpk, void* stream) {
-    if (!w || !wpk || Cout <= 0 || Cin <= 0 || Cout % 16 || (taps != 1 && taps != 9)) return OSSID_EINVAL;
-    const size_t total = ossid_conv_packed_floats(Cin, Cout, taps) / 4;        // a [Cout' = Cin][Cin' = Cout] layer
-    hipLaunchKernelGGL(pack_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout,
-                       Cin, taps, (float4*)wpk, total);
-    return ossid_launch_status();
+    if (taps != 1 && taps != 9) return OSSID_EINVAL;
+    return ossid_conv_pack_weights_form(w, Cout, Cin, taps, 1, 0, wpk, stream);
 }
 
 size_t ossid_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps) {

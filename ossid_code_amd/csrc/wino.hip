@@ -516,6 +516,14 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 
 extern "C" {
 
+int ossid_conv_wino_split_bf16(void) {
+#ifdef OSSID_WINO_F32
+    return 0;
+#else
+    return 1;
+#endif
+}
+
 size_t ossid_conv_wino_packed_floats(int Cout, int Cin) {
     return (size_t)((Cout + 31) / 32) * (Cin / 8) * 16 * 64 * 4;
 }

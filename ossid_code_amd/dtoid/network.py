@@ -848,7 +848,7 @@ class Network(nn.Module):
                     local, join_local = lazy_local()
             elif isinstance(m, Transition):
                 stride = m.pool.stride if isinstance(m.pool.stride, int) else m.pool.stride[0]
-                x = T.AvgPool2.apply(T.bn_relu_conv(x, m.norm, m.conv), stride)
+                x = T.AvgPool2.apply(T.bn_relu_conv(x, m.norm, m.conv, deciding=True), stride)
             else:
                 norm5 = m
         B = x.shape[0]
@@ -902,7 +902,15 @@ class Network(nn.Module):
             for m in list(ife.backdense_1) + list(ife.backdense_2):
                 if isinstance(m, DenseBlock):
                     for layer in m.values():
-                        kinds[layer.conv2] = ("fwd", "wino_dgrad") if T.USE_WINO else ("fwd", "dgrad")
+                        kinds[layer.conv1] = (T.FWD_DECIDING, "dgrad")
+                        kinds[layer.conv2] = (T.FWD_DECIDING, "wino_dgrad") if T.USE_WINO else (T.FWD_DECIDING, "dgrad")
+                elif isinstance(m, Transition):
+                    kinds[m.conv] = (T.FWD_DECIDING, "dgrad")
+            if self.use_hip_template_training:
+                for enc in (self.template_feature_extractor_global, self.template_feature_extractor):
+                    for cv in encoder_convs(enc):
+                        final = any(cv is getattr(enc, n, None) for n in ("final_conv_1", "final_conv_2"))
+                        kinds[cv] = ("fwd_exact", "dgrad_exact") if final else (T.FWD_DECIDING, "dgrad")
             plan = self.__dict__["_pack_plan"] = T.PackPlan(convs, kinds)
         return plan
 

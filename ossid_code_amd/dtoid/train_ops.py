@@ -159,11 +159,12 @@ class _Packed:
             if kind in ("wino_fwd", "wino_dgrad"):
                 n = _lib.fn("ossid_conv_wino_packed_floats")(*((cout, cin) if kind == "wino_fwd" else (cin, cout)))
             else:
-                n = _lib.fn("ossid_conv_packed_floats")(cout, cin, taps) if kind == "fwd" else \
+                n = _lib.fn("ossid_conv_packed_floats")(cout, cin, taps) if kind in ("fwd", "fwd_exact") else \
                     _lib.fn("ossid_conv_packed_floats")(cin, cout, taps)
             if len(cls._cache) > 4096:
                 cls.clear()
             ent = cls._cache[key] = torch.empty(n, dtype=torch.float32, device=w.device)
+            ent._ossid_exact = kind.endswith("_exact")      # conv_raw sets ossid_conv_desc.exact from the buffer it is handed
         return ent
 
     @classmethod
@@ -181,7 +182,12 @@ _ACTIVE_PLAN = None  # weakref to the PackPlan that packed last. Its `fresh` dic
 #                      recycled for other tensors; when its network dies the weakref dies with it and nothing is "fresh".
 
 
+FWD_DECIDING = "fwd_exact"      # the forward layout of layers whose output a ReLU / max-pool decides on: the exact-f32 launch
+#                                  (include/ossid_hip.h, ossid_conv_desc::exact). Data gradients and the ELU head run split-bf16.
+
+
 def _pack(w, kind):
+    """kind: "fwd" / "dgrad" (split-bf16 launches), "fwd_exact" / "dgrad_exact" (exact-f32 launches), "wino_fwd" / "wino_dgrad"."""
     w = w.detach()
     assert w.is_contiguous() and w.dtype == torch.float32
     cout, cin, taps = int(w.shape[0]), int(w.shape[1]), int(w.shape[2] * w.shape[3])
@@ -195,8 +201,9 @@ def _pack(w, kind):
             name = "ossid_conv_pack_weights_wino"
             _lib.check(_lib.fn(name)(w.data_ptr(), cout, cin, 1 if kind == "wino_dgrad" else 0, buf.data_ptr(), _lib.stream()), name)
         else:
-            name = "ossid_conv_pack_weights" if kind == "fwd" else "ossid_conv_pack_weights_dgrad"
-            _lib.check(_lib.fn(name)(w.data_ptr(), cout, cin, taps, buf.data_ptr(), _lib.stream()), name)
+            name = "ossid_conv_pack_weights_form"
+            _lib.check(_lib.fn(name)(w.data_ptr(), cout, cin, taps, 1 if kind.startswith("dgrad") else 0,
+                                     1 if kind.endswith("_exact") else 0, buf.data_ptr(), _lib.stream()), name)
     return buf
 
 
@@ -206,7 +213,7 @@ class PackPlan:
     are stable: FlatParams views); `run()` marks them fresh so the per-layer _pack() calls only look the buffers up."""
 
     def __init__(self, convs, kinds=None):
-        """kinds: optional {conv: tuple of layouts} -- which of ("fwd", "dgrad", "wino_fwd", "wino_dgrad") the step will ask
+        """kinds: optional {conv: tuple of layouts} -- which of ("fwd", "fwd_exact", "dgrad", "wino_fwd", "wino_dgrad") the step will ask
         for (a layout left out is simply packed by its layer's own _pack() launch if it is asked for after all)."""
         rows, keys, first = [], [], 0
         self.bufs, self.buf_ptr = [], {}       # strong references: the table below holds raw addresses of these buffers
@@ -214,9 +221,9 @@ class PackPlan:
             w = conv.weight.detach()
             cout, cin, taps = int(w.shape[0]), int(w.shape[1]), int(w.shape[2] * w.shape[3])
             for kind in (("fwd", "dgrad") if kinds is None else kinds.get(conv, ("fwd", "dgrad"))):
-                if kind == "dgrad" and cout % 16:
+                if kind in ("dgrad", "dgrad_exact") and cout % 16:
                     continue
-                if kind == "fwd" and (cin % 16 or cout % 4):
+                if kind in ("fwd", "fwd_exact") and (cin % 16 or cout % 4):
                     continue
                 if kind == "wino_fwd" and not (USE_WINO and taps == 9 and cin % 16 == 0 and cout >= 64):
                     continue
@@ -224,7 +231,7 @@ class PackPlan:
                     continue
                 buf = _Packed.get(w, kind)
                 rows.append((w.data_ptr(), buf.data_ptr(), first, cout, cin, taps,
-                             {"fwd": 0, "dgrad": 1, "wino_fwd": 2, "wino_dgrad": 3}[kind]))
+                             {"fwd": 0, "dgrad": 1, "wino_fwd": 2, "wino_dgrad": 3, "fwd_exact": 4, "dgrad_exact": 5}[kind]))
                 keys.append((w.data_ptr(), tuple(w.shape), kind))
                 self.bufs.append(buf)
                 self.buf_ptr[keys[-1]] = buf.data_ptr()
@@ -274,6 +281,7 @@ def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_rel
     d.in_batch_stride, d.pre_batch_stride = -1, 0
     d.batch, d.height, d.width, d.cin, d.cout, d.taps = B, H, W, cin, cout, taps
     d.act, d.pre_relu = int(act), 1 if pre_relu else 0
+    d.exact = 1 if getattr(wpk, "_ossid_exact", False) else 0        # the arithmetic the weights were packed for (_pack kinds)
     d.src_height, d.src_width = int(src_hw[0]), int(src_hw[1])
     d.in_channel_stride, d.out_channel_stride, d.out_channel_offset = int(in_cs), int(out_cs), int(out_coff)
     if epi is not None and epi.get("timing_buf") is not None:
@@ -544,6 +552,31 @@ def wino_fits(B, H, W, cin, cout, taps, plain=True):
     return ((B * ((H + 1) // 2) * ((W + 1) // 2) + 31) // 32) * ((cout + 63) // 64) >= WINO_MIN_WGS
 
 
+class _Flag:
+    def __init__(self):
+        self.v = False
+
+    def get(self):
+        return self.v
+
+
+_EXACT_FWD = _Flag()
+
+
+class exact_forward:
+    """`with exact_forward():` -- FusedConv forwards inside run the exact-f32 launch (their output feeds a hard decision)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.old, _EXACT_FWD.v = _EXACT_FWD.v, self.on or _EXACT_FWD.v
+
+    def __exit__(self, *a):
+        _EXACT_FWD.v = self.old
+        return False
+
+
 class FusedConv(torch.autograd.Function):
     """u = ELU?( conv( relu?( x * pre_scale + pre_shift ) [nearest-up-sampled to `size`], w ) + bias ), optionally with
     the column sums of u as a second output (for the BatchNorm that follows). 3x3 / pad 1 / stride 1 or 1x1.
@@ -561,7 +594,8 @@ class FusedConv(torch.autograd.Function):
         u = empty_nhwc(B, Cout, H, W, x.device)
         act = int(act_elu)                       # 0 none, 1 ELU, 2 ReLU (True = ELU: the head's `F.elu(conv(x))`)
         wino = wino_fits(B, H, W, Cin, Cout, taps, plain=(H, W) == (Hs, Ws))
-        conv_raw(x, _pack(w, "wino_fwd" if wino else "fwd"), B, H, W, Cin, Cout, taps, u,
+        deciding = act == 2 or _EXACT_FWD.get()
+        conv_raw(x, _pack(w, "wino_fwd" if wino else (FWD_DECIDING if deciding else "fwd")), B, H, W, Cin, Cout, taps, u,
                  bias=None if bias is None else bias.detach(), pre=pre, pre_relu=pre_relu, act=act,
                  src_hw=(Hs, Ws) if size is not None else (0, 0), wino=wino)
         sums = batch_stats(flat(u), B * H * W, Cout) if want_stats else None
@@ -719,11 +753,11 @@ def _dense_forward(buf, table, block, params, C0):
                          layer.norm1.running_var, sums_row_stride=Ct, pivot=table[2])
         mid = int(w1.shape[0])
         y1 = new_buf((B, mid, H, W), dev, channels_last=True)
-        conv_raw(buf, _pack(w1, "fwd"), B, H, W, c, mid, 1, y1, pre=(f1[0], f1[1]), pre_relu=True, in_cs=Ct)
+        conv_raw(buf, _pack(w1, FWD_DECIDING), B, H, W, c, mid, 1, y1, pre=(f1[0], f1[1]), pre_relu=True, in_cs=Ct)
         s2 = batch_stats(flat(y1), N, mid, defer=True)
         f2 = bn_fold_fwd(s2, mid, N, g2, b2, layer.norm2.eps, _mom(layer.norm2), layer.norm2.running_mean,
                          layer.norm2.running_var)
-        conv_raw(y1, _pack(w2, "fwd"), B, H, W, mid, growth, 9, buf, pre=(f2[0], f2[1]), pre_relu=True, out_cs=Ct, out_coff=c)
+        conv_raw(y1, _pack(w2, FWD_DECIDING), B, H, W, mid, growth, 9, buf, pre=(f2[0], f2[1]), pre_relu=True, out_cs=Ct, out_coff=c)
         batch_stats(flat(buf, c), N, growth, cs=Ct, sums=table.view(-1)[c:], sums_row_stride=Ct)
         saved.append((f1, y1, f2))
         c += growth
@@ -823,7 +857,7 @@ class DenseBlockTrain(torch.autograd.Function):
         if SEQ_REPLAY and not torch.cuda.is_current_stream_capturing():
             plan = _plan_for(block, (B, C0, H, W, str(dev), params[0].data_ptr(), params[-1].data_ptr(),
                                      block[next(iter(block))].norm1.running_mean.data_ptr(),
-                                     _Packed.get(params[2].detach(), "fwd").data_ptr()))
+                                     _Packed.get(params[2].detach(), FWD_DECIDING).data_ptr()))
         if plan is None:
             buf = empty_nhwc(B, Ct, H, W, dev)
             table = torch.empty((3, Ct), dtype=torch.float32, device=dev)
@@ -1059,11 +1093,13 @@ def dense_block_train(x, block):
     return DenseBlockTrain.apply(x, block, *params)
 
 
-def bn_relu_conv(x, bn, conv, relu=True, act_elu=False, want_stats=False):
-    """Training-mode BatchNorm (+ReLU) in front of a convolution, folded into its input staging."""
+def bn_relu_conv(x, bn, conv, relu=True, act_elu=False, want_stats=False, deciding=False):
+    """Training-mode BatchNorm (+ReLU) in front of a convolution, folded into its input staging. deciding: the output
+    goes on into a BatchNorm + ReLU (a DenseNet transition): exact-f32 launch, see FWD_DECIDING."""
     B, C, H, W = x.shape
     scale, shift = bn_fold(ColStats.apply(x), B * H * W, bn)
-    return fused_conv(x, conv, pre=(scale, shift), pre_relu=relu, act_elu=act_elu, want_stats=want_stats)
+    with exact_forward(deciding):
+        return fused_conv(x, conv, pre=(scale, shift), pre_relu=relu, act_elu=act_elu, want_stats=want_stats)
 
 
 def bump_batches_tracked(module):
