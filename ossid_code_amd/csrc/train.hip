@@ -586,9 +586,238 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& A, const int L) {
             }
 }
 
-template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same weight gradient on split-bf16 products (the default for the tilings without a wave split of the k-steps;
+// -DOSSID_WGRAD_F32 keeps every launch on the exact kernel above). Both operands are split when they are staged
+// (x = hi + lo, bf16 each) and kept in LDS as [pixel][channel] bf16 images, one per part -- the natural order of the
+// channels-last tensors, so a thread's float4 becomes two 8-byte writes. The matrix cores want the REDUCTION index (pixels)
+// contiguous per lane: ds_read_b64_tr_b16 (cdna_hip_programming.md T10) reads a block of 4 pixels x 16 channels and hands
+// lane i the 4 pixels of channel i, two of them make the 8-pixel operand of v_mfma_f32_32x32x16_bf16; the 3x3 taps'
+// column shift is just a different first row of the block. Per 16 pixels and pair of 32x32 tiles three MFMAs
+// (dy_lo*x_hi + dy_hi*x_lo + dy_hi*x_hi) instead of eight f32 ones. Row pitch of an image: channels * 2 bytes padded so that
+// (pitch mod 256) is 64 or 192 -- the four rows of a block then sit on four different quarter-sets of the 64 banks.
+// One LDS buffer (the images of one chunk), the next chunk's global loads in flight in registers under the MFMAs.
+typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int wgrad_sb_pitch(int channels) {      // bytes
+    return channels == 128 ? 320 : (channels == 64 ? 192 : (channels == 32 ? 64 : channels * 2 + 64));
+}
+
+template <int TAPS, int KYB, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void wgrad_sb_body(const WgradArgs& A, const int L) {
+    constexpr int CO_T = WM * TM * 32, CI_T = WN * TN * 32;
+    constexpr int KX = TAPS == 9 ? 3 : 1;
+    constexpr int NT = TM * TN * KX * KYB;
+    constexpr int HALO = TAPS == 9 ? 2 : 0;
+    constexpr int KTMAX = 48;
+    constexpr int DY4 = CO_T / 4, X4 = CI_T / 4;
+    constexpr int NLD_DY = (KTMAX * DY4 + 255) / 256, NLD_X = (KYB * (KTMAX + HALO) * X4 + 255) / 256;
+    constexpr int PD = wgrad_sb_pitch(CO_T), PX = wgrad_sb_pitch(CI_T);
+    static_assert(WM * WN == 4 && 256 % DY4 == 0 && 256 % X4 == 0, "bad tiling");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int KT = A.KT;                                     // a multiple of 16 here
+    const int dy_img = KT * PD, x_img = KYB * (KT + HALO) * PX;          // bytes per part
+    char* dyl = (char*)lds;                                  // [2 parts][KT][PD]
+    char* xl = dyl + 2 * dy_img;                             // [2 parts][KYB][KT + HALO][PX]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int wm = wave % WM, wn = wave / WM;
+
+    const int split = L / A.ntiles;
+    int tile = L - split * A.ntiles;
+    int ky0 = 0;
+    if (TAPS == 9 && KYB == 1) {
+        ky0 = tile % 3;
+        tile /= 3;
+    }
+    const int cib = tile % A.ci_blocks, cob = tile / A.ci_blocks;
+    const int co0 = cob * CO_T, ci0 = cib * CI_T;
+
+    v16f acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    const int dyq = tid % DY4, xq = tid % X4;
+    const bool dyq_ok = co0 + 4 * dyq < A.Cout, xq_ok = ci0 + 4 * xq < A.Cin;
+    float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (A.pre_scale && xq_ok) {
+        ps = *(const float4*)(A.pre_scale + ci0 + 4 * xq);
+        pt = *(const float4*)(A.pre_shift + ci0 + 4 * xq);
+    }
+    float4 sdy[NLD_DY], sx[NLD_X];
+
+    const int H = A.H, W = A.W;
+    const int cpr = A.chunks_per_row;
+    const int d_cr = A.nsplit % cpr, d_row = A.nsplit / cpr, d_y = d_row % H, d_b = d_row / H;
+    auto advance = [&](int& b, int& y, int& cr) {
+        cr += d_cr;
+        int carry = cr >= cpr ? 1 : 0;
+        cr -= carry * cpr;
+        y += d_y + carry;
+        carry = y >= H ? 1 : 0;
+        y -= carry * H;
+        b += d_b + carry;
+    };
+    int xkr[NLD_X], xp[NLD_X];
+#pragma unroll
+    for (int e = 0; e < NLD_X; ++e) {
+        const int idx = (tid + e * 256) / X4;
+        xkr[e] = idx / (KT + HALO);
+        xp[e] = idx - xkr[e] * (KT + HALO);
+    }
+    auto stage_load = [&](int b, int y, int cr) {
+        const int x0 = cr * KT;
+        const float* dyr = A.dy + ((size_t)(b * H + y) * W) * A.dy_cs + co0 + 4 * dyq;
+#pragma unroll
+        for (int e = 0; e < NLD_DY; ++e) {
+            const int p = (tid + e * 256) / DY4;
+            const bool ok = p < KT && x0 + p < W && dyq_ok;
+            sdy[e] = ok ? *(const float4*)(dyr + (size_t)(x0 + p) * A.dy_cs) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < NLD_X; ++e) {
+            const int kr = xkr[e], p = xp[e];
+            const int yy = y + (TAPS == 9 ? ky0 + kr - 1 : 0), xx = x0 + p - (TAPS == 9 ? 1 : 0);
+            const bool ok = kr < KYB && yy >= 0 && yy < H && xx >= 0 && xx < W && xq_ok;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const int sy = (A.Hs == H) ? yy : min((int)floorf((float)yy * A.scale_h), A.Hs - 1);
+                const int sxx = (A.Ws == W) ? xx : min((int)floorf((float)xx * A.scale_w), A.Ws - 1);
+                v = *(const float4*)(A.x + ((size_t)(b * A.Hs + sy) * A.Ws + sxx) * A.in_cs + ci0 + 4 * xq);
+                if (A.pre_scale) {
+                    v.x = v.x * ps.x + pt.x, v.y = v.y * ps.y + pt.y, v.z = v.z * ps.z + pt.z, v.w = v.w * ps.w + pt.w;
+                    if (A.pre_relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                }
+            }
+            sx[e] = v;
+        }
+    };
+    auto split_store = [&](const float4& f, char* hi_at, int part_stride) {
+        const float v[4] = {f.x, f.y, f.z, f.w};
+        union {
+            __bf16 b[4];
+            uint2 u;
+        } hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hi.b[i] = (__bf16)v[i];
+            lo.b[i] = (__bf16)(v[i] - (float)hi.b[i]);
+        }
+        *(uint2*)hi_at = hi.u;
+        *(uint2*)(hi_at + part_stride) = lo.u;
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int e = 0; e < NLD_DY; ++e) {
+            const int idx = tid + e * 256;
+            if (idx < KT * DY4) split_store(sdy[e], dyl + (size_t)(idx / DY4) * PD + 8 * dyq, dy_img);
+        }
+#pragma unroll
+        for (int e = 0; e < NLD_X; ++e) {
+            const int idx = tid + e * 256;
+            if (idx < KYB * (KT + HALO) * X4) split_store(sx[e], xl + (size_t)(idx / X4) * PX + 8 * xq, x_img);
+        }
+    };
+
+    // transposed-read addresses (T10): within its group of 16 lanes, lane 4q+p supplies the address of block row q (a pixel),
+    // channels 4p..4p+3 of the block's 16; groups 0/1 take channels 0-15 / 16-31 of a 32-channel tile, the wave's halves the
+    // pixels 8h..8h+7 of the k-step (two blocks of 4 pixels each)
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
+    const char* a_base = dyl + (size_t)(8 * h + tq) * PD + ((wm * TM) * 32 + 16 * tg + 4 * tp) * 2;
+    const char* b_base = xl + (size_t)(8 * h + tq) * PX + ((wn * TN) * 32 + 16 * tg + 4 * tp) * 2;
+    auto tr8 = [&](const char* at, int pitch) {
+        const v4i16 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)at);
+        const v4i16 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(at + 4 * pitch));
+        typedef short v8i16 __attribute__((ext_vector_type(8)));
+        const v8i16 v = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(v8bf16, v);
+    };
+
+    long long ch = split;
+    int gb, gy, gcr;
+    {
+        gcr = split % cpr;
+        const int row = split / cpr;
+        gy = row % H, gb = row / H;
+    }
+    if (ch < A.n_chunks) stage_load(gb, gy, gcr);
+    const int ksteps = KT / 16;
+#pragma unroll 1
+    for (; ch < A.n_chunks; ch += A.nsplit) {
+        stage_write();
+        __syncthreads();
+        const long long nxt = ch + A.nsplit;
+        advance(gb, gy, gcr);
+        if (nxt < A.n_chunks) stage_load(gb, gy, gcr);       // in flight under this chunk's MFMAs
+#pragma unroll 1
+        for (int k = 0; k < ksteps; ++k) {
+            v8bf16 a[TM][2], bv[KYB][TN][KX][2];
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int part = 0; part < 2; ++part)
+                    a[m][part] = tr8(a_base + (size_t)part * dy_img + (size_t)(16 * k) * PD + m * 64, PD);
+#pragma unroll
+            for (int kr = 0; kr < KYB; ++kr)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int kx = 0; kx < KX; ++kx)
+#pragma unroll
+                        for (int part = 0; part < 2; ++part)
+                            bv[kr][n][kx][part] = tr8(b_base + (size_t)part * x_img +
+                                                      (size_t)(kr * (KT + HALO) + 16 * k + kx) * PX + n * 64, PX);
+#pragma unroll
+            for (int kr = 0; kr < KYB; ++kr)
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+#pragma unroll
+                        for (int kx = 0; kx < KX; ++kx) {
+                            const int t = ((kr * TM + m) * TN + n) * KX + kx;
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bv[kr][n][kx][0], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bv[kr][n][kx][1], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bv[kr][n][kx][0], acc[t], 0, 0, 0);
+                        }
+        }
+        __syncthreads();                                      // every wave has read this chunk's images
+    }
+
+    float* slab = A.slabs + (size_t)split * TAPS * A.Cout * A.Cin;
+#pragma unroll
+    for (int kr = 0; kr < KYB; ++kr)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                const int ci = ci0 + (wn * TN + n) * 32 + c;
+                if (ci >= A.Cin) continue;
+#pragma unroll
+                for (int kx = 0; kx < KX; ++kx) {
+                    const int t = ((kr * TM + m) * TN + n) * KX + kx;
+                    const int tap = TAPS == 9 ? (ky0 + kr) * 3 + kx : 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = co0 + (wm * TM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (co < A.Cout) slab[((size_t)tap * A.Cout + co) * A.Cin + ci] = acc[t][r];
+                    }
+                }
+            }
+}
+
+template <bool SB, int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
+__device__ __forceinline__ void wgrad_any_body(const WgradArgs& A, const int L) {
+    if constexpr (SB && WK == 1) wgrad_sb_body<TAPS, KYB, TM, TN, WM, WN>(A, L);
+    else wgrad_body<TAPS, KYB, TM, TN, WM, WN, WK>(A, L);
+}
+
+template <bool SB, int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
-    wgrad_body<TAPS, KYB, TM, TN, WM, WN, WK>(A, blockIdx.x);
+    wgrad_any_body<SB, TAPS, KYB, TM, TN, WM, WN, WK>(A, blockIdx.x);
 }
 
 // Several independent weight gradients of ONE tiling variant in one launch (the 2 x L small problems of a dense block,
@@ -600,12 +829,12 @@ struct WgradGroup {
     int n;
 };
 
-template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
+template <bool SB, int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
 __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradGroup G) {
     int i = 0;
     const int b = blockIdx.x;
     while (i + 1 < G.n && G.first_block[i + 1] <= b) ++i;
-    wgrad_body<TAPS, KYB, TM, TN, WM, WN, WK>(G.a[i], b - G.first_block[i]);
+    wgrad_any_body<SB, TAPS, KYB, TM, TN, WM, WN, WK>(G.a[i], b - G.first_block[i]);
 }
 
 struct ReduceRow {
@@ -690,12 +919,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
     *o = accumulate ? *o + s : s;
 }
 
+#ifdef OSSID_WGRAD_F32
+#define OSSID_WGRAD_SB 0
+#else
+#define OSSID_WGRAD_SB 1
+#endif
 struct WgradPlan {
     // variant: 0 <9,1,2,1,2,2,1> 128 co x 64 ci    1 <9,1,1,2,2,2,1> 64 x 128     2 <9,1,1,1,1,4,1> 32 x 128
     //          3 <1,1,2,2,2,2,1> 128 x 128 (1x1)   4 <1,1,1,2,2,2,1> 64 x 128 (1x1)
     //          5 <9,3,1,1,1,1,4> 32 x 32, all nine taps, k-steps shared out over the waves   6 <9,3,1,1,1,2,2> 32 x 64
     int variant, co_t, ci_t, kyb, wk, tiles_per_wave;
     int KT, chunks_per_row, nsplit, co_blocks, ci_blocks, ntiles, B, H, W;
+    int sb;                 // 1: the split-bf16 kernel (wgrad_sb_body: KT a multiple of 16, one LDS buffer of bf16 images)
     long long n_chunks;
     size_t lds;
 };
@@ -711,12 +946,15 @@ bool wgrad_plan(int B, int H, int W, int Cin, int Cout, int taps, WgradPlan& p) 
         else if (Cout <= 64 || Cout == 96) p.variant = 1, p.co_t = 64, p.ci_t = 128, p.tiles_per_wave = 6;
         else p.variant = 0, p.co_t = 128, p.ci_t = 64, p.tiles_per_wave = 6;
         p.B = B, p.H = H, p.W = W;
+        p.sb = OSSID_WGRAD_SB && p.wk == 1;
         p.chunks_per_row = (W + ktmax - 1) / ktmax;
-        p.KT = ((W + p.chunks_per_row - 1) / p.chunks_per_row + 1) & ~1;
+        p.KT = p.sb ? ((W + p.chunks_per_row - 1) / p.chunks_per_row + 15) & ~15
+                    : ((W + p.chunks_per_row - 1) / p.chunks_per_row + 1) & ~1;
     } else if (taps == 1) {
         if (Cout <= 64) p.variant = 4, p.co_t = 64, p.ci_t = 128, p.tiles_per_wave = 2;
         else p.variant = 3, p.co_t = 128, p.ci_t = 128, p.tiles_per_wave = 4;
         p.B = 1, p.H = 1, p.W = B * H * W;          // no halo: the whole tensor is one long pixel row
+        p.sb = OSSID_WGRAD_SB;
         p.KT = 32;
         p.chunks_per_row = (p.W + p.KT - 1) / p.KT;
     } else {
@@ -727,12 +965,14 @@ bool wgrad_plan(int B, int H, int W, int Cin, int Cout, int taps, WgradPlan& p) 
     p.ci_blocks = (Cin + p.ci_t - 1) / p.ci_t;
     p.ntiles = p.co_blocks * p.ci_blocks * ((taps == 9 && p.kyb == 1) ? 3 : 1);
     const int halo = taps == 9 ? 2 : 0;
-    p.lds = (size_t)2 * (p.KT * p.co_t + p.kyb * (p.KT + halo) * p.ci_t) * sizeof(float);
+    p.lds = p.sb ? (size_t)2 * (p.KT * wgrad_sb_pitch(p.co_t) + p.kyb * (p.KT + halo) * wgrad_sb_pitch(p.ci_t))
+                 : (size_t)2 * (p.KT * p.co_t + p.kyb * (p.KT + halo) * p.ci_t) * sizeof(float);
     // How many K-splits (multiples of 8: one per XCD)? More splits = more workgroups in flight but every split costs a
     // slab (written here, read by the reduction). Model, in microseconds: rounds of resident workgroups x (chunks per
     // workgroup x MFMA time of a chunk + a fixed ~4 us to fill the pipeline and store the tiles) + slab traffic at ~3 TB/s.
     const int per_cu = p.lds > 80 * 1024 ? 1 : (p.lds > 53 * 1024 ? 2 : 3);
-    const double t_chunk = (double)(p.KT / 2) * p.tiles_per_wave / p.wk * 64.0 / 2400.0 + 0.35;
+    const double t_chunk = p.sb ? (double)(p.KT / 16) * p.tiles_per_wave * 96.0 / 2400.0 + 0.5
+                                : (double)(p.KT / 2) * p.tiles_per_wave / p.wk * 64.0 / 2400.0 + 0.35;
     const double dw_bytes = (double)taps * Cout * Cin * 4.0;
     double best = 1e30;
     int best_s = 1;
@@ -750,21 +990,35 @@ bool wgrad_plan(int B, int H, int W, int Cin, int Cout, int taps, WgradPlan& p) 
     return true;
 }
 
-template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
-int launch_wgrad_group(const WgradGroup& g, size_t lds, hipStream_t s) {
-    auto kern = wgrad_group_kernel<TAPS, KYB, TM, TN, WM, WN, WK>;
+template <bool SB, int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
+int launch_wgrad_group_form(const WgradGroup& g, size_t lds, hipStream_t s) {
+    auto kern = wgrad_group_kernel<SB, TAPS, KYB, TM, TN, WM, WN, WK>;
     OSSID_ENSURE_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)g.first_block[g.n]), dim3(256), lds, s, g);
     return ossid_launch_status();
 }
-
 template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
-int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t s) {
-    auto kern = wgrad_kernel<TAPS, KYB, TM, TN, WM, WN, WK>;
+int launch_wgrad_group(const WgradGroup& g, size_t lds, bool sb, hipStream_t s) {
+    if constexpr (WK == 1) {
+        if (sb) return launch_wgrad_group_form<true, TAPS, KYB, TM, TN, WM, WN, WK>(g, lds, s);
+    }
+    return launch_wgrad_group_form<false, TAPS, KYB, TM, TN, WM, WN, WK>(g, lds, s);
+}
+
+template <bool SB, int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
+int launch_wgrad_form(const WgradArgs& a, const WgradPlan& p, hipStream_t s) {
+    auto kern = wgrad_kernel<SB, TAPS, KYB, TM, TN, WM, WN, WK>;
     OSSID_ENSURE_LDS(kern, p.lds);
     const long nwg = (long)p.nsplit * p.ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), p.lds, s, a);
     return ossid_launch_status();
+}
+template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
+int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t s) {
+    if constexpr (WK == 1) {
+        if (p.sb) return launch_wgrad_form<true, TAPS, KYB, TM, TN, WM, WN, WK>(a, p, s);
+    }
+    return launch_wgrad_form<false, TAPS, KYB, TM, TN, WM, WN, WK>(a, p, s);
 }
 
 template <int QX>
@@ -1341,13 +1595,13 @@ int ossid_conv_wgrad_group(const ossid_wgrad_desc* descs, int n, void* workspace
             }
             int rc;
             switch (v) {
-                case 0: rc = launch_wgrad_group<9, 1, 2, 1, 2, 2, 1>(g, lds, s); break;
-                case 1: rc = launch_wgrad_group<9, 1, 1, 2, 2, 2, 1>(g, lds, s); break;
-                case 2: rc = launch_wgrad_group<9, 1, 1, 1, 1, 4, 1>(g, lds, s); break;
-                case 3: rc = launch_wgrad_group<1, 1, 2, 2, 2, 2, 1>(g, lds, s); break;
-                case 4: rc = launch_wgrad_group<1, 1, 1, 2, 2, 2, 1>(g, lds, s); break;
-                case 5: rc = launch_wgrad_group<9, 3, 1, 1, 1, 1, 4>(g, lds, s); break;
-                default: rc = launch_wgrad_group<9, 3, 1, 1, 1, 2, 2>(g, lds, s); break;
+                case 0: rc = launch_wgrad_group<9, 1, 2, 1, 2, 2, 1>(g, lds, sub[0].sb != 0, s); break;
+                case 1: rc = launch_wgrad_group<9, 1, 1, 2, 2, 2, 1>(g, lds, sub[0].sb != 0, s); break;
+                case 2: rc = launch_wgrad_group<9, 1, 1, 1, 1, 4, 1>(g, lds, sub[0].sb != 0, s); break;
+                case 3: rc = launch_wgrad_group<1, 1, 2, 2, 2, 2, 1>(g, lds, sub[0].sb != 0, s); break;
+                case 4: rc = launch_wgrad_group<1, 1, 1, 2, 2, 2, 1>(g, lds, sub[0].sb != 0, s); break;
+                case 5: rc = launch_wgrad_group<9, 3, 1, 1, 1, 1, 4>(g, lds, sub[0].sb != 0, s); break;
+                default: rc = launch_wgrad_group<9, 3, 1, 1, 1, 2, 2>(g, lds, sub[0].sb != 0, s); break;
             }
             if (rc != OSSID_OK) return rc;
         }
