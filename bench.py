@@ -248,16 +248,19 @@ def dtoid_leg(a, dev, dist, world):
     note = ("frac_mfma = the MFMA pipe's busy fraction: matrix-core multiply-adds the leg ISSUES (counted at the launch "
             "sites of one eager pass, ossid_code_amd._lib.count_mfma: Winograd layers at their 16 multiplies per 2x2 tile, "
             "reassociated layers at what they run, weight gradients included), each launch in units of f32-pipe time -- "
-            "layers on v_mfma_f32_32x32x2_f32 1:1, the split-bf16 Winograd layers (three v_mfma_f32_32x32x16_bf16 per f32 "
-            "product, an instruction with 16x the f32 one's rate) 3/16 -- / wall time / 157.3 TFLOP/s, over the whole "
+            "launches on v_mfma_f32_32x32x2_f32 1:1, split-bf16 launches (three v_mfma_f32_32x32x16_bf16 per f32 product, an "
+            "instruction with 16x the f32 one's rate: every test-time convolution, the Winograd layers, data and weight "
+            "gradients) 3/16 -- "
+            "/ wall time / 157.3 TFLOP/s, over the whole "
             "call incl. top-k / NMS / host latency: <= 1 by construction. achieved_mfma = the same multiply-adds as f32 "
             "arithmetic / time (mfma_gflop_per_call; pipe-weighted: mfma_pipe_gflop_per_call). frac = the reference's NOMINAL flops "
             "(39.7 + 45.96 n_t GFLOP per frame; 258 GFLOP per finetune sample) / time / peak: a throughput in the "
             "reference's units that can exceed 1 because Winograd and the exact reassociations of DESIGN.md 5 execute "
             "fewer multiplies. frac_executed = nominal minus the reassociations only (kept from round 2). peak = the "
-            "guide's dense f32 MFMA figure at 2.4 GHz; this build's kernels run the part at 1.95-2.08 GHz "
-            "(profiles/r02_conv_timeline.txt) -- a property of their LDS / L2 traffic per MFMA, not an external ceiling: "
-            "the operands-in-registers probe holds 2.32 GHz (profiles/r02_split_bf16_probe.txt)")
+            "guide's dense f32 MFMA figure at 2.4 GHz. Arithmetic: f32 tensors and f32 accumulation everywhere; the DTOID "
+            "convolutions form each f32 product from three bf16 matrix-core products (~5e-6 of the output scale vs float64, "
+            "DESIGN.md 5e) except the training forward of the ReLU / max-pool networks, which stays on the exact-f32 "
+            "instruction")
 
     def mfma_fields(counted_pair, t):
         arith, pipe = counted_pair

@@ -264,8 +264,11 @@ int ossid_conv3x3_wgrad(const float* x, const float* dy, int B, int H, int W, in
  *   dw[co][ci][tap] (+)= sum_{b,y,x} dy[b][y][x][co] * P(x)[b][y+dy][x+dx][ci],  P(v) = relu?(v * pre_scale[ci] + pre_shift[ci])
  * on real pixels, zero outside the image (pre_scale NULL = identity). x [B][H][W][in_channel_stride], dy
  * [B][H][W][dy_channel_stride] channels-last (0 = cin / cout); dw in torch layout [cout][cin][kh][kw]. Operands are staged
- * through LDS and fed to v_mfma_f32_32x32x2_f32 with the pixels on K; split-K slabs in `workspace`
- * (ossid_conv_wgrad_workspace_bytes), summed in a fixed order -- bit-reproducible, no float atomics. cin, cout % 4 == 0. */
+ * through LDS with the pixels on K: as bf16 hi/lo images read back K-major (ds_read_b64_tr_b16) for three
+ * v_mfma_f32_32x32x16_bf16 per f32 product (split-bf16, ~5e-6 of the result's scale; ossid_conv_wgrad_split_bf16() != 0),
+ * or as f32 for v_mfma_f32_32x32x2_f32 (3x3 layers with cout <= 32 and cin <= 64, and every layer of a -DOSSID_WGRAD_F32
+ * build); split-K slabs in `workspace` (ossid_conv_wgrad_workspace_bytes), summed in a fixed order -- bit-reproducible,
+ * no float atomics. cin, cout % 4 == 0. */
 typedef struct ossid_wgrad_desc {
     const float* x;
     const float* dy;
@@ -279,6 +282,7 @@ typedef struct ossid_wgrad_desc {
     int32_t src_height, src_width;   /* > 0 (3x3 only): x is [B][src_h][src_w][..], nearest-neighbour up-sampled to
                                         [height][width] on the fly, as in the forward (ossid_conv_desc) */
 } ossid_wgrad_desc;
+int ossid_conv_wgrad_split_bf16(void);
 size_t ossid_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps);
 int ossid_conv_wgrad(const ossid_wgrad_desc* desc_host, void* stream);
 /* Up to 48 INDEPENDENT weight gradients (e.g. the 2 x L of one DenseNet block, each too small to fill the chip) as one

@@ -54,6 +54,7 @@ _PROTOS = {
     "ossid_abi_version": (_i, [C.c_char_p, _i]),
     "ossid_conv_wino_split_bf16": (_i, []),
     "ossid_conv_split_bf16": (_i, []),
+    "ossid_conv_wgrad_split_bf16": (_i, []),
     "ossid_zephyr_prep_frame_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ossid_zephyr_prep_frame_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ossid_zephyr_prep_model": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
@@ -281,12 +282,25 @@ _MFMA_COUNT = None
 SPLIT_BF16_PIPE_WEIGHT = 3.0 / 16.0
 
 
-def _pipe_weight(name, args=None):
-    if name in ("ossid_conv3x3_wino_fwd", "ossid_conv3x3_wino_fwd_pair") and lib().ossid_conv_wino_split_bf16():
-        return SPLIT_BF16_PIPE_WEIGHT
-    if name == "ossid_conv_nhwc_fwd" and lib().ossid_conv_split_bf16() and not (args and args[0]._obj.exact):
-        return SPLIT_BF16_PIPE_WEIGHT
-    return 1.0
+def _wgrad_pipe(d):
+    """f32-pipe-equivalent flops of one weight gradient: the tilings of few-channel 3x3 layers (Cout <= 32 and Cin <= 64:
+    csrc/train.hip, wgrad_plan variants 5 / 6) stay on the f32 instruction, everything else runs split."""
+    f = _wgrad_flops_d(d)
+    few = d.taps == 9 and d.cout <= 32 and d.cin <= 64
+    return f * (SPLIT_BF16_PIPE_WEIGHT if (lib().ossid_conv_wgrad_split_bf16() and not few) else 1.0)
+
+
+def _pipe_flops(name, args, flops):
+    if name in ("ossid_conv3x3_wino_fwd", "ossid_conv3x3_wino_fwd_pair"):
+        return flops * (SPLIT_BF16_PIPE_WEIGHT if lib().ossid_conv_wino_split_bf16() else 1.0)
+    if name == "ossid_conv_nhwc_fwd":
+        split = lib().ossid_conv_split_bf16() and not (args and args[0]._obj.exact)
+        return flops * (SPLIT_BF16_PIPE_WEIGHT if split else 1.0)
+    if name == "ossid_conv_wgrad" and args:
+        return _wgrad_pipe(args[0]._obj)
+    if name == "ossid_conv_wgrad_group" and args:
+        return sum(_wgrad_pipe(args[0][i]) for i in range(args[1]))
+    return flops
 
 
 def _conv_flops(args):
@@ -338,7 +352,7 @@ class count_mfma:
 
     def _add(self, name, flops, args=None):
         self.flops += flops
-        self.pipe += flops * _pipe_weight(name, args)
+        self.pipe += _pipe_flops(name, args, flops)
         self.launches += 1
 
     @staticmethod

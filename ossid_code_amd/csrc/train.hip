@@ -1448,6 +1448,8 @@ size_t ossid_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, 
     return (size_t)p.nsplit * p.wk * taps * Cout * Cin * sizeof(float);
 }
 
+int ossid_conv_wgrad_split_bf16(void) { return OSSID_WGRAD_SB; }
+
 int ossid_conv_wgrad(const ossid_wgrad_desc* d, void* stream) {
     if (!d) return OSSID_EINVAL;
     const int B = d->batch, H = d->height, W = d->width, Cin = d->cin, Cout = d->cout, taps = d->taps;
