@@ -12,8 +12,9 @@
  *   - return 0 on success, a negative errno-style code otherwise (OSSID_EINVAL bad argument,
  *     OSSID_ELAUNCH a HIP launch error); no exceptions cross the boundary;
  *   - thread-safe for distinct streams; no global mutable state;
- *   - all arithmetic is IEEE binary32 with the operation order fixed by SPEC.md, so results are
- *     bit-identical to oracle/zephyr_oracle.c.
+ *   - Zephyr entry points (ossid_zephyr_*, ossid_pn2_*): all arithmetic is IEEE binary32 with the operation order
+ *     fixed by SPEC.md, so results are bit-identical to oracle/zephyr_oracle.c. DTOID entry points: binary32 tensors
+ *     and accumulation; the convolution kernels' products as documented at ossid_conv_desc (`exact`).
  */
 #ifndef OSSID_HIP_H
 #define OSSID_HIP_H
@@ -29,7 +30,11 @@ extern "C" {
 #define OSSID_EINVAL (-22)
 #define OSSID_ELAUNCH (-5)
 
-/* library / device probe: returns the ABI version (>0); arch_out_host (may be NULL, >=32 bytes)
+/* The version of the struct layouts and signatures below; bumped whenever one changes (3: ossid_conv_desc gained
+ * scratch / scratch_bytes / exact). A binding compares it with ossid_abi_version() when it loads the library. */
+#define OSSID_ABI_VERSION 3
+
+/* library / device probe: returns OSSID_ABI_VERSION of the build; arch_out_host (may be NULL, >=32 bytes)
  * receives the gcnArchName of the current device, e.g. "gfx950:sramecc+:xnack-". */
 int ossid_abi_version(char* arch_out_host, int len);
 
@@ -326,7 +331,14 @@ typedef struct ossid_chan_op_desc {
     int32_t channels, g_stride, x_stride, out_stride, mask_mode, accumulate, sum_mode;
     int32_t sums_row_stride;         /* floats between sums[0][.] and sums[1][.] (0 = channels): lets a layer write the
                                         statistics of its channel slice into a block-wide [2][C_total] table */
-    int32_t defer_finalize;          /* Zero `bytes` bytes at `ptr` on `stream` (an accumulator a recorded launch sequence must clear on every replay: the
+    int32_t defer_finalize;          /* != 0: leave the column sums as the ossid_chan_op_partials(rows, channels)
+                                        per-block partials in `partials` (sums may be NULL); the consumer --
+                                        ossid_bn_fold_fwd / _bwd with n_partials > 0 -- combines them itself */
+} ossid_chan_op_desc;
+int ossid_chan_op_partials(long long n_rows, int channels);
+int ossid_chan_op(const ossid_chan_op_desc* desc_host, void* stream);
+
+/* Zero `bytes` bytes at `ptr` on `stream` (an accumulator a recorded launch sequence must clear on every replay: the
  * coefficient table of a dense block's backward pass; replaces torch.zeros inside such a sequence). */
 int ossid_fill_zero(void* ptr, size_t bytes, void* stream);
 
@@ -354,13 +366,6 @@ int ossid_conv3x3_c1_wgrad(const float* x, const float* g, int B, int H, int W, 
  * the parameter's layout). The strided stems (7x7 / 2 of the image backbone, network.py:164-170; 3x3 / 2 of the template
  * encoders, :203-208) run as im2col + a 1x1 MFMA convolution. */
 int ossid_stem_weight_relayout(const float* src, float* dst, int cout, int cin, int k, int kpad, int inverse, void* stream);
-
-/* != 0: leave the column sums as the ossid_chan_op_partials(rows, channels)
-                                        per-block partials in `partials` (sums may be NULL); the consumer --
-                                        ossid_bn_fold_fwd / _bwd with n_partials > 0 -- combines them itself */
-} ossid_chan_op_desc;
-int ossid_chan_op_partials(long long n_rows, int channels);
-int ossid_chan_op(const ossid_chan_op_desc* desc_host, void* stream);
 
 /* D16  training-mode BatchNorm2d (nn.BatchNorm2d in train(), online_learning.py:656) folded into the per-channel affine
  * the NEXT convolution applies while staging its input: from sums = (sum x, sum x^2) over n rows,

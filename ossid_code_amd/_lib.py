@@ -142,6 +142,9 @@ _PROTOS = {
 }
 
 
+ABI_VERSION = 3      # OSSID_ABI_VERSION of include/ossid_hip.h: the struct layouts below (tests/test_abi.py compares the two)
+
+
 def exported_symbols():
     """Names include/ossid_hip.h declares (kept in step by tests/test_abi.py)."""
     return sorted(_PROTOS)
@@ -161,6 +164,10 @@ def lib():
             if fn is None:
                 continue  # a later round's symbol not built yet; calling it raises in check()
             fn.restype, fn.argtypes = res, args
+        have = handle.ossid_abi_version(None, 0)
+        if have != ABI_VERSION:
+            raise RuntimeError("libossid_hip.so has ABI version %d, this binding expects %d (include/ossid_hip.h, "
+                               "OSSID_ABI_VERSION): rebuild the library with `python -m ossid_code_amd._build`" % (have, ABI_VERSION))
         _lib = handle
     return _lib
 

@@ -5,7 +5,6 @@
 
 #include "../../include/ossid_hip.h"
 
-#define OSSID_ABI_VERSION 1
 
 static inline int ossid_launch_status() {
     hipError_t e = hipGetLastError();

@@ -820,8 +820,9 @@ class Network(nn.Module):
             # stem on this repo's kernels, channels-last from the first one: im2col -> 1x1 MFMA conv (weight gradient
             # by the same 1x1 wgrad kernel), template modulation, training BatchNorm + ReLU, max-pool
             conv0 = ife.backdense_0[0]
-            x0 = T.FusedConv.apply(ops.im2col_stem(image, 7, 2, 3, 160), T.relaid_stem_weight(conv0, 160), conv0.bias, None,
-                                   None, False, 0, None, False)
+            with T.exact_forward():                               # BatchNorm + ReLU + max-pool decide on its output
+                x0 = T.FusedConv.apply(ops.im2col_stem(image, 7, 2, 3, 160), T.relaid_stem_weight(conv0, 160), conv0.bias, None,
+                                       None, False, 0, None, False)
             if lazy_g is not None:
                 g, s_g = lazy_g()
                 self._join(s_g, [g])

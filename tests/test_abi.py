@@ -31,6 +31,27 @@ def test_python_prototypes_cover_the_header(hiplib):
     assert set(_declared()) == set(hiplib.exported_symbols())
 
 
+def test_abi_version_and_struct_layouts_agree_between_header_and_binding(hiplib, tmp_path):
+    """OSSID_ABI_VERSION of the header = the binding's = what the built library reports, and every descriptor struct has
+    the same size and the same offset of its LAST field when the header is compiled by gcc as in the ctypes mirror."""
+    import subprocess
+    text = open(os.path.join(ROOT, "include", "ossid_hip.h")).read()
+    ver = int(re.search(r"#define\s+OSSID_ABI_VERSION\s+(\d+)", text).group(1))
+    assert ver == hiplib.ABI_VERSION == hiplib.lib().ossid_abi_version(None, 0)
+    pairs = [("ossid_pn2_weights", hiplib.PN2Weights), ("ossid_conv_desc", hiplib.ConvDesc), ("ossid_wgrad_desc", hiplib.WgradDesc),
+             ("ossid_chan_op_desc", hiplib.ChanOpDesc), ("ossid_pack_row", hiplib.PackRow)]
+    src = tmp_path / "layout.c"
+    body = "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));\n' % (c, c, st._fields_[-1][0]) for c, st in pairs)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ossid_hip.h"\nint main(void) {\n%sreturn 0;\n}\n' % body)
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    lines = subprocess.check_output([str(exe)]).decode().split("\n")
+    for (c, st), line in zip(pairs, lines):
+        size, off = (int(v) for v in line.split())
+        assert size == ctypes.sizeof(st), (c, size, ctypes.sizeof(st))
+        assert off == getattr(st, st._fields_[-1][0]).offset, (c, off)
+
+
 def test_no_cpu_fallback():
     """The product path refuses CPU tensors instead of silently computing elsewhere."""
     import torch
