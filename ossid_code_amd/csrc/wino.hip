@@ -50,7 +50,9 @@ struct WinoArgs {
     int H, W, Cin, Cout, n_cotiles, act, in_cs, out_cs, out_coff, pre_relu, pre_bs;
     long long in_bs;
     int TH, TW, T;     // tiles per image (rows, columns), tiles in the batch
-    int gx, gy;        // groups of 32 tiles, groups of 2 channel tiles
+    int gx, gy;        // groups of 32 tiles, groups of ct channel tiles
+    int ct;            // channel tiles per workgroup: 2 (256 threads) or 4 (512 threads; the input transform, which every
+                       // channel group of a tile group repeats, is then shared by 128 output channels instead of 64)
     unsigned x_bytes;  // extent of x in bytes (the staging loads are bounds-checked buffer loads)
     float* dbg;        // -DOSSID_TIMING builds: per-wave time stamps (tools/conv_timeline.py --wino)
 };
@@ -64,9 +66,9 @@ constexpr int KCH = 16, F4 = 4, VBUF = 16 * 32 * F4;      // float4 per LDS buff
 // whole reduction and the epilogue here.
 struct WinoTail {
     int lcut, ks;          // virtual blocks [0, lcut) run whole; block lcut + t / ks, slice t % ks for t = blockIdx - lcut
-    float* partial;        // [tail blocks][ks][4 waves][2][16][64] floats
+    float* partial;        // [tail blocks][ks][2 ct waves][2][16][64] floats
 };
-constexpr int WINO_PARTIAL_FLOATS = 4 * 2 * 16 * 64;
+constexpr int wino_partial_floats(int ct) { return 2 * ct * 2 * 16 * 64; }
 
 __device__ __forceinline__ bool wino_block_map(const WinoArgs& A, const int L, int& bx, int& by) {
     const int P = A.gx;
@@ -132,12 +134,16 @@ __device__ __forceinline__ void wino_epilogue(const WinoArgs& A, const int bx, c
     }
 }
 
+template <int CT>
 __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int block, const int slice = 0, const int ks = 1,
                                                float* __restrict__ partial = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float4 vb[];   // [2][16 xi][32 tiles][4 quads]
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform TO THE COMPILER: weight addresses become scalar
-    const int wm = wave & 1, wx = wave >> 1;
+    const int wm = wave % CT, wx = wave / CT;
+    // the input transform is the work of the first 256 threads (waves 0-3) whatever the workgroup size: 32 tiles x 4 channel
+    // quads x 2 transform halves; with CT = 4 the other four waves only multiply
+    const bool stager = wave < 4;
 #ifdef OSSID_TIMING   // diagnostic build only: per-wave s_memrealtime stamps (100 MHz), shader cycles of the main loop, HW_ID
     auto tnow = []() {
         unsigned long long t;
@@ -152,7 +158,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     unsigned long long tstamp[4] = {tnow(), 0, 0, 0}, cstamp[2] = {0, 0};
     auto tdump = [&]() {
         if (lane == 0 && A.dbg) {
-            unsigned long long* o = (unsigned long long*)A.dbg + ((size_t)block * 4 + wave) * 6;
+            unsigned long long* o = (unsigned long long*)A.dbg + ((size_t)block * 2 * CT + wave) * 6;
             o[0] = tstamp[0], o[1] = tstamp[1], o[2] = tstamp[2], o[3] = tstamp[3];
             o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
             o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) | ((cstamp[1] - cstamp[0]) << 8);
@@ -166,7 +172,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     const int H = A.H, W = A.W, TPI = A.TH * A.TW;
 
     // ---- staging role: (tile tl, channel quad j, transform half ih) -> 3 patch rows x 4 columns ------------------
-    const int j = tid & 3, tl = (tid >> 2) & 31, ih = __builtin_amdgcn_readfirstlane(tid >> 7);   // (wave-uniform)
+    const int j = tid & 3, tl = (tid >> 2) & 31, ih = __builtin_amdgcn_readfirstlane((tid >> 7) & 1);   // (wave-uniform)
     // Staging loads are bounds-checked buffer loads: an element outside the image (or of a tile past the last) gets the
     // byte offset 0xffffffff and the hardware returns zeros -- no per-lane branch, no select of the four loaded words.
     // Which lanes hold a real pixel for patch element k is wave-uniform DATA (a 64-bit lane mask in scalar registers,
@@ -268,7 +274,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     };
 
     // ---- MFMA role: channel tile wm of the group, transform rows i in {2wx, 2wx+1}, the group's 32 tiles -----------
-    const int co_tile = by * 2 + wm;
+    const int co_tile = by * CT + wm;
     const bool active = co_tile < A.n_cotiles;
     const int nq = (A.Cin / 8) * 16;                              // 16-byte weight units per channel tile (either layout)
     const float4* W4 = A.wpk + (size_t)(active ? co_tile : 0) * nq * 64;      // (scalar; + lane at the load)
@@ -280,8 +286,10 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
 
     const int nchunks = A.Cin / KCH;
     const int ch0 = (int)((long long)slice * nchunks / ks), ch1 = (int)((long long)(slice + 1) * nchunks / ks);
-    stage_load(ch0 * KCH);
-    transform_write(ch0 & 1);
+    if (stager) {
+        stage_load(ch0 * KCH);
+        transform_write(ch0 & 1);
+    }
 #ifndef OSSID_WINO_F32
     // ---- split-bf16 core: per 16-channel chunk and transform position ONE v_mfma_f32_32x32x16_bf16 triple
     // (lo*vh + hi*vl + hi*vh, small terms first) instead of eight v_mfma_f32_32x32x2_f32. Weight units of position xi of
@@ -306,7 +314,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     int p0 = 8 * ch0;
 #pragma unroll 1
     for (int ch = ch0; ch < ch1; ++ch) {
-        if (ch + 1 < ch1) stage_load((ch + 1) * KCH);             // in flight under this chunk's MFMAs
+        if (stager && ch + 1 < ch1) stage_load((ch + 1) * KCH);   // in flight under this chunk's MFMAs
         const float4* pb = vb + (size_t)(ch & 1) * VBUF + (size_t)(8 * wx * 32 + c) * F4 + h;
         float4 bh = pb[0], bl = pb[2];
 #pragma unroll
@@ -318,12 +326,16 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
             acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, vh, acc[e], 0, 0, 0);
             acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, vl, acc[e], 0, 0, 0);
             acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, vh, acc[e], 0, 0, 0);
+#ifndef OSSID_WINO_ABL_NOW          // (ablations, wrong results, timing only: what the loop costs without its weight stream ...
             wq[e & 1][0] = W4[(size_t)unit_of(p0 + e + 2, 0) * 64 + lane];
             wq[e & 1][1] = W4[(size_t)unit_of(p0 + e + 2, 1) * 64 + lane];
+#endif
             __builtin_amdgcn_sched_barrier(0);      // keep this order: the compiler would sink the loads to their use
         }
         p0 += 8;
-        if (ch + 1 < ch1) transform_write((ch + 1) & 1);
+#ifndef OSSID_WINO_ABL_NOTF         // ... and without the input transform of the next chunk)
+        if (stager && ch + 1 < ch1) transform_write((ch + 1) & 1);
+#endif
         __syncthreads();
     }
 #else
@@ -346,7 +358,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     int gi = 4 * ch0;
 #pragma unroll 1
     for (int ch = ch0; ch < ch1; ++ch) {
-        if (ch + 1 < ch1) stage_load((ch + 1) * KCH);             // in flight under this chunk's MFMAs
+        if (stager && ch + 1 < ch1) stage_load((ch + 1) * KCH);   // in flight under this chunk's MFMAs
         const float4* pb = vb + (size_t)(ch & 1) * VBUF + (size_t)(8 * wx * 32 + c) * F4 + h;
         float4 bq = pb[0];
 #pragma unroll
@@ -369,7 +381,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
             }
             ++gi;
         }
-        if (ch + 1 < ch1) transform_write((ch + 1) & 1);
+        if (stager && ch + 1 < ch1) transform_write((ch + 1) & 1);
         __syncthreads();
     }
 #endif
@@ -397,7 +409,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
 #pragma unroll
     for (int b2 = 0; b2 < 2; ++b2)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ex[((size_t)((wm * 2 + wx) * 2 + b2) * 16 + r) * 64 + lane] = give[b2][r];
+        for (int r = 0; r < 16; ++r) ex[((size_t)((wm * 2 + wx) * 2 + b2) * 16 + r) * 64 + lane] = give[b2][r];      // (CT x 2 x 2 x 4 KB: the two V buffers)
     __syncthreads();
 #pragma unroll
     for (int b2 = 0; b2 < 2; ++b2)
@@ -423,26 +435,29 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
 #endif
 }
 
-__global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs A, const WinoTail T) {
+template <int CT>
+__global__ __launch_bounds__(128 * CT, 2) void wino_conv_kernel(const WinoArgs A, const WinoTail T) {
     const int b = blockIdx.x;
     if (T.ks <= 1 || b < T.lcut) {
-        wino_conv_body(A, b);
+        wino_conv_body<CT>(A, b);
     } else {
         const int t = b - T.lcut, j = t / T.ks, sl = t - j * T.ks;
-        wino_conv_body(A, T.lcut + j, sl, T.ks, T.partial + ((size_t)j * T.ks + sl) * WINO_PARTIAL_FLOATS);
+        wino_conv_body<CT>(A, T.lcut + j, sl, T.ks, T.partial + ((size_t)j * T.ks + sl) * wino_partial_floats(CT));
     }
 }
 
 // The tail's second half: one workgroup per tail block adds the ks shares (fixed order: bit-reproducible) and runs the epilogue.
 // (grid: tail blocks x 4 -- blockIdx.y takes one channel quad-row of the tile, so that the handful of tail blocks becomes a
 // few hundred workgroups whose 8 * ks loads per thread are all independent)
+template <int CT>
 __device__ __forceinline__ void wino_finish_body(const WinoArgs& A, const int L, const float* __restrict__ part, const int ks,
                                                  const int q) {
+    constexpr int WINO_PARTIAL_FLOATS = wino_partial_floats(CT);
     int bx, by;
     if (!wino_block_map(A, L, bx, by)) return;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31, wave = tid >> 6;
-    const int wm = wave & 1, wx = wave >> 1;
-    const int co_tile = by * 2 + wm;
+    const int wm = wave % CT, wx = wave / CT;
+    const int co_tile = by * CT + wm;
     if (co_tile >= A.n_cotiles) return;
     v16f keep[2];
     float s[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -473,8 +488,9 @@ __device__ __forceinline__ void wino_finish_body(const WinoArgs& A, const int L,
         }
     wino_epilogue(A, bx, co_tile, wx, c, h, keep, q, q + 1);
 }
-__global__ __launch_bounds__(256) void wino_finish_kernel(const WinoArgs A, const WinoTail T) {
-    wino_finish_body(A, T.lcut + blockIdx.x, T.partial + (size_t)blockIdx.x * T.ks * WINO_PARTIAL_FLOATS, T.ks, blockIdx.y);
+template <int CT>
+__global__ __launch_bounds__(128 * CT) void wino_finish_kernel(const WinoArgs A, const WinoTail T) {
+    wino_finish_body<CT>(A, T.lcut + blockIdx.x, T.partial + (size_t)blockIdx.x * T.ks * wino_partial_floats(CT), T.ks, blockIdx.y);
 }
 
 // Two independent layers in ONE grid (the classification and the regression trunk's i-th convolution, network.py:113-121 /
@@ -485,22 +501,24 @@ struct WinoPair {
     int n0;
     WinoTail t;           // over the COMBINED virtual ids [0, n0 + n1)
 };
-__global__ __launch_bounds__(256, 2) void wino_conv_pair_kernel(const WinoPair G) {
+template <int CT>
+__global__ __launch_bounds__(128 * CT, 2) void wino_conv_pair_kernel(const WinoPair G) {
     int v = blockIdx.x, sl = 0, ks = 1;
     float* part = nullptr;
     if (G.t.ks > 1 && v >= G.t.lcut) {
         const int t = v - G.t.lcut, j = t / G.t.ks;
         sl = t - j * G.t.ks, ks = G.t.ks, v = G.t.lcut + j;
-        part = G.t.partial + ((size_t)j * ks + sl) * WINO_PARTIAL_FLOATS;
+        part = G.t.partial + ((size_t)j * ks + sl) * wino_partial_floats(CT);
     }
-    if (v < G.n0) wino_conv_body(G.a, v, sl, ks, part);
-    else wino_conv_body(G.b, v - G.n0, sl, ks, part);
+    if (v < G.n0) wino_conv_body<CT>(G.a, v, sl, ks, part);
+    else wino_conv_body<CT>(G.b, v - G.n0, sl, ks, part);
 }
-__global__ __launch_bounds__(256) void wino_finish_pair_kernel(const WinoPair G) {
+template <int CT>
+__global__ __launch_bounds__(128 * CT) void wino_finish_pair_kernel(const WinoPair G) {
     const int v = G.t.lcut + blockIdx.x;
-    const float* part = G.t.partial + (size_t)blockIdx.x * G.t.ks * WINO_PARTIAL_FLOATS;
-    if (v < G.n0) wino_finish_body(G.a, v, part, G.t.ks, blockIdx.y);
-    else wino_finish_body(G.b, v - G.n0, part, G.t.ks, blockIdx.y);
+    const float* part = G.t.partial + (size_t)blockIdx.x * G.t.ks * wino_partial_floats(CT);
+    if (v < G.n0) wino_finish_body<CT>(G.a, v, part, G.t.ks, blockIdx.y);
+    else wino_finish_body<CT>(G.b, v - G.n0, part, G.t.ks, blockIdx.y);
 }
 
 // U = G g G^T packed as the kernel streams it. dgrad != 0: the weights of the data gradient (the transposed layer:
@@ -563,7 +581,14 @@ static int wino_args(const ossid_conv_desc* d, WinoArgs& a, long& nwg) {
     const long long T = (long long)B * a.TH * a.TW;
     if (T > 0x7fffffffLL) return OSSID_EINVAL;
     a.T = (int)T;
-    a.gx = (int)((T + 31) / 32), a.gy = (a.n_cotiles + 1) / 2;
+    // 128 output channels per workgroup where the layer has them (the transform of a tile group is then done half as often);
+    // OSSID_WINO_CT=2 / 4 forces one form (A/B runs)
+    static const int ct_env = getenv("OSSID_WINO_CT") ? atoi(getenv("OSSID_WINO_CT")) : 0;
+    // (measured, profiles/r03_wino_ct4.txt: 8-13 % on the 256 / 512-channel layers at 21 templates; at the finetune batch --
+    // 75 tile groups -- the 512-thread workgroups leave the side streams' kernels less room and the step loses 0.4 ms)
+    a.gx = (int)((T + 31) / 32);
+    a.ct = ct_env == 2 || ct_env == 4 ? ct_env : ((a.n_cotiles >= 4 && a.gx >= 128) ? 4 : 2);
+    a.gy = (a.n_cotiles + a.ct - 1) / a.ct;
     const long P = a.gx;
     if (a.gy <= 8 && 8 % a.gy == 0)
         nwg = 8 * ((P + 8 / a.gy - 1) / (8 / a.gy));
@@ -576,8 +601,8 @@ static int wino_args(const ossid_conv_desc* d, WinoArgs& a, long& nwg) {
 // resident workgroups: 1 576 workgroups (768 -> 512 at 21 templates) cost four rounds for 3.08 rounds of work. The last,
 // partial round is therefore cut along the reduction into ks slices per workgroup (one more, shorter round of `tail * ks`
 // workgroups + a finishing launch) whenever that fits the slots and the reduction is long enough to split.
-static void wino_plan_tail(long nwg, int nchunks, WinoTail& t) {
-    const long S = 512;
+static void wino_plan_tail(long nwg, int nchunks, int ct, WinoTail& t) {
+    const long S = ct == 4 ? 256 : 512;       // resident workgroups: two of 256 threads or one of 512 per CU
     t.lcut = (int)((nwg / S) * S), t.ks = 1, t.partial = nullptr;
     const long tail = nwg - t.lcut;
     if (tail == 0) return;
@@ -599,17 +624,17 @@ size_t ossid_conv3x3_wino_workspace_bytes(const ossid_conv_desc* d) {
     long nwg = 0;
     if (wino_args(d, a, nwg) != OSSID_OK) return 0;
     WinoTail t;
-    wino_plan_tail(nwg, a.Cin / KCH, t);
-    return t.ks > 1 ? (size_t)(nwg - t.lcut) * t.ks * WINO_PARTIAL_FLOATS * sizeof(float) : 0;
+    wino_plan_tail(nwg, a.Cin / KCH, a.ct, t);
+    return t.ks > 1 ? (size_t)(nwg - t.lcut) * t.ks * wino_partial_floats(a.ct) * sizeof(float) : 0;
 }
 
 size_t ossid_conv3x3_wino_pair_workspace_bytes(const ossid_conv_desc* d0, const ossid_conv_desc* d1) {
     WinoArgs a, b;
     long n0 = 0, n1 = 0;
-    if (wino_args(d0, a, n0) != OSSID_OK || wino_args(d1, b, n1) != OSSID_OK || a.Cin != b.Cin) return 0;
+    if (wino_args(d0, a, n0) != OSSID_OK || wino_args(d1, b, n1) != OSSID_OK || a.Cin != b.Cin || a.ct != b.ct) return 0;
     WinoTail t;
-    wino_plan_tail(n0 + n1, a.Cin / KCH, t);
-    return t.ks > 1 ? (size_t)(n0 + n1 - t.lcut) * t.ks * WINO_PARTIAL_FLOATS * sizeof(float) : 0;
+    wino_plan_tail(n0 + n1, a.Cin / KCH, a.ct, t);
+    return t.ks > 1 ? (size_t)(n0 + n1 - t.lcut) * t.ks * wino_partial_floats(a.ct) * sizeof(float) : 0;
 }
 
 int ossid_conv3x3_wino_fwd(const ossid_conv_desc* d, void* stream) {
@@ -618,11 +643,11 @@ int ossid_conv3x3_wino_fwd(const ossid_conv_desc* d, void* stream) {
     const int rc = wino_args(d, a, nwg);
     if (rc != OSSID_OK) return rc;
     WinoTail t;
-    wino_plan_tail(nwg, a.Cin / KCH, t);
+    wino_plan_tail(nwg, a.Cin / KCH, a.ct, t);
 #ifndef OSSID_TIMING
     // the tail split needs scratch for the slices' raw sums (desc->scratch, scratch_bytes);
     // without it the launch simply runs whole workgroups
-    const size_t need = t.ks > 1 ? (size_t)(nwg - t.lcut) * t.ks * WINO_PARTIAL_FLOATS * sizeof(float) : 0;
+    const size_t need = t.ks > 1 ? (size_t)(nwg - t.lcut) * t.ks * wino_partial_floats(a.ct) * sizeof(float) : 0;
     if (need && d->scratch && (size_t)d->scratch_bytes >= need) t.partial = (float*)d->scratch;
     else t.ks = 1;
 #else
@@ -630,10 +655,17 @@ int ossid_conv3x3_wino_fwd(const ossid_conv_desc* d, void* stream) {
 #endif
     const long grid = t.ks > 1 ? t.lcut + (nwg - t.lcut) * t.ks : nwg;
     const size_t lds = (size_t)2 * VBUF * 16;
-    OSSID_ENSURE_LDS(wino_conv_kernel, lds);
-    hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a, t);
-    if (t.ks > 1)
-        hipLaunchKernelGGL(wino_finish_kernel, dim3((unsigned)(nwg - t.lcut), 4), dim3(256), 0, (hipStream_t)stream, a, t);
+    if (a.ct == 4) {
+        OSSID_ENSURE_LDS(wino_conv_kernel<4>, lds);
+        hipLaunchKernelGGL(wino_conv_kernel<4>, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a, t);
+        if (t.ks > 1)
+            hipLaunchKernelGGL(wino_finish_kernel<4>, dim3((unsigned)(nwg - t.lcut), 4), dim3(512), 0, (hipStream_t)stream, a, t);
+    } else {
+        OSSID_ENSURE_LDS(wino_conv_kernel<2>, lds);
+        hipLaunchKernelGGL(wino_conv_kernel<2>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a, t);
+        if (t.ks > 1)
+            hipLaunchKernelGGL(wino_finish_kernel<2>, dim3((unsigned)(nwg - t.lcut), 4), dim3(256), 0, (hipStream_t)stream, a, t);
+    }
     return ossid_launch_status();
 }
 
@@ -645,10 +677,11 @@ int ossid_conv3x3_wino_fwd_pair(const ossid_conv_desc* d0, const ossid_conv_desc
     rc = wino_args(d1, g.b, n1);
     if (rc != OSSID_OK) return rc;
     g.n0 = (int)n0;
-    wino_plan_tail(n0 + n1, g.a.Cin / KCH, g.t);
+    if (g.a.ct != g.b.ct) return OSSID_EINVAL;                  // (the two layers of a pair have the same shape)
+    wino_plan_tail(n0 + n1, g.a.Cin / KCH, g.a.ct, g.t);
 #ifndef OSSID_TIMING
     // scratch for the tail slices: d0->scratch / scratch_bytes, see ossid_conv3x3_wino_pair_workspace_bytes
-    const size_t need = g.t.ks > 1 ? (size_t)(n0 + n1 - g.t.lcut) * g.t.ks * WINO_PARTIAL_FLOATS * sizeof(float) : 0;
+    const size_t need = g.t.ks > 1 ? (size_t)(n0 + n1 - g.t.lcut) * g.t.ks * wino_partial_floats(g.a.ct) * sizeof(float) : 0;
     if (need && g.a.Cin == g.b.Cin && d0->scratch && (size_t)d0->scratch_bytes >= need) g.t.partial = (float*)d0->scratch;
     else g.t.ks = 1;
 #else
@@ -657,9 +690,15 @@ int ossid_conv3x3_wino_fwd_pair(const ossid_conv_desc* d0, const ossid_conv_desc
     const long tail = n0 + n1 - g.t.lcut;
     const long grid = g.t.ks > 1 ? g.t.lcut + tail * g.t.ks : n0 + n1;
     const size_t lds = (size_t)2 * VBUF * 16;
-    OSSID_ENSURE_LDS(wino_conv_pair_kernel, lds);
-    hipLaunchKernelGGL(wino_conv_pair_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, g);
-    if (g.t.ks > 1) hipLaunchKernelGGL(wino_finish_pair_kernel, dim3((unsigned)tail, 4), dim3(256), 0, (hipStream_t)stream, g);
+    if (g.a.ct == 4) {
+        OSSID_ENSURE_LDS(wino_conv_pair_kernel<4>, lds);
+        hipLaunchKernelGGL(wino_conv_pair_kernel<4>, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, g);
+        if (g.t.ks > 1) hipLaunchKernelGGL(wino_finish_pair_kernel<4>, dim3((unsigned)tail, 4), dim3(512), 0, (hipStream_t)stream, g);
+    } else {
+        OSSID_ENSURE_LDS(wino_conv_pair_kernel<2>, lds);
+        hipLaunchKernelGGL(wino_conv_pair_kernel<2>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, g);
+        if (g.t.ks > 1) hipLaunchKernelGGL(wino_finish_pair_kernel<2>, dim3((unsigned)tail, 4), dim3(256), 0, (hipStream_t)stream, g);
+    }
     return ossid_launch_status();
 }
 

@@ -2,6 +2,7 @@
 (the same kernel on the rotated weights) and weight gradient (kernel + slab reduction), each timed alone with HIP events.
 The layer list is DtoidNet's (models/dtoid/network.py: DenseNet-121 blocks at 120x160 / 60x80 / 30x40 / 29x39, the
 correlation / fusion / decoder / cls / reg convolutions).  python tools/train_layers_bench.py [--batch 8] [--what wgrad,fwd,dgrad]"""
+import re
 import argparse
 import json
 import os
@@ -63,7 +64,7 @@ def main():
     rows = []
     print("%-22s %3s %5s %5s %9s | " % ("layer", "n", "Cin", "Cout", "HxW") + " | ".join("%-7s ms   TF/s" % w for w in what))
     for name, count, cin, cout, H, W, taps, src, extra in layers():
-        if a.only and a.only not in name:
+        if a.only and not re.search(a.only, name):
             continue
         Hs, Ws = (H, W) if src is None else src
         k = 3 if taps == 9 else 1
