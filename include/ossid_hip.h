@@ -244,7 +244,9 @@ int ossid_conv3x3_wino_fwd_pair(const ossid_conv_desc* desc0_host, const ossid_c
  * ossid_seg_tail_pack_weights(w1 [16][32][3][3]); post = * post_scale[16] + post_shift[16] (eval-mode BatchNorm);
  * w2 [16][3][3] (the [1][16][3][3] weight); b2 [1] (device, may be NULL); out [B][H][W]. Both convolutions zero-pad at the [H][W] border. The
  * 16-channel full-resolution tensor is never materialised. Returns OSSID_EINVAL when the up-sampling ratio is
- * below ~1.5 (the source footprint of a tile would not fit the staged patch): run the two layers separately then. */
+ * below ~1.5 (the source footprint of a tile would not fit the staged patch): run the two layers separately then.
+ * Arithmetic: the 32 -> 16 convolution on split-bf16 matrix-core products (as ossid_conv_desc.exact = 0: 8e-6 of the output
+ * scale measured against float64; -DOSSID_SEGTAIL_F32 builds: exact f32, 1e-6), the 16 -> 1 convolution as f32 fmaf chains. */
 size_t ossid_seg_tail_packed_floats(void);
 int ossid_seg_tail_pack_weights(const float* w1, float* w1p, void* stream);
 int ossid_seg_tail_fwd(const float* x, int batch, int src_height, int src_width, int in_channel_stride, int height,

@@ -11,6 +11,12 @@
 // needs on v_mfma_f32_16x16x4_f32 (16 output channels = one tile, no padding waste) into LDS, and finishes with the
 // 144-tap second conv on the vector ALUs (weights broadcast from LDS).
 //
+// Arithmetic of the first conv (default build): split-bf16, as csrc/conv.hip -- every f32 product is three
+// v_mfma_f32_16x16x32_bf16 (w_lo*x_hi + w_hi*x_lo + w_hi*x_hi, f32 accumulation; K = 32 = all input channels of a tap in
+// ONE instruction): 48 pipe cycles per tap and 16-pixel tile instead of 256. The source patch is split when it is staged
+// ([pixel][hi 32 ch | lo 32 ch] bf16, same 144-byte pixel stride), the weights -- including the row-merged ones, merged in
+// f32 first -- when they are packed. -DOSSID_SEGTAIL_F32 keeps the exact-f32 form described next.
+//
 // MFMA operand layout (16x16x4, one block): A = weights, lane l holds W[co = l%16][k = l/16]; B = activations, lane l
 // holds X[k = l/16][px = l%16]; D: lane l holds rows co = 4*(l/16)+r (r = 0..3) of column px = l%16. A lane's B quad is
 // ONE ds_read_b128 of four consecutive channels of its pixel (k-group g = l/16 <-> channels 16*cb + 4g + i for the i-th
@@ -60,6 +66,39 @@ __device__ __forceinline__ float elu_fast(float x) {
 
 __device__ __forceinline__ int src_index(int dst, float scale, int n_src) {
     return min((int)floorf((float)dst * scale), n_src - 1);   // F.interpolate(mode="nearest")
+}
+
+// ---- second conv (16 -> 1) on the vector ALUs: one output pixel per thread, two passes; weights broadcast from LDS
+// (measured alternatives: weights through scalar loads, two rows per thread -- both slower)
+__device__ __forceinline__ void seg_tail_second_conv(const SegTailArgs& A, const float* mid, const float* w2s, const int y0,
+                                                     const int x0, const int b) {
+    const int tid = threadIdx.x, H = A.H, W = A.W;
+#ifdef ST_ABL_NOCONV2
+    for (int p = tid; p < 1; p += 256) {
+#else
+    for (int p = tid; p < ST_TH * ST_TW; p += 256) {
+#endif
+        const int oy = p / ST_TW, ox = p - oy * ST_TW;
+        const int y = y0 + oy, x = x0 + ox;
+        if (y >= H || x >= W) continue;
+        float s = A.b2 ? A.b2[0] : 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const float* m = mid + (size_t)((oy + dy) * ST_MW + ox + dx) * ST_MSTRIDE;
+                const float* w = w2s + (dy * 3 + dx) * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *(const float4*)(m + 4 * q), k = *(const float4*)(w + 4 * q);
+                    s = fmaf(v.x, k.x, s);
+                    s = fmaf(v.y, k.y, s);
+                    s = fmaf(v.z, k.z, s);
+                    s = fmaf(v.w, k.w, s);
+                }
+            }
+        A.out[((size_t)b * H + y) * W + x] = s;
+    }
 }
 
 __global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A, const float* __restrict__ w2) {
@@ -230,35 +269,199 @@ __global__ __launch_bounds__(256, 2) void seg_tail_kernel(const SegTailArgs A, c
     }
     __syncthreads();
 
-    // ---- second conv (16 -> 1) on the vector ALUs: one output pixel per thread, two passes; weights broadcast from LDS
-    // (measured alternatives: weights through scalar loads, two rows per thread -- both slower) ---------------------------
-#ifdef ST_ABL_NOCONV2
-    for (int p = tid; p < 1; p += 256) {
-#else
-    for (int p = tid; p < ST_TH * ST_TW; p += 256) {
-#endif
-        const int oy = p / ST_TW, ox = p - oy * ST_TW;
-        const int y = y0 + oy, x = x0 + ox;
-        if (y >= H || x >= W) continue;
-        float s = A.b2 ? A.b2[0] : 0.0f;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const float* m = mid + (size_t)((oy + dy) * ST_MW + ox + dx) * ST_MSTRIDE;
-                const float* w = w2s + (dy * 3 + dx) * 16;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v = *(const float4*)(m + 4 * q), k = *(const float4*)(w + 4 * q);
-                    s = fmaf(v.x, k.x, s);
-                    s = fmaf(v.y, k.y, s);
-                    s = fmaf(v.z, k.z, s);
-                    s = fmaf(v.w, k.w, s);
-                }
-            }
-        A.out[((size_t)b * H + y) * W + x] = s;
-    }
+    seg_tail_second_conv(A, mid, w2s, y0, x0, b);
 }
+
+#ifndef OSSID_SEGTAIL_F32
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+// Packed weights of the split form: [15 operands][hi, lo][64 lanes] 16 bytes. Operand o = combo * 3 + dx with combo 0 / 1 / 2
+// = kernel row ky, 3 = rows 0 + 1 merged, 4 = rows 1 + 2 merged (the row merging of the f32 kernel, done once here);
+// lane (co = l % 16, g = l / 16) holds channels 8g .. 8g + 7 of W_o[co] as bf16.
+constexpr int ST_SB_OPS = 15;
+__global__ __launch_bounds__(256) void seg_tail_pack_sb_kernel(const float* __restrict__ w1, float4* __restrict__ w1p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ST_SB_OPS * 2 * 64) return;
+    const int lane = i & 63, part = (i >> 6) & 1, o = i >> 7, combo = o / 3, dx = o - combo * 3, g = lane >> 4, co = lane & 15;
+    union {
+        __bf16 b[8];
+        float4 f;
+    } u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float* w = w1 + ((size_t)co * ST_CIN + 8 * g + e) * 9 + dx;
+        const float v = combo < 3 ? w[combo * 3] : (combo == 3 ? w[0] + w[3] : w[3] + w[6]);
+        const __bf16 hi = (__bf16)v;
+        u.b[e] = part == 0 ? hi : (__bf16)(v - (float)hi);
+    }
+    w1p[i] = u.f;
+}
+
+__global__ __launch_bounds__(256, 2) void seg_tail_sb_kernel(const SegTailArgs A, const float* __restrict__ w2) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* patch = lds;                     // per source pixel ST_PSTRIDE floats: [hi: 32 x bf16][lo: 32 x bf16][16 bytes pad]
+    float* mid = lds + ST_PATCH_FLOATS;
+    float* w2s = mid + ST_MID_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
+    const int y0 = ty * ST_TH, x0 = tx * ST_TW;
+    const int H = A.H, W = A.W;
+
+    const int sr0 = src_index(max(y0 - 2, 0), A.scale_h, A.Hs), sr1 = src_index(min(y0 + ST_TH + 1, H - 1), A.scale_h, A.Hs);
+    const int sc0 = src_index(max(x0 - 2, 0), A.scale_w, A.Ws), sc1 = src_index(min(x0 + ST_TW + 1, W - 1), A.scale_w, A.Ws);
+    const int nr = sr1 - sr0 + 1, nc = sc1 - sc0 + 1;
+    {
+        const int nf4 = nr * nc * (ST_CIN / 4);
+        for (int i = tid; i < nf4; i += 256) {
+            const int p = i >> 3, j = i & 7;
+            const int r = p / nc, cc = p - r * nc;
+            const float4 v = *(const float4*)(A.x + ((size_t)(b * A.Hs + sr0 + r) * A.Ws + sc0 + cc) * A.in_cs + 4 * j);
+            const float f[4] = {v.x, v.y, v.z, v.w};
+            union {
+                __bf16 h[4];
+                uint2 u;
+            } hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi.h[e] = (__bf16)f[e];
+                lo.h[e] = (__bf16)(f[e] - (float)hi.h[e]);
+            }
+            char* px = (char*)(patch + (size_t)(r * ST_PC + cc) * ST_PSTRIDE);
+            *(uint2*)(px + 8 * j) = hi.u;
+            *(uint2*)(px + 64 + 8 * j) = lo.u;
+        }
+        if (tid < 144) w2s[tid] = w2[(tid & 15) * 9 + (tid >> 4)];
+        if (tid < ST_PSTRIDE / 4) *(float4*)(patch + (size_t)ST_PR * ST_PC * ST_PSTRIDE + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 wsb[ST_SB_OPS][2];               // every operand, hi and lo, resident in registers
+#pragma unroll
+    for (int o = 0; o < ST_SB_OPS; ++o)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) wsb[o][part] = A.w1p[(o * 2 + part) * 64 + lane];
+    float bias4[4], sc4[4], sh4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias4[r] = A.b1[4 * g + r], sc4[r] = A.bn_scale[4 * g + r], sh4[r] = A.bn_shift[4 * g + r];
+    __syncthreads();
+
+    const int zero_off = ST_PR * ST_PC * ST_PSTRIDE;
+    int cofs[2][3];
+    bool cin[2];
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        const int X = x0 - 1 + hx * 16 + c;
+        cin[hx] = X >= 0 && X < W;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int xx = X - 1 + d;
+            cofs[hx][d] = (xx >= 0 && xx < W) ? (src_index(xx, A.scale_w, A.Ws) - sc0) * ST_PSTRIDE + 4 * g : -1;
+        }
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool can_merge = 2.0f * A.scale_h <= 1.0f;
+#pragma unroll 1
+    for (int t0 = 2 * wave_u; t0 < ST_MH * 2; t0 += 8) {
+        const int my = t0 >> 1;
+        const int Y = y0 - 1 + my;
+        int rofs[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = Y - 1 + dy;
+            rofs[dy] = (yy >= 0 && yy < H) ? (src_index(yy, A.scale_h, A.Hs) - sr0) * (ST_PC * ST_PSTRIDE) : -1;
+        }
+        bool inside[2];
+        int mpos[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            inside[u] = Y >= 0 && Y < H && cin[u];
+            mpos[u] = (my * ST_MW + u * 16 + c) * ST_MSTRIDE + 4 * g;
+        }
+        v4f acc0 = {bias4[0], bias4[1], bias4[2], bias4[3]}, acc1 = acc0;
+        // one tap of both tiles: the operands of the NEXT tap are read by the caller while these six MFMAs run
+        auto tap3 = [&](const float4& whi, const float4& wlo, const float4& h0, const float4& l0, const float4& h1, const float4& l1) {
+            const v8bf ah = __builtin_bit_cast(v8bf, whi), al = __builtin_bit_cast(v8bf, wlo);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(v8bf, h0), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(v8bf, h1), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(v8bf, l0), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(v8bf, l1), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(v8bf, h0), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(v8bf, h1), acc1, 0, 0, 0);
+        };
+        const bool interior = rofs[0] >= 0 && rofs[2] >= 0;
+        const bool va = rofs[1] == rofs[2], vb = rofs[0] == rofs[1];
+        if (can_merge && interior && (va || vb)) {
+            // variant A: rows 1,2 share a source row -> operands (row 0 | rows 1+2); B: rows 0,1 do -> (rows 0+1 | row 2)
+            const int r0 = rofs[0], r1 = va ? rofs[1] : rofs[2];
+            int off[2][6];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int cf = cofs[u][dx];
+                    off[u][dx] = cf >= 0 ? r0 + cf : zero_off + 4 * g;
+                    off[u][3 + dx] = cf >= 0 ? r1 + cf : zero_off + 4 * g;
+                }
+            float4 h0 = *(const float4*)(patch + off[0][0]), l0 = *(const float4*)(patch + off[0][0] + 16);
+            float4 h1 = *(const float4*)(patch + off[1][0]), l1 = *(const float4*)(patch + off[1][0] + 16);
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+                const int sn = st + 1 < 6 ? st + 1 : st, dx = st % 3;
+                const float4 nh0 = *(const float4*)(patch + off[0][sn]), nl0 = *(const float4*)(patch + off[0][sn] + 16);
+                const float4 nh1 = *(const float4*)(patch + off[1][sn]), nl1 = *(const float4*)(patch + off[1][sn] + 16);
+                // (wave-uniform choice between two resident operands: selects, no branch)
+                const int oa = (st < 3 ? 0 : 4) * 3 + dx, ob = (st < 3 ? 3 : 2) * 3 + dx;
+                float4 whi, wlo;
+                whi.x = va ? wsb[oa][0].x : wsb[ob][0].x, whi.y = va ? wsb[oa][0].y : wsb[ob][0].y;
+                whi.z = va ? wsb[oa][0].z : wsb[ob][0].z, whi.w = va ? wsb[oa][0].w : wsb[ob][0].w;
+                wlo.x = va ? wsb[oa][1].x : wsb[ob][1].x, wlo.y = va ? wsb[oa][1].y : wsb[ob][1].y;
+                wlo.z = va ? wsb[oa][1].z : wsb[ob][1].z, wlo.w = va ? wsb[oa][1].w : wsb[ob][1].w;
+                __builtin_amdgcn_sched_barrier(0);
+                tap3(whi, wlo, h0, l0, h1, l1);
+                __builtin_amdgcn_sched_barrier(0);
+                h0 = nh0, l0 = nl0, h1 = nh1, l1 = nl1;
+            }
+        } else {
+            int off[2][9];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int cf = cofs[u][dx];
+                        off[u][dy * 3 + dx] = (rofs[dy] >= 0 && cf >= 0) ? rofs[dy] + cf : zero_off + 4 * g;
+                    }
+            float4 h0 = *(const float4*)(patch + off[0][0]), l0 = *(const float4*)(patch + off[0][0] + 16);
+            float4 h1 = *(const float4*)(patch + off[1][0]), l1 = *(const float4*)(patch + off[1][0] + 16);
+#pragma unroll
+            for (int st = 0; st < 9; ++st) {
+                const int sn = st + 1 < 9 ? st + 1 : st;
+                const float4 nh0 = *(const float4*)(patch + off[0][sn]), nl0 = *(const float4*)(patch + off[0][sn] + 16);
+                const float4 nh1 = *(const float4*)(patch + off[1][sn]), nl1 = *(const float4*)(patch + off[1][sn] + 16);
+                __builtin_amdgcn_sched_barrier(0);
+                tap3(wsb[st][0], wsb[st][1], h0, l0, h1, l1);          // operand (ky, dx) = combo ky, column dx = index st
+                __builtin_amdgcn_sched_barrier(0);
+                h0 = nh0, l0 = nl0, h1 = nh1, l1 = nl1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const v4f acc = u ? acc1 : acc0;
+            float4 o;
+            float* op = &o.x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[r];
+                v = elu_fast(v);
+                op[r] = inside[u] ? v * sc4[r] + sh4[r] : 0.0f;
+            }
+            *(float4*)(mid + mpos[u]) = o;
+        }
+    }
+    __syncthreads();
+    seg_tail_second_conv(A, mid, w2s, y0, x0, b);
+}
+#endif
 
 // w1 [16][32][3][3] (torch) -> [tap][cb][lane = g*16 + co] float4 of channels 16cb + 4g + 0..3
 __global__ __launch_bounds__(256) void seg_tail_pack_kernel(const float* __restrict__ w1, float4* __restrict__ w1p) {
@@ -275,6 +478,16 @@ __global__ __launch_bounds__(256) void seg_tail_pack_kernel(const float* __restr
 
 extern "C" {
 
+#ifndef OSSID_SEGTAIL_F32
+size_t ossid_seg_tail_packed_floats(void) { return ST_SB_OPS * 2 * 64 * 4; }
+
+int ossid_seg_tail_pack_weights(const float* w1, float* w1p, void* stream) {
+    if (!w1 || !w1p) return OSSID_EINVAL;
+    hipLaunchKernelGGL(seg_tail_pack_sb_kernel, dim3((ST_SB_OPS * 2 * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w1,
+                       (float4*)w1p);
+    return ossid_launch_status();
+}
+#else
 size_t ossid_seg_tail_packed_floats(void) { return 18 * 64 * 4; }
 
 int ossid_seg_tail_pack_weights(const float* w1, float* w1p, void* stream) {
@@ -282,6 +495,7 @@ int ossid_seg_tail_pack_weights(const float* w1, float* w1p, void* stream) {
     hipLaunchKernelGGL(seg_tail_pack_kernel, dim3(5), dim3(256), 0, (hipStream_t)stream, w1, (float4*)w1p);
     return ossid_launch_status();
 }
+#endif
 
 int ossid_seg_tail_fwd(const float* x, int batch, int src_height, int src_width, int in_channel_stride, int height,
                        int width, const float* w1p, const float* b1, const float* post_scale, const float* post_shift,
@@ -300,8 +514,13 @@ int ossid_seg_tail_fwd(const float* x, int batch, int src_height, int src_width,
     if (need_r > ST_PR || need_c > ST_PC) return OSSID_EINVAL;
     a.tiles_x = (width + ST_TW - 1) / ST_TW, a.tiles_y = (height + ST_TH - 1) / ST_TH;
     const int lds = ST_LDS_FLOATS * 4;
+#ifndef OSSID_SEGTAIL_F32
+    OSSID_ENSURE_LDS(seg_tail_sb_kernel, (size_t)lds);
+    hipLaunchKernelGGL(seg_tail_sb_kernel, dim3(a.tiles_x * a.tiles_y, batch), dim3(256), lds, (hipStream_t)stream, a, w2);
+#else
     OSSID_ENSURE_LDS(seg_tail_kernel, (size_t)lds);
     hipLaunchKernelGGL(seg_tail_kernel, dim3(a.tiles_x * a.tiles_y, batch), dim3(256), lds, (hipStream_t)stream, a, w2);
+#endif
     return ossid_launch_status();
 }
 
