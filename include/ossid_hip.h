@@ -247,6 +247,7 @@ int ossid_conv3x3_wino_fwd_pair(const ossid_conv_desc* desc0_host, const ossid_c
  * below ~1.5 (the source footprint of a tile would not fit the staged patch): run the two layers separately then.
  * Arithmetic: the 32 -> 16 convolution on split-bf16 matrix-core products (as ossid_conv_desc.exact = 0: 8e-6 of the output
  * scale measured against float64; -DOSSID_SEGTAIL_F32 builds: exact f32, 1e-6), the 16 -> 1 convolution as f32 fmaf chains. */
+int ossid_seg_tail_split_bf16(void);
 size_t ossid_seg_tail_packed_floats(void);
 int ossid_seg_tail_pack_weights(const float* w1, float* w1p, void* stream);
 int ossid_seg_tail_fwd(const float* x, int batch, int src_height, int src_width, int in_channel_stride, int height,

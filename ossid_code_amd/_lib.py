@@ -55,6 +55,7 @@ _PROTOS = {
     "ossid_conv_wino_split_bf16": (_i, []),
     "ossid_conv_split_bf16": (_i, []),
     "ossid_conv_wgrad_split_bf16": (_i, []),
+    "ossid_seg_tail_split_bf16": (_i, []),
     "ossid_zephyr_prep_frame_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ossid_zephyr_prep_frame_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ossid_zephyr_prep_model": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
@@ -303,6 +304,8 @@ def _pipe_flops(name, args, flops):
     if name == "ossid_conv_nhwc_fwd":
         split = lib().ossid_conv_split_bf16() and not (args and args[0]._obj.exact)
         return flops * (SPLIT_BF16_PIPE_WEIGHT if split else 1.0)
+    if name == "ossid_seg_tail_fwd":
+        return flops * (SPLIT_BF16_PIPE_WEIGHT if lib().ossid_seg_tail_split_bf16() else 1.0)
     if name == "ossid_conv_wgrad" and args:
         return _wgrad_pipe(args[0]._obj)
     if name == "ossid_conv_wgrad_group" and args:

@@ -478,6 +478,14 @@ __global__ __launch_bounds__(256) void seg_tail_pack_kernel(const float* __restr
 
 extern "C" {
 
+int ossid_seg_tail_split_bf16(void) {
+#ifndef OSSID_SEGTAIL_F32
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 #ifndef OSSID_SEGTAIL_F32
 size_t ossid_seg_tail_packed_floats(void) { return ST_SB_OPS * 2 * 64 * 4; }
 
