@@ -128,9 +128,10 @@ def test_data_gradient_is_the_forward_kernel_on_dgrad_packed_weights(hiplib, B, 
                                               (2, 64, 48, 120, 160, 3)])    # wide image: 2-D pixel tiles
 def test_convolution_forms_exact_f32_and_split_bf16_against_float64(hiplib, B, Cin, Cout, H, W, k):
     """ossid_conv_desc.exact: the same launch on v_mfma_f32_32x32x2_f32 (exact f32 products) and as three bf16 matrix-core
-    products per f32 product, forward and data-gradient weight layouts, against float64. The stated bounds -- 2e-6 and 2e-5
-    of the largest output -- are what every other tolerance in this file builds on; the split form must also be the less
-    exact of the two (otherwise the flag would select nothing)."""
+    products per f32 product, forward and data-gradient weight layouts, against float64. The stated bounds -- 5e-6 (f32
+    accumulation over up to 6 912 terms: measured 1e-6 .. 3.3e-6) and 2e-5 of the largest output -- are what every other
+    tolerance in this file builds on; the split form must also be the less exact of the two (otherwise the flag would
+    select nothing)."""
     g = torch.Generator().manual_seed(Cin + 7 * Cout + k)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
@@ -141,14 +142,14 @@ def test_convolution_forms_exact_f32_and_split_bf16_against_float64(hiplib, B, C
         out = T.empty_nhwc(B, Cout, H, W, "cuda")
         T.conv_raw(xd, T._pack(wd, kind), B, H, W, Cin, Cout, k * k, out)
         err[kind] = rel(out, want)
-    assert err["fwd_exact"] < 2e-6 and err["fwd"] < 2e-5, err
+    assert err["fwd_exact"] < 5e-6 and err["fwd"] < 2e-5, err
     if hiplib.lib().ossid_conv_split_bf16():
         assert err["fwd"] > err["fwd_exact"], err
     if Cout % 16 == 0:
         dy = torch.randn(B, Cout, H, W, generator=g)
         xg = x.double().requires_grad_(True)
         F.conv2d(xg, w.double(), padding=k // 2).backward(dy.double())
-        for kind, tol in (("dgrad_exact", 2e-6), ("dgrad", 2e-5)):
+        for kind, tol in (("dgrad_exact", 5e-6), ("dgrad", 2e-5)):
             dx = T.empty_nhwc(B, Cin, H, W, "cuda")
             T.conv_raw(cl(dy), T._pack(wd, kind), B, H, W, Cout, Cin, k * k, dx)
             assert rel(dx, xg.grad) < tol, (kind, rel(dx, xg.grad))
