@@ -274,9 +274,8 @@ int ossid_conv3x3_wgrad(const float* x, const float* dy, int B, int H, int W, in
  * [B][H][W][dy_channel_stride] channels-last (0 = cin / cout); dw in torch layout [cout][cin][kh][kw]. Operands are staged
  * through LDS with the pixels on K: as bf16 hi/lo images read back K-major (ds_read_b64_tr_b16) for three
  * v_mfma_f32_32x32x16_bf16 per f32 product (split-bf16, ~5e-6 of the result's scale; ossid_conv_wgrad_split_bf16() != 0),
- * or as f32 for v_mfma_f32_32x32x2_f32 (3x3 layers with cout <= 32 and cin <= 64, and every layer of a -DOSSID_WGRAD_F32
- * build); split-K slabs in `workspace` (ossid_conv_wgrad_workspace_bytes), summed in a fixed order -- bit-reproducible,
- * no float atomics. cin, cout % 4 == 0. */
+ * or as f32 for v_mfma_f32_32x32x2_f32 (every layer of a -DOSSID_WGRAD_F32 build); split-K slabs in `workspace`
+ * (ossid_conv_wgrad_workspace_bytes), summed in a fixed order -- bit-reproducible, no float atomics. cin, cout % 4 == 0. */
 typedef struct ossid_wgrad_desc {
     const float* x;
     const float* dy;

@@ -291,11 +291,8 @@ SPLIT_BF16_PIPE_WEIGHT = 3.0 / 16.0
 
 
 def _wgrad_pipe(d):
-    """f32-pipe-equivalent flops of one weight gradient: the tilings of few-channel 3x3 layers (Cout <= 32 and Cin <= 64:
-    csrc/train.hip, wgrad_plan variants 5 / 6) stay on the f32 instruction, everything else runs split."""
-    f = _wgrad_flops_d(d)
-    few = d.taps == 9 and d.cout <= 32 and d.cin <= 64
-    return f * (SPLIT_BF16_PIPE_WEIGHT if (lib().ossid_conv_wgrad_split_bf16() and not few) else 1.0)
+    """f32-pipe-equivalent flops of one weight gradient."""
+    return _wgrad_flops_d(d) * (SPLIT_BF16_PIPE_WEIGHT if lib().ossid_conv_wgrad_split_bf16() else 1.0)
 
 
 def _pipe_flops(name, args, flops):

@@ -605,24 +605,26 @@ __host__ __device__ constexpr int wgrad_sb_pitch(int channels) {      // bytes
     return channels == 128 ? 320 : (channels == 64 ? 192 : (channels == 32 ? 64 : channels * 2 + 64));
 }
 
-template <int TAPS, int KYB, int TM, int TN, int WM, int WN>
+template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
 __device__ __forceinline__ void wgrad_sb_body(const WgradArgs& A, const int L) {
     constexpr int CO_T = WM * TM * 32, CI_T = WN * TN * 32;
     constexpr int KX = TAPS == 9 ? 3 : 1;
     constexpr int NT = TM * TN * KX * KYB;
     constexpr int HALO = TAPS == 9 ? 2 : 0;
-    constexpr int KTMAX = 48;
+    constexpr int KTMAX = 64;
     constexpr int DY4 = CO_T / 4, X4 = CI_T / 4;
     constexpr int NLD_DY = (KTMAX * DY4 + 255) / 256, NLD_X = (KYB * (KTMAX + HALO) * X4 + 255) / 256;
     constexpr int PD = wgrad_sb_pitch(CO_T), PX = wgrad_sb_pitch(CI_T);
-    static_assert(WM * WN == 4 && 256 % DY4 == 0 && 256 % X4 == 0, "bad tiling");
+    static_assert(WM * WN * WK == 4 && 256 % DY4 == 0 && 256 % X4 == 0, "bad tiling");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int KT = A.KT;                                     // a multiple of 16 here
     const int dy_img = KT * PD, x_img = KYB * (KT + HALO) * PX;          // bytes per part
     char* dyl = (char*)lds;                                  // [2 parts][KT][PD]
     char* xl = dyl + 2 * dy_img;                             // [2 parts][KYB][KT + HALO][PX]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
-    const int wm = wave % WM, wn = wave / WM;
+    // WK > 1 (few-channel layers: one or two 32 x 32 tiles of (co, ci) per kernel row): the waves share the tiles and take
+    // every WK-th 16-pixel k-step of a chunk, each writes its own slab (index split * WK + wk)
+    const int wm = wave % WM, wn = (wave / WM) % WN, wk = wave / (WM * WN);
 
     const int split = L / A.ntiles;
     int tile = L - split * A.ntiles;
@@ -753,7 +755,7 @@ __device__ __forceinline__ void wgrad_sb_body(const WgradArgs& A, const int L) {
         advance(gb, gy, gcr);
         if (nxt < A.n_chunks) stage_load(gb, gy, gcr);       // in flight under this chunk's MFMAs
 #pragma unroll 1
-        for (int k = 0; k < ksteps; ++k) {
+        for (int k = wk; k < ksteps; k += WK) {
             v8bf16 a[TM][2], bv[KYB][TN][KX][2];
 #pragma unroll
             for (int m = 0; m < TM; ++m)
@@ -787,7 +789,7 @@ __device__ __forceinline__ void wgrad_sb_body(const WgradArgs& A, const int L) {
         __syncthreads();                                      // every wave has read this chunk's images
     }
 
-    float* slab = A.slabs + (size_t)split * TAPS * A.Cout * A.Cin;
+    float* slab = A.slabs + ((size_t)split * WK + wk) * TAPS * A.Cout * A.Cin;
 #pragma unroll
     for (int kr = 0; kr < KYB; ++kr)
 #pragma unroll
@@ -811,7 +813,7 @@ __device__ __forceinline__ void wgrad_sb_body(const WgradArgs& A, const int L) {
 
 template <bool SB, int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
 __device__ __forceinline__ void wgrad_any_body(const WgradArgs& A, const int L) {
-    if constexpr (SB && WK == 1) wgrad_sb_body<TAPS, KYB, TM, TN, WM, WN>(A, L);
+    if constexpr (SB) wgrad_sb_body<TAPS, KYB, TM, TN, WM, WN, WK>(A, L);
     else wgrad_body<TAPS, KYB, TM, TN, WM, WN, WK>(A, L);
 }
 
@@ -946,10 +948,14 @@ bool wgrad_plan(int B, int H, int W, int Cin, int Cout, int taps, WgradPlan& p) 
         else if (Cout <= 64 || Cout == 96) p.variant = 1, p.co_t = 64, p.ci_t = 128, p.tiles_per_wave = 6;
         else p.variant = 0, p.co_t = 128, p.ci_t = 64, p.tiles_per_wave = 6;
         p.B = B, p.H = H, p.W = W;
-        p.sb = OSSID_WGRAD_SB && p.wk == 1;
+        p.sb = OSSID_WGRAD_SB;
+        // split form: k-steps of 16 pixels, WK of them per chunk for the tilings whose waves share the k-steps
+        if (p.sb && p.variant == 5) ktmax = 64;
+        if (p.sb && p.variant == 6) ktmax = 32;
         p.chunks_per_row = (W + ktmax - 1) / ktmax;
         p.KT = p.sb ? ((W + p.chunks_per_row - 1) / p.chunks_per_row + 15) & ~15
                     : ((W + p.chunks_per_row - 1) / p.chunks_per_row + 1) & ~1;
+        if (p.sb && p.KT < 16 * p.wk) p.KT = 16 * p.wk;
     } else if (taps == 1) {
         if (Cout <= 64) p.variant = 4, p.co_t = 64, p.ci_t = 128, p.tiles_per_wave = 2;
         else p.variant = 3, p.co_t = 128, p.ci_t = 128, p.tiles_per_wave = 4;
@@ -971,7 +977,7 @@ bool wgrad_plan(int B, int H, int W, int Cin, int Cout, int taps, WgradPlan& p) 
     // slab (written here, read by the reduction). Model, in microseconds: rounds of resident workgroups x (chunks per
     // workgroup x MFMA time of a chunk + a fixed ~4 us to fill the pipeline and store the tiles) + slab traffic at ~3 TB/s.
     const int per_cu = p.lds > 80 * 1024 ? 1 : (p.lds > 53 * 1024 ? 2 : 3);
-    const double t_chunk = p.sb ? (double)(p.KT / 16) * p.tiles_per_wave * 96.0 / 2400.0 + 0.5
+    const double t_chunk = p.sb ? (double)(p.KT / 16) * p.tiles_per_wave / p.wk * 96.0 / 2400.0 + 0.5
                                 : (double)(p.KT / 2) * p.tiles_per_wave / p.wk * 64.0 / 2400.0 + 0.35;
     const double dw_bytes = (double)taps * Cout * Cin * 4.0;
     double best = 1e30;
@@ -999,9 +1005,7 @@ int launch_wgrad_group_form(const WgradGroup& g, size_t lds, hipStream_t s) {
 }
 template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
 int launch_wgrad_group(const WgradGroup& g, size_t lds, bool sb, hipStream_t s) {
-    if constexpr (WK == 1) {
-        if (sb) return launch_wgrad_group_form<true, TAPS, KYB, TM, TN, WM, WN, WK>(g, lds, s);
-    }
+    if (sb) return launch_wgrad_group_form<true, TAPS, KYB, TM, TN, WM, WN, WK>(g, lds, s);
     return launch_wgrad_group_form<false, TAPS, KYB, TM, TN, WM, WN, WK>(g, lds, s);
 }
 
@@ -1015,9 +1019,7 @@ int launch_wgrad_form(const WgradArgs& a, const WgradPlan& p, hipStream_t s) {
 }
 template <int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
 int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t s) {
-    if constexpr (WK == 1) {
-        if (p.sb) return launch_wgrad_form<true, TAPS, KYB, TM, TN, WM, WN, WK>(a, p, s);
-    }
+    if (p.sb) return launch_wgrad_form<true, TAPS, KYB, TM, TN, WM, WN, WK>(a, p, s);
     return launch_wgrad_form<false, TAPS, KYB, TM, TN, WM, WN, WK>(a, p, s);
 }
 
