@@ -611,7 +611,7 @@ __device__ __forceinline__ void wgrad_sb_body(const WgradArgs& A, const int L) {
     constexpr int KX = TAPS == 9 ? 3 : 1;
     constexpr int NT = TM * TN * KX * KYB;
     constexpr int HALO = TAPS == 9 ? 2 : 0;
-    constexpr int KTMAX = 64;
+    constexpr int KTMAX = WK == 4 ? 64 : 48;                 // pixels per chunk at most (the staging registers are sized by it)
     constexpr int DY4 = CO_T / 4, X4 = CI_T / 4;
     constexpr int NLD_DY = (KTMAX * DY4 + 255) / 256, NLD_X = (KYB * (KTMAX + HALO) * X4 + 255) / 256;
     constexpr int PD = wgrad_sb_pitch(CO_T), PX = wgrad_sb_pitch(CI_T);
