@@ -818,7 +818,7 @@ __device__ __forceinline__ void wgrad_any_body(const WgradArgs& A, const int L) 
 }
 
 template <bool SB, int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
+__global__ __launch_bounds__(256, (SB && WK == 1) ? 2 : 1) void wgrad_kernel(const WgradArgs A) {
     wgrad_any_body<SB, TAPS, KYB, TM, TN, WM, WN, WK>(A, blockIdx.x);
 }
 
@@ -832,7 +832,7 @@ struct WgradGroup {
 };
 
 template <bool SB, int TAPS, int KYB, int TM, int TN, int WM, int WN, int WK>
-__global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradGroup G) {
+__global__ __launch_bounds__(256, (SB && WK == 1) ? 2 : 1) void wgrad_group_kernel(const WgradGroup G) {
     int i = 0;
     const int b = blockIdx.x;
     while (i + 1 < G.n && G.first_block[i + 1] <= b) ++i;
