@@ -195,16 +195,19 @@ typedef struct ossid_conv_desc {
     /* Arithmetic of the reduction in ossid_conv_nhwc_fwd (csrc/conv.hip). 0 (default): every f32 product w*x is formed as
      * three bf16 matrix-core products (w = hi + lo, x = hi + lo as bf16 pairs; w_lo*x_hi + w_hi*x_lo + w_hi*x_hi accumulated
      * in f32; the dropped lo*lo term is ~2^-16 of a product): ~5e-6 of the output scale against float64, tests hold 2e-5.
-     * 1: v_mfma_f32_32x32x2_f32, exact f32 products (~1e-6), 3-5x the matrix-pipe time -- for layers whose output feeds a
-     * hard decision that a later pass repeats (the training forward of the ReLU / max-pool networks: a pre-activation that
-     * lands on the other side of zero changes which units the gradient flows through). wpk must be packed for the same
-     * form (ossid_conv_pack_weights_form). A library built with -DOSSID_CONV_F32 runs every launch exact;
+     * 1: v_mfma_f32_32x32x2_f32, exact f32 products (~1e-6), 5x the matrix-pipe time. 2: the three-way split -- operands as
+     * three bf16 pieces (24 significant bits: the f32 value itself), six products, f32-level accuracy (~1e-6) at 2x the
+     * pipe time of form 0 -- for layers whose output feeds a hard decision that a later pass repeats (the training forward
+     * of the ReLU / max-pool networks: a pre-activation that lands on the other side of zero changes which units the
+     * gradient flows through). wpk must be packed for the same form (ossid_conv_pack_weights_form; form 2 needs
+     * ossid_conv_packed_floats_form floats, 1.5x the others). A library built with -DOSSID_CONV_F32 runs every launch exact;
      * ossid_conv_split_bf16() says whether the split form exists. The Winograd entry ignores the field (its own build
      * switch, below). */
     int32_t exact;
 } ossid_conv_desc;
 int ossid_conv_split_bf16(void);
 size_t ossid_conv_packed_floats(int Cout, int Cin, int taps);
+size_t ossid_conv_packed_floats_form(int Cout, int Cin, int taps, int exact);
 /* w [Cout][Cin][taps] -> the operand layout of ossid_conv_nhwc_fwd (common.h, ossid_conv_pack_quad). dgrad != 0: the layer
  * of the DATA gradient (Cin output channels, Cout reduction channels, taps reversed; needs ossid_conv_packed_floats(Cin,
  * Cout, taps) floats). exact: the form of the launches that will read it. ossid_conv_pack_weights = (dgrad 0, exact 0). */
@@ -392,7 +395,7 @@ int ossid_colsum_finalize(const float* partials, int n_partials, int C, float* s
 /* D16  all convolution weights of a training step re-packed in ONE launch (they change every optimizer step): a device
  * table with one row per (layer, layout): kind 0 = the forward layout of ossid_conv_pack_weights, 1 = the data-gradient
  * layout of ossid_conv_pack_weights_dgrad, 2 / 3 = ossid_conv_pack_weights_wino with dgrad = 0 / 1 (taps = 9), 4 / 5 = kinds
- * 0 / 1 for exact launches (ossid_conv_desc::exact); first_block = prefix sum of ceil(packed float4 / 256) over the rows before. */
+ * 0 / 1 for exact launches (ossid_conv_desc::exact = 1), 6 / 7 = for three-way-split launches (exact = 2); first_block = prefix sum of ceil(packed float4 / 256) over the rows before. */
 typedef struct ossid_pack_row {
     const float* w;
     float* wpk;

@@ -84,6 +84,7 @@ _PROTOS = {
     "ossid_conv_packed_floats": (_sz, [_i, _i, _i]),
     "ossid_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ossid_conv_pack_weights_form": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ossid_conv_packed_floats_form": (C.c_size_t, [_i, _i, _i, _i]),
     "ossid_conv_nhwc_fwd": (_i, [_vp, _vp]),
     "ossid_seg_tail_packed_floats": (_sz, []),
     "ossid_seg_tail_pack_weights": (_i, [_vp, _vp, _vp]),
@@ -204,7 +205,7 @@ RECORDABLE = frozenset((
     "ossid_stem_weight_relayout"))
 # entry points that only compute sizes / return static data: called through, never stored
 _QUERIES = frozenset((
-    "ossid_conv_packed_floats", "ossid_conv_wino_packed_floats", "ossid_chan_op_partials", "ossid_conv_wgrad_workspace_bytes",
+    "ossid_conv_packed_floats", "ossid_conv_packed_floats_form", "ossid_conv_wino_packed_floats", "ossid_chan_op_partials", "ossid_conv_wgrad_workspace_bytes",
     "ossid_conv_wgrad_group_workspace_bytes", "ossid_dw_bwd_k_workspace_floats",
     "ossid_conv3x3_wgrad_splits", "ossid_abi_version", "ossid_conv3x3_wino_workspace_bytes",
     "ossid_conv3x3_wino_pair_workspace_bytes"))
@@ -299,8 +300,8 @@ def _pipe_flops(name, args, flops):
     if name in ("ossid_conv3x3_wino_fwd", "ossid_conv3x3_wino_fwd_pair"):
         return flops * (SPLIT_BF16_PIPE_WEIGHT if lib().ossid_conv_wino_split_bf16() else 1.0)
     if name == "ossid_conv_nhwc_fwd":
-        split = lib().ossid_conv_split_bf16() and not (args and args[0]._obj.exact)
-        return flops * (SPLIT_BF16_PIPE_WEIGHT if split else 1.0)
+        form = (args[0]._obj.exact if args else 0) if lib().ossid_conv_split_bf16() else 1
+        return flops * (SPLIT_BF16_PIPE_WEIGHT if form == 0 else (2.0 * SPLIT_BF16_PIPE_WEIGHT if form == 2 else 1.0))
     if name == "ossid_seg_tail_fwd":
         return flops * (SPLIT_BF16_PIPE_WEIGHT if lib().ossid_seg_tail_split_bf16() else 1.0)
     if name == "ossid_conv_wgrad" and args:

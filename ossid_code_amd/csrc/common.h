@@ -99,9 +99,10 @@ __device__ __forceinline__ float4 ossid_wino_pack_quad(const float* __restrict__
 // value w[k][m][taps-1-tap] (transposed, rotated by 180 degrees). w is [Cout][Cin][taps].
 //   split-bf16 form (default):  [ceil(M/32)][K/16][taps][2 parts][64 lanes][8 bf16] -- lane (c,h) of (mt, u, tap, part) holds
 //       W[32mt+c][16u+8h+0..7][tap]: part 0 = hi = bf16(W), part 1 = lo = bf16(W - hi)
-//   exact-f32 form (exact != 0; every layer of a -DOSSID_CONV_F32 build): [ceil(M/32)][K/8][taps][64 lanes][4 floats] --
+//   exact-f32 form (exact == 1; every layer of a -DOSSID_CONV_F32 build): [ceil(M/32)][K/8][taps][64 lanes][4 floats] --
 //       lane (c,h) holds W[32mt+c][8kb+4h+0..3][tap]
-// Both have the same size (ossid_conv_packed_floats).
+//   three-way split (exact == 2): as the split form with [3 parts] -- p0 = bf16(W), p1 = bf16(W - p0), p2 = bf16(W - p0 - p1)
+// The first two have the same size (ossid_conv_packed_floats), the third 1.5 x that (ossid_conv_packed_floats_form).
 #ifdef OSSID_CONV_F32
 #define OSSID_CONV_SB 0
 #else
@@ -115,9 +116,10 @@ __device__ __forceinline__ float4 ossid_conv_pack_quad(const float* __restrict__
     auto at = [&](int m, int k, int tap) {
         return dgrad ? w[((size_t)k * Cin + m) * taps + (taps - 1 - tap)] : w[((size_t)m * Cin + k) * taps + tap];
     };
-    if (OSSID_CONV_SB && !exact) {
-        const int part = (int)(r & 1);
-        r >>= 1;
+    if (OSSID_CONV_SB && exact != 1) {
+        const int parts = exact == 2 ? 3 : 2;
+        const int part = (int)(r % parts);
+        r /= parts;
         const int tap = (int)(r % taps);
         r /= taps;
         const int KU = K / 16;
@@ -129,9 +131,13 @@ __device__ __forceinline__ float4 ossid_conv_pack_quad(const float* __restrict__
         } o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = m < M ? at(m, k0 + e, tap) : 0.0f;
-            const __bf16 hi = (__bf16)v;
-            o.hv[e] = part == 0 ? hi : (__bf16)(v - (float)hi);
+            float v = m < M ? at(m, k0 + e, tap) : 0.0f;
+            __bf16 pc = (__bf16)v;
+            for (int k = 0; k < part; ++k) {
+                v -= (float)pc;
+                pc = (__bf16)v;
+            }
+            o.hv[e] = pc;
         }
         return o.f;
     }

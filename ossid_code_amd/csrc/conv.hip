@@ -36,12 +36,27 @@ __device__ __forceinline__ v16f mfma(float a, float b, v16f c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// Split-bf16 arithmetic (kernel template argument SB; chosen per launch, see ossid_conv_desc::exact): every f32 operand is a pair
+// Split-bf16 arithmetic (kernel template argument FORM = 1; chosen per launch, see ossid_conv_desc::exact): every f32 operand is a pair
 // of bf16 values, x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 significant bits together), and a 16-channel slice
 // of the reduction is three v_mfma_f32_32x32x16_bf16 -- w_lo*x_hi + w_hi*x_lo + w_hi*x_hi, accumulated in f32 -- instead of
 // eight v_mfma_f32_32x32x2_f32: 96 pipe cycles instead of 512. The dropped w_lo*x_lo term is ~2^-16 of a product; measured
 // against float64 the results sit at ~5e-6 of the output scale (exact form: ~1e-6), tests hold 2e-5. Weights are split when
 // they are packed (common.h, ossid_conv_pack_quad), activations when they are staged into LDS.
+// FORM = 2, the three-way split: x = p0 + p1 + p2 with p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) -- 24
+// significant bits, i.e. the f32 value itself up to its last bit -- and six products per slice (all pairs (i, j) with
+// i + j <= 2; the dropped ones are <= 2^-24 of a product, the size of f32's own rounding): f32-level accuracy (measured
+// like the exact form: ~1e-6 of the output scale) at 192 pipe cycles per 16-channel slice instead of 512. For the layers
+// whose output a ReLU / max-pool decides on in training (ossid_conv_desc::exact = 2).
+__device__ __forceinline__ v16f mfma6(const float4 (&w)[3], const float4& x0, const float4& x1, const float4& x2, v16f c) {
+    const v8bf a0 = __builtin_bit_cast(v8bf, w[0]), a1 = __builtin_bit_cast(v8bf, w[1]), a2 = __builtin_bit_cast(v8bf, w[2]);
+    const v8bf b0 = __builtin_bit_cast(v8bf, x0), b1 = __builtin_bit_cast(v8bf, x1), b2 = __builtin_bit_cast(v8bf, x2);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);          // smallest terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+}
 __device__ __forceinline__ v16f mfma3(const float4& whi, const float4& wlo, const float4& xhi, const float4& xlo, v16f c) {
     const v8bf ah = __builtin_bit_cast(v8bf, whi), al = __builtin_bit_cast(v8bf, wlo);
     const v8bf bh = __builtin_bit_cast(v8bf, xhi), bl = __builtin_bit_cast(v8bf, xlo);
@@ -76,7 +91,7 @@ struct ConvArgs {
     int gx, gy, gz;   // logical grid: pixel blocks x channel-tile groups x images (the launch itself is 1-D)
     float scale_h, scale_w;
     float* e_partials;        // -DOSSID_TIMING builds: per-wave time stamps (desc->scratch)
-    int split;                // 1: split-bf16 products (wpk in that layout), 0: exact f32
+    int split;                // pieces per operand - 1: 1 = split-bf16 (three products), 2 = three-way split (six), 0 = exact f32; wpk in that layout
 };
 
 // Workgroup = 4 waves = WM (channel tiles) x WK (split of the reduction) x WN (pixel groups), each wave NT pixel tiles.
@@ -87,14 +102,15 @@ struct ConvArgs {
 // source pixels (i+a-1, i+a) x (j+b-1, j+b), so each of the four phases (a,b) is a 2x2 convolution of the SOURCE with
 // row/column-merged weights -- 4/9 of the multiply-adds of convolving the up-sampled image (network.py:354-356). Geometry
 // (H, W, pixel tiles, patch) is the source's; a block's group index carries the phase; outputs go to [2H][2W].
-template <bool SB, int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
+template <int FORM, int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
 __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
+    constexpr bool SB = FORM != 0;              // operands as bf16 pieces (FORM = number of pieces - 1), 16-channel units
     constexpr int WN = 4 / (WM * WK);
     constexpr int BPX = WN * NT * 32;
-    constexpr int F4 = KCH / 4;                 // float4 per patch position
-    constexpr int F4P = F4 + OSSID_LDS_PAD;     // ... and its stride in LDS
-    constexpr int UNIT = SB ? 16 : 8;           // reduction channels per weight unit (one float4 per lane; hi + lo: two)
-    constexpr int WPQ = SB ? 2 : 1;             // float4 per weight unit and lane
+    constexpr int F4 = KCH / 4;                 // float4 STAGED per patch position (f32 from global memory)
+    constexpr int WPQ = FORM + 1;               // pieces: float4 per weight unit and lane, 16-byte slots per (unit, lane half) in LDS
+    constexpr int F4P = (FORM == 2 ? KCH / 16 * 6 : F4) + OSSID_LDS_PAD;     // float4 per patch position in LDS
+    constexpr int UNIT = SB ? 16 : 8;           // reduction channels per weight unit
     constexpr int NKB = KCH / UNIT / WK;        // units of a chunk handled by one wave
     constexpr int KY = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1);   // prefetch groups per channel block (one kernel row each)
     constexpr int GQ = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : (NKB >= 2 ? 2 : 1));   // weight quads per prefetch group
@@ -212,7 +228,8 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         // LDS slot of the staged quad. f32: float4 j of the position. Split form: per position and 16-channel unit 64
         // bytes [hi ch 0-7][hi ch 8-15][lo ch 0-7][lo ch 8-15] (an MFMA operand = one ds_read_b128); this thread's four
         // channels are half of one of those pieces: index in 8-byte units of its hi half, the lo half sits 4 further
-        lidx[e] = pos >= npos ? -1 : (SB ? pos * F4P * 2 + (j >> 2) * 8 + ((j >> 1) & 1) * 2 + (j & 1) : pos * F4P + j);
+        // (pieces of a unit: [p0 h0][p0 h1][p1 h0][p1 h1]([p2 h0][p2 h1]), piece k of this thread's half sits 4 k further)
+        lidx[e] = pos >= npos ? -1 : (SB ? pos * F4P * 2 + (j >> 2) * (WPQ * 4) + ((j >> 1) & 1) * 2 + (j & 1) : pos * F4P + j);
     }
 
     // this lane's pixel in each of its NT tiles: patch position of tap (0,0), output pixel index (or -1)
@@ -299,14 +316,18 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
                 union {
                     __bf16 b[4];
                     uint2 u;
-                } hi, lo;
+                } pc[3];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    hi.b[i] = (__bf16)v[i];
-                    lo.b[i] = (__bf16)(v[i] - (float)hi.b[i]);
+                    float r = v[i];
+#pragma unroll
+                    for (int k = 0; k < WPQ; ++k) {
+                        pc[k].b[i] = (__bf16)r;
+                        r -= (float)pc[k].b[i];          // exact: the remainder is representable
+                    }
                 }
-                p2[lidx[e]] = hi.u;
-                p2[lidx[e] + 4] = lo.u;
+#pragma unroll
+                for (int k = 0; k < WPQ; ++k) p2[lidx[e] + 4 * k] = pc[k].u;
             }
         } else {
 #pragma unroll
@@ -338,7 +359,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     // a wait on a weight quad also waits for every staging load issued before it: PF groups of MFMAs cover both)
     // (split form: a group's MFMAs take 96 cycles per unit and pixel tile instead of 512, so the ring is deeper where a
     // group is short -- the distance has to cover an L2 round trip either way)
-    constexpr int GROUP_CYCLES = GQ * NT * (SB ? 96 : 512);
+    constexpr int GROUP_CYCLES = GQ * NT * (FORM == 2 ? 192 : (SB ? 96 : 512));
     constexpr int PF = !SB ? OSSID_WPF : (GROUP_CYCLES >= 768 ? 1 : (GROUP_CYCLES >= 384 ? 2 : 3));
     float4 wq[PF + 1][GQ][WPQ];
 #pragma unroll
@@ -375,8 +396,9 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
                 if constexpr (SB) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        const float4* px = pb + (size_t)(pos0[t] + toff) * F4P + 4 * kb;
-                        acc[t] = mfma3(wq[0][i][0], wq[0][i][WPQ - 1], px[0], px[2], acc[t]);
+                        const float4* px = pb + (size_t)(pos0[t] + toff) * F4P + 2 * WPQ * kb;
+                        if constexpr (FORM == 2) acc[t] = mfma6(wq[0][i], px[0], px[2], px[4], acc[t]);
+                        else acc[t] = mfma3(wq[0][i][0], wq[0][i][WPQ - 1], px[0], px[2], acc[t]);
                     }
                 } else {
                     const float4 a = wq[0][i][0];
@@ -482,7 +504,7 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
     wpk[i] = ossid_conv_pack_quad(w, Cout, Cin, taps, dgrad, exact, i);
 }
 
-template <bool SB, int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
+template <int FORM, int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
 int launch_conv_form(ConvArgs a, int B, hipStream_t s) {
     constexpr int WN = 4 / (WM * WK), BPX = WN * NT * 32, F4 = KCH / 4;
     // a ragged last chunk (Cin no multiple of KCH) stages zeros past Cin and clamps the weight quads: any variant, Cin % 8 == 0
@@ -508,10 +530,10 @@ int launch_conv_form(ConvArgs a, int B, hipStream_t s) {
     }
     a.buf_pos = rows * PW;
     if (a.buf_pos * F4 > NLD * 256) return OSSID_EINVAL;
-    size_t lds = (size_t)2 * a.buf_pos * (F4 + OSSID_LDS_PAD) * 16;
+    size_t lds = (size_t)2 * a.buf_pos * ((FORM == 2 ? KCH / 16 * 6 : F4) + OSSID_LDS_PAD) * 16;
     const size_t red = WK > 1 ? (size_t)WK * (WM * WN) * NT * 16 * 64 * 4 : 0;
     if (red > lds) lds = red;
-    auto kern0 = conv_nhwc_kernel<SB, WM, WK, NT, ROWSEG, NLD, TAPS, KCH>;
+    auto kern0 = conv_nhwc_kernel<FORM, WM, WK, NT, ROWSEG, NLD, TAPS, KCH>;
     OSSID_ENSURE_LDS(kern0, lds);
     a.gx = nblk, a.gy = (a.n_cotiles + WM - 1) / WM * (TAPS == 4 ? 4 : 1), a.gz = B;
     const long P = (long)a.gx * a.gz;
@@ -530,9 +552,10 @@ int launch_conv_form(ConvArgs a, int B, hipStream_t s) {
 template <int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
 int launch_conv(const ConvArgs& a, int B, hipStream_t s) {
     if constexpr (KCH % (16 * WK) == 0) {
-        if (a.split) return launch_conv_form<true, WM, WK, NT, ROWSEG, NLD, TAPS, KCH>(a, B, s);
+        if (a.split == 1) return launch_conv_form<1, WM, WK, NT, ROWSEG, NLD, TAPS, KCH>(a, B, s);
+        if (a.split == 2) return launch_conv_form<2, WM, WK, NT, ROWSEG, NLD, TAPS, KCH>(a, B, s);
     }
-    return launch_conv_form<false, WM, WK, NT, ROWSEG, NLD, TAPS, KCH>(a, B, s);
+    return launch_conv_form<0, WM, WK, NT, ROWSEG, NLD, TAPS, KCH>(a, B, s);
 }
 
 }  // namespace
@@ -545,11 +568,17 @@ size_t ossid_conv_packed_floats(int Cout, int Cin, int taps) {
     return (size_t)((Cout + 31) / 32) * (Cin / 8) * taps * 64 * 4;
 }
 
+size_t ossid_conv_packed_floats_form(int Cout, int Cin, int taps, int exact) {
+    const size_t n = ossid_conv_packed_floats(Cout, Cin, taps);
+    return (exact == 2 && OSSID_CONV_SB) ? n / 2 * 3 : n;       // three pieces per value instead of two
+}
+
 int ossid_conv_pack_weights_form(const float* w, int Cout, int Cin, int taps, int dgrad, int exact, float* wpk, void* stream) {
     if (!w || !wpk || Cout <= 0 || Cin <= 0 || (dgrad ? Cout : Cin) % 16 || (taps != 1 && taps != 9 && taps != 4)) return OSSID_EINVAL;
-    const size_t total = (dgrad ? ossid_conv_packed_floats(Cin, Cout, taps) : ossid_conv_packed_floats(Cout, Cin, taps)) / 4;
+    if (exact < 0 || exact > 2) return OSSID_EINVAL;
+    const size_t total = (dgrad ? ossid_conv_packed_floats_form(Cin, Cout, taps, exact) : ossid_conv_packed_floats_form(Cout, Cin, taps, exact)) / 4;
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       Cout, Cin, taps, dgrad ? 1 : 0, exact ? 1 : 0, (float4*)wpk, total);
+                       Cout, Cin, taps, dgrad ? 1 : 0, exact, (float4*)wpk, total);
     return ossid_launch_status();
 }
 
@@ -579,7 +608,8 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
         return OSSID_EINVAL;
     a.scale_h = (float)a.Hs / (float)H, a.scale_w = (float)a.Ws / (float)W;
     a.e_partials = (float*)d->scratch;       // (-DOSSID_TIMING builds only: per-wave time stamps)
-    a.split = (OSSID_CONV_SB && !d->exact) ? 1 : 0;
+    if (d->exact < 0 || d->exact > 2) return OSSID_EINVAL;
+    a.split = !OSSID_CONV_SB ? 0 : (d->exact == 0 ? 1 : (d->exact == 2 ? 2 : 0));
     hipStream_t s = (hipStream_t)stream;
     const int tiles = a.n_cotiles;
     const long px = (long)B * H * W;

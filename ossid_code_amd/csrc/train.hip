@@ -340,7 +340,7 @@ struct PackRow {
     const float* w;
     float4* wpk;
     long long first_block;      // prefix sum of blocks (256 float4 each)
-    int Cout, Cin, taps, kind;  // kind 0: forward layout, 1: data-gradient layout, 2 / 3: their Winograd forms, 4 / 5: 0 / 1 for exact-f32 launches
+    int Cout, Cin, taps, kind;  // kind 0: forward layout, 1: data-gradient layout, 2 / 3: their Winograd forms, 4 / 5: 0 / 1 for exact-f32 launches, 6 / 7: for three-way-split launches
 };
 
 __global__ __launch_bounds__(256) void pack_all_kernel(const PackRow* __restrict__ table, int n_rows) {
@@ -357,11 +357,11 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackRow* __restrict
         if (i < (size_t)M32 * K8 * 16 * 64) R.wpk[i] = ossid_wino_pack_quad(R.w, R.Cout, R.Cin, R.kind == 3, i);
         return;
     }
-    if (R.kind < 0 || R.kind > 5) return;
-    const int dgrad = R.kind & 1, exact = R.kind >= 4;
+    if (R.kind < 0 || R.kind > 7) return;
+    const int dgrad = R.kind & 1, exact = R.kind >= 6 ? 2 : (R.kind >= 4 ? 1 : 0);
     const int KB = (dgrad ? R.Cout : R.Cin) / 8;
     const int MT = ((dgrad ? R.Cin : R.Cout) + 31) / 32;
-    const size_t total = (size_t)MT * KB * R.taps * 64;
+    const size_t total = (size_t)MT * KB * R.taps * 64 / 2 * ((exact == 2 && OSSID_CONV_SB) ? 3 : 2);
     if (i >= total) return;
     R.wpk[i] = ossid_conv_pack_quad(R.w, R.Cout, R.Cin, R.taps, dgrad, exact, i);
 }

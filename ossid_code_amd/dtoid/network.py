@@ -911,7 +911,7 @@ class Network(nn.Module):
                 for enc in (self.template_feature_extractor_global, self.template_feature_extractor):
                     for cv in encoder_convs(enc):
                         final = any(cv is getattr(enc, n, None) for n in ("final_conv_1", "final_conv_2"))
-                        kinds[cv] = ("fwd_exact", "dgrad_exact") if final else (T.FWD_DECIDING, "dgrad")
+                        kinds[cv] = ("fwd_exact", "dgrad_exact") if final else (T.FWD_ENCODER, "dgrad")
             plan = self.__dict__["_pack_plan"] = T.PackPlan(convs, kinds)
         return plan
 

@@ -160,11 +160,12 @@ def _encoder_forward(mod, cols):
     sv = {"cols": cols, "stages": []}
     w_stem = new_buf((64, STEM_KPAD), dev)
     stem_relayout(stem.weight.detach(), w_stem, 64, 4, 3, STEM_KPAD)
-    wpk = new_buf((_lib.fn("ossid_conv_packed_floats")(64, STEM_KPAD, 1),), dev)
+    form = T._KIND_FORM[T.FWD_ENCODER]     # every convolution in front of a ReLU / max-pool runs at f32-level accuracy (T.FWD_ENCODER)
+    wpk = new_buf((_lib.fn("ossid_conv_packed_floats_form")(64, STEM_KPAD, 1, form),), dev)
     with _lib.on_device(dev):
-        _lib.check(_lib.fn("ossid_conv_pack_weights_form")(w_stem.data_ptr(), 64, STEM_KPAD, 1, 0, 1, wpk.data_ptr(), _lib.stream()),
+        _lib.check(_lib.fn("ossid_conv_pack_weights_form")(w_stem.data_ptr(), 64, STEM_KPAD, 1, 0, form, wpk.data_ptr(), _lib.stream()),
                    "ossid_conv_pack_weights_form")
-    wpk._ossid_exact = True            # every convolution in front of a ReLU / max-pool runs the exact-f32 launch (T.FWD_DECIDING)
+    wpk._ossid_exact = form
     x = new_buf((B, 64, H, W), dev, channels_last=True)
     conv_raw(cols, wpk, B, H, W, STEM_KPAD, 64, 1, x, bias=stem.bias.detach(), act=2)
     sv["x0"] = x
@@ -189,10 +190,10 @@ def _encoder_forward(mod, cols):
                 sq, e1, e3 = m.squeeze, m.expand1x1, m.expand3x3
                 nsq, n1, n3 = sq.out_channels, e1.out_channels, e3.out_channels
                 s = new_buf((B, nsq, H, W), dev, channels_last=True)
-                conv_raw(x, T._pack(sq.weight, T.FWD_DECIDING), B, H, W, C, nsq, 1, s, bias=sq.bias.detach(), act=2)
+                conv_raw(x, T._pack(sq.weight, T.FWD_ENCODER), B, H, W, C, nsq, 1, s, bias=sq.bias.detach(), act=2)
                 out = new_buf((B, n1 + n3, H, W), dev, channels_last=True)
-                conv_raw(s, T._pack(e1.weight, T.FWD_DECIDING), B, H, W, nsq, n1, 1, out, bias=e1.bias.detach(), act=2, out_cs=n1 + n3)
-                conv_raw(s, T._pack(e3.weight, T.FWD_DECIDING), B, H, W, nsq, n3, 9, out, bias=e3.bias.detach(), act=2, out_cs=n1 + n3,
+                conv_raw(s, T._pack(e1.weight, T.FWD_ENCODER), B, H, W, nsq, n1, 1, out, bias=e1.bias.detach(), act=2, out_cs=n1 + n3)
+                conv_raw(s, T._pack(e3.weight, T.FWD_ENCODER), B, H, W, nsq, n3, 9, out, bias=e3.bias.detach(), act=2, out_cs=n1 + n3,
                          out_coff=n1)
                 sv["stages"].append(("fire", m, x, s, out, (H, W)))
                 x = out
@@ -351,7 +352,7 @@ class TemplateEncoderTrain(torch.autograd.Function):
         if T.SEQ_REPLAY and not torch.cuda.is_current_stream_capturing():
             plan = T._plan_for(mod, (tuple(img.shape), str(dev), params[0].data_ptr(), params[-1].data_ptr(),
                                      mod.norm_1.running_mean.data_ptr(),
-                                     T._Packed.get(params[2].detach(), T.FWD_DECIDING).data_ptr()))
+                                     T._Packed.get(params[2].detach(), T.FWD_ENCODER).data_ptr()))
         if plan is None:
             out, sv = _encoder_forward(mod, ops.im2col_stem(img, 3, 2, 0, STEM_KPAD))
         else:

@@ -159,12 +159,13 @@ class _Packed:
             if kind in ("wino_fwd", "wino_dgrad"):
                 n = _lib.fn("ossid_conv_wino_packed_floats")(*((cout, cin) if kind == "wino_fwd" else (cin, cout)))
             else:
-                n = _lib.fn("ossid_conv_packed_floats")(cout, cin, taps) if kind in ("fwd", "fwd_exact") else \
-                    _lib.fn("ossid_conv_packed_floats")(cin, cout, taps)
+                form = _KIND_FORM[kind]
+                n = _lib.fn("ossid_conv_packed_floats_form")(cout, cin, taps, form) if kind.startswith("fwd") else \
+                    _lib.fn("ossid_conv_packed_floats_form")(cin, cout, taps, form)
             if len(cls._cache) > 4096:
                 cls.clear()
             ent = cls._cache[key] = torch.empty(n, dtype=torch.float32, device=w.device)
-            ent._ossid_exact = kind.endswith("_exact")      # conv_raw sets ossid_conv_desc.exact from the buffer it is handed
+            ent._ossid_exact = _KIND_FORM.get(kind, 0)      # conv_raw sets ossid_conv_desc.exact from the buffer it is handed
         return ent
 
     @classmethod
@@ -182,12 +183,25 @@ _ACTIVE_PLAN = None  # weakref to the PackPlan that packed last. Its `fresh` dic
 #                      recycled for other tensors; when its network dies the weakref dies with it and nothing is "fresh".
 
 
-FWD_DECIDING = "fwd_exact"      # the forward layout of layers whose output a ReLU / max-pool decides on: the exact-f32 launch
-#                                  (include/ossid_hip.h, ossid_conv_desc::exact). Data gradients and the ELU head run split-bf16.
+# ossid_conv_desc::exact of each direct-kernel layout (include/ossid_hip.h): 0 split-bf16, 1 exact-f32 instruction, 2 three-way split
+_KIND_FORM = {"fwd": 0, "dgrad": 0, "fwd_exact": 1, "dgrad_exact": 1, "fwd_x6": 2}
+# The forward layout of layers whose output a ReLU / max-pool decides on: f32-level accuracy is needed (a pre-activation on the
+# other side of zero changes the gradient's path) -- the three-way split delivers it at 2x the split form's
+# matrix-pipe time instead of 5x. OSSID_TRAIN_FWD=fwd_exact puts these layers on the exact-f32 instruction. Data gradients and
+# the ELU head run split-bf16.
+FWD_DECIDING = os.environ.get("OSSID_TRAIN_FWD", "fwd_x6")
+assert FWD_DECIDING in ("fwd_x6", "fwd_exact")
+# The two SqueezeNet template encoders keep the exact-f32 instruction: their convolutions are small (0.3 ms of the step), and
+# with ~2 M ReLU / max-pool decisions per pass ANY f32-level path lands one of them differently from torch's in some passes
+# (2e-3 .. 1e-2 on the gradients in front of it instead of 2e-5; tools/debug_encoder_tol.py: one pass in six with the exact
+# instruction, three in six with the three-way split) -- the tests' bound is calibrated on the exact one.
+FWD_ENCODER = os.environ.get("OSSID_TRAIN_FWD_ENCODER", "fwd_exact")
+assert FWD_ENCODER in ("fwd_x6", "fwd_exact")
 
 
 def _pack(w, kind):
-    """kind: "fwd" / "dgrad" (split-bf16 launches), "fwd_exact" / "dgrad_exact" (exact-f32 launches), "wino_fwd" / "wino_dgrad"."""
+    """kind: "fwd" / "dgrad" (split-bf16 launches), "fwd_exact" / "dgrad_exact" (exact-f32 launches), "fwd_x6" (three-way
+    split), "wino_fwd" / "wino_dgrad"."""
     w = w.detach()
     assert w.is_contiguous() and w.dtype == torch.float32
     cout, cin, taps = int(w.shape[0]), int(w.shape[1]), int(w.shape[2] * w.shape[3])
@@ -203,7 +217,7 @@ def _pack(w, kind):
         else:
             name = "ossid_conv_pack_weights_form"
             _lib.check(_lib.fn(name)(w.data_ptr(), cout, cin, taps, 1 if kind.startswith("dgrad") else 0,
-                                     1 if kind.endswith("_exact") else 0, buf.data_ptr(), _lib.stream()), name)
+                                     _KIND_FORM[kind], buf.data_ptr(), _lib.stream()), name)
     return buf
 
 
@@ -223,7 +237,7 @@ class PackPlan:
             for kind in (("fwd", "dgrad") if kinds is None else kinds.get(conv, ("fwd", "dgrad"))):
                 if kind in ("dgrad", "dgrad_exact") and cout % 16:
                     continue
-                if kind in ("fwd", "fwd_exact") and (cin % 16 or cout % 4):
+                if kind.startswith("fwd") and (cin % 16 or cout % 4):
                     continue
                 if kind == "wino_fwd" and not (USE_WINO and taps == 9 and cin % 16 == 0 and cout >= 64):
                     continue
@@ -231,7 +245,7 @@ class PackPlan:
                     continue
                 buf = _Packed.get(w, kind)
                 rows.append((w.data_ptr(), buf.data_ptr(), first, cout, cin, taps,
-                             {"fwd": 0, "dgrad": 1, "wino_fwd": 2, "wino_dgrad": 3, "fwd_exact": 4, "dgrad_exact": 5}[kind]))
+                             {"fwd": 0, "dgrad": 1, "wino_fwd": 2, "wino_dgrad": 3, "fwd_exact": 4, "dgrad_exact": 5, "fwd_x6": 6}[kind]))
                 keys.append((w.data_ptr(), tuple(w.shape), kind))
                 self.bufs.append(buf)
                 self.buf_ptr[keys[-1]] = buf.data_ptr()
@@ -281,7 +295,7 @@ def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_rel
     d.in_batch_stride, d.pre_batch_stride = -1, 0
     d.batch, d.height, d.width, d.cin, d.cout, d.taps = B, H, W, cin, cout, taps
     d.act, d.pre_relu = int(act), 1 if pre_relu else 0
-    d.exact = 1 if getattr(wpk, "_ossid_exact", False) else 0        # the arithmetic the weights were packed for (_pack kinds)
+    d.exact = int(getattr(wpk, "_ossid_exact", 0))                   # the arithmetic the weights were packed for (_pack kinds)
     d.src_height, d.src_width = int(src_hw[0]), int(src_hw[1])
     d.in_channel_stride, d.out_channel_stride, d.out_channel_offset = int(in_cs), int(out_cs), int(out_coff)
     if epi is not None and epi.get("timing_buf") is not None:
