@@ -667,10 +667,12 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
                                   : (long)B * ((W + 31) / 32) * (tiles >= 4 ? (H + 1) / 2 * ((tiles + 3) / 4)
                                                                             : tiles >= 2 ? (H + 3) / 4 : (H + 7) / 8);
     // under one workgroup per CU either way: row segments of 32 pixels, one channel tile, the reduction split over the
-    // four waves in 128-channel chunks
+    // four waves in 64-channel chunks
     // (only for Cin >= 128: with fewer input channels three of the four waves would multiply the zero padding of the
-    // 128-channel chunk -- the data gradient of a dense layer's 128->32 conv is such a 32->128 layer)
-    if ((plain_wgs < 160 || wide_wgs < 256) && Cin >= 128) return launch_conv<1, 4, 1, true, 13, 9, 128>(a, B, s);
+    // chunk -- the data gradient of a dense layer's 128->32 conv is such a 32->128 layer)
+    // (64-channel chunks: with 128 the first chunk's loads -- the launch's start-up latency -- are twice as long and the
+    // three-way split's patch would take 156 KB of LDS; measured on 128 -> 32 at 30 x 40 x 8: 23 -> 18 us, 17 in the three-way form)
+    if ((plain_wgs < 160 || wide_wgs < 256) && Cin >= 128) return launch_conv<1, 4, 1, true, 7, 9, 64>(a, B, s);
     // medium problems on narrow images (the 29x39 head at n_t ~ 10 or batch 8: ~1 plain workgroup per CU, i.e. one or
     // two waves per SIMD and a ragged tail): one channel tile x 32 flat pixels per workgroup, reduction split over the
     // four waves in 32-channel chunks -> 8x as many, 4x shorter work items

@@ -17,6 +17,7 @@ rocprofv3 --kernel-trace -d $O/fw --output-format csv -- python3 tools/bench_dto
 python tools/trace_step.py $O/fw/*/*kernel_trace.csv --marker nms_scan --top 40 > $O/forward_step_kernels.txt
 python tools/train_layers_bench.py --json $O/train_layers.json > $O/train_layers.txt 2>&1
 python tools/train_layers_bench.py --what fwd,dgrad --wino > $O/train_layers_wino.txt 2>&1
+for k in fwd_x6 fwd_exact; do python tools/train_layers_bench.py --what fwd --fwd-kind $k --only "^b[1-4]|^t[1-3]" > $O/train_layers_$k.txt 2>&1; done
 python tools/train_layers_bench.py --what fwd --wino --batch 21 --only . > $O/forward_layers_wino_nt21.txt 2>&1
 rm -rf $O/stats $O/ft $O/fw
 ls -la $O
