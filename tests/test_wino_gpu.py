@@ -41,6 +41,65 @@ def test_wino_forward_matches_conv2d(T, B, cin, cout, H, W):
     assert rel(out, direct) < 2e-5 and rel(direct, ref) < 2e-5
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W", [(21, 256, 256, 29, 39),    # 197 tile groups x 2 channel groups = 400 workgroups on
+                                                                        # 256 slots: the tail (144) is cut along the reduction
+                                            (21, 64, 512, 29, 39),     # four channel groups, reduction too short to cut
+                                            (16, 48, 160, 32, 32)])    # five channel tiles: the second group is one tile wide
+def test_wino_128_channel_workgroups_match_conv2d(T, B, cin, cout, H, W):
+    """Layers with >= 128 output channels and >= 128 tile groups run four channel tiles per (512-thread) workgroup -- the
+    test-time head at 21 templates; incl. the tail split with its finishing launch, and against the 64-channel form
+    (OSSID_WINO_CT is read once per process, so that comparison is against the direct kernel and float64 only)."""
+    g = torch.Generator().manual_seed(B + cin + cout)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ps, pt = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    ref = F.conv2d(F.relu(x.double() * ps.double()[None, :, None, None] + pt.double()[None, :, None, None]), w.double(),
+                   bias.double(), padding=1)
+    ref = F.elu(ref)
+    xd, wd = nhwc(x.cuda()), w.cuda()
+    out = T.empty_nhwc(B, cout, H, W, "cuda")
+    T.conv_raw(xd, T._pack(wd, "wino_fwd"), B, H, W, cin, cout, 9, out, bias=bias.cuda(), pre=(ps.cuda(), pt.cuda()),
+               pre_relu=True, act=1, wino=True)
+    assert rel(out, ref) < 2e-5
+    again = T.empty_nhwc(B, cout, H, W, "cuda")
+    T.conv_raw(xd, T._pack(wd, "wino_fwd"), B, H, W, cin, cout, 9, again, bias=bias.cuda(), pre=(ps.cuda(), pt.cuda()),
+               pre_relu=True, act=1, wino=True)
+    assert torch.equal(out, again)                                  # fixed-order sums in the finishing launch
+
+
+def test_wino_pair_launch_at_128_channel_workgroups(T):
+    """The pair entry with four channel tiles per workgroup (the classification / regression trunks at 21 templates) against
+    two single launches. Not bit-equal here: the combined grid's tail -- the workgroups whose reduction is cut into slices and
+    summed by the finishing launch -- is a different set of workgroups than each single launch's, so some outputs are summed
+    in a different (still fixed) order: equal to f32 reordering, 2e-6, and both within the kernel's bound of float64."""
+    import ctypes
+    from ossid_code_amd import _lib
+    from ossid_code_amd.dtoid import ops
+    g = torch.Generator().manual_seed(33)
+    B, cin, cout, H, W = 21, 128, 256, 29, 39
+    descs, outs, keep = [], [], []
+    for _ in range(2):
+        x = nhwc(torch.randn(B, cin, H, W, generator=g).cuda())
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()
+        bias = torch.randn(cout, generator=g).cuda()
+        single = T.empty_nhwc(B, cout, H, W, "cuda")
+        T.conv_raw(x, T._pack(w, "wino_fwd"), B, H, W, cin, cout, 9, single, bias=bias, act=1, wino=True)
+        out = T.empty_nhwc(B, cout, H, W, "cuda")
+        d = _lib.ConvDesc()
+        d.x, d.wpk, d.bias, d.out = x.data_ptr(), T._pack(w, "wino_fwd").data_ptr(), bias.data_ptr(), out.data_ptr()
+        d.in_batch_stride, d.batch, d.height, d.width, d.cin, d.cout, d.taps, d.act = -1, B, H, W, cin, cout, 9, 1
+        descs.append(d)
+        ref = F.elu(F.conv2d(x.double(), w.double(), bias.double(), padding=1))
+        outs.append((single, out, ref))
+        keep += [x, w, bias]
+    ops.wino_workspace(descs, "cuda:0")
+    assert _lib.fn("ossid_conv3x3_wino_fwd_pair")(ctypes.byref(descs[0]), ctypes.byref(descs[1]), _lib.stream()) == 0
+    torch.cuda.synchronize()
+    for single, out, ref in outs:
+        assert rel(out, single) < 2e-6 and rel(out, ref) < 2e-5 and rel(single, ref) < 2e-5
+
+
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_wino_prologue_epilogue_strides(T, act):
     """Input affine + ReLU on real pixels only, bias -> activation -> output affine, channel strides and an output
