@@ -41,7 +41,8 @@ __device__ __forceinline__ v16f mfma(float a, float b, v16f c) {
 // of the reduction is three v_mfma_f32_32x32x16_bf16 -- w_lo*x_hi + w_hi*x_lo + w_hi*x_hi, accumulated in f32 -- instead of
 // eight v_mfma_f32_32x32x2_f32: 96 pipe cycles instead of 512. The dropped w_lo*x_lo term is ~2^-16 of a product; measured
 // against float64 the results sit at ~5e-6 of the output scale (exact form: ~1e-6), tests hold 2e-5. Weights are split when
-// they are packed (common.h, ossid_conv_pack_quad), activations when they are staged into LDS.
+// they are packed (common.h, ossid_conv_pack_quad), activations when they are staged into LDS ([position][hi of the chunk's
+// channels | lo ...] bf16: an MFMA operand is one ds_read_b128 of 8 channels).
 // FORM = 2, the three-way split: x = p0 + p1 + p2 with p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) -- 24
 // significant bits, i.e. the f32 value itself up to its last bit -- and six products per slice (all pairs (i, j) with
 // i + j <= 2; the dropped ones are <= 2^-24 of a product, the size of f32's own rounding): f32-level accuracy (measured
@@ -68,13 +69,14 @@ __device__ __forceinline__ v16f mfma3(const float4& whi, const float4& wlo, cons
 #ifndef OSSID_WPF
 #define OSSID_WPF 1
 #endif
-// Optional float4 of padding per patch position (a wave's ds_read_b128 takes the same channel quad of 32 consecutive
-// positions: a lane stride of KCH*4 bytes). A/B on the GPU (round 2): 0 and 1 time the same within noise on every layer
-// of tools/train_layers_bench.py and on both DTOID legs -- the loop is not LDS-bound -- so the default stays 0.
+// One float4 of padding per patch position: a wave's ds_read_b128 takes the same 16 bytes of 32 consecutive positions, a
+// lane stride of KCH*4 bytes -- 64 / 128 / 256 / 512 bytes, i.e. every lane of a 16-lane group on the same banks. On the f32
+// instruction this cost nothing measurable (round 2: the MFMAs hid it); on the split forms SQ_LDS_BANK_CONFLICT was 72-91 %
+// of all LDS cycles (tools/pmc_lds_conflicts.py, profiles/r03_lds_conflicts.txt) and the padding is worth 20-40 % of a layer.
 // Likewise OSSID_WPF (weight prefetch distance in groups): 1, 2 and 3 time the same; the main loop's MFMA pipe is
 // 74-89 % busy at the clock the part actually holds under this load (1.95-2.03 GHz, tools/conv_timeline.py).
 #ifndef OSSID_LDS_PAD
-#define OSSID_LDS_PAD 0
+#define OSSID_LDS_PAD 1
 #endif
 #ifndef OSSID_MEDIUM_WGS
 #define OSSID_MEDIUM_WGS 600
@@ -228,8 +230,9 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         // LDS slot of the staged quad. f32: float4 j of the position. Split form: per position and 16-channel unit 64
         // bytes [hi ch 0-7][hi ch 8-15][lo ch 0-7][lo ch 8-15] (an MFMA operand = one ds_read_b128); this thread's four
         // channels are half of one of those pieces: index in 8-byte units of its hi half, the lo half sits 4 further
-        // (pieces of a unit: [p0 h0][p0 h1][p1 h0][p1 h1]([p2 h0][p2 h1]), piece k of this thread's half sits 4 k further)
-        lidx[e] = pos >= npos ? -1 : (SB ? pos * F4P * 2 + (j >> 2) * (WPQ * 4) + ((j >> 1) & 1) * 2 + (j & 1) : pos * F4P + j);
+        // (pieces of a position: [p0 of all its channels][p1 ...]([p2 ...]), KCH * 2 bytes each -- the threads of a position
+        // write 8 consecutive bytes each, piece k sits F4 eight-byte units further)
+        lidx[e] = pos >= npos ? -1 : (SB ? pos * F4P * 2 + j : pos * F4P + j);
     }
 
     // this lane's pixel in each of its NT tiles: patch position of tap (0,0), output pixel index (or -1)
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < WPQ; ++k) p2[lidx[e] + 4 * k] = pc[k].u;
+                for (int k = 0; k < WPQ; ++k) p2[lidx[e] + F4 * k] = pc[k].u;
             }
         } else {
 #pragma unroll
@@ -396,9 +399,9 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
                 if constexpr (SB) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        const float4* px = pb + (size_t)(pos0[t] + toff) * F4P + 2 * WPQ * kb;
-                        if constexpr (FORM == 2) acc[t] = mfma6(wq[0][i], px[0], px[2], px[4], acc[t]);
-                        else acc[t] = mfma3(wq[0][i][0], wq[0][i][WPQ - 1], px[0], px[2], acc[t]);
+                        const float4* px = pb + (size_t)(pos0[t] + toff) * F4P + 2 * kb;      // (+ h in pb: 16 bytes = 8 channels)
+                        if constexpr (FORM == 2) acc[t] = mfma6(wq[0][i], px[0], px[F4 / 2], px[F4], acc[t]);
+                        else acc[t] = mfma3(wq[0][i][0], wq[0][i][WPQ - 1], px[0], px[F4 / 2], acc[t]);
                     }
                 } else {
                     const float4 a = wq[0][i][0];
