@@ -234,7 +234,12 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
         // split-bf16: V = vh + vl with vh = bf16(V), vl = bf16(V - vh). LDS unit (xi, tile) = 4 x 16 bytes: slot part * 2 + khalf
         // holds channels 8 khalf .. 8 khalf + 7 of part (hi / lo) as bf16 -- one ds_read_b128 per MFMA operand. This thread
         // owns channels 4j .. 4j + 3: 8 bytes at (j & 1) * 8 of slots (0, j >> 1) and (1, j >> 1).
-        char* ob = (char*)(vb + (size_t)buf * VBUF + (size_t)tl * F4) + (j >> 1) * 16 + (j & 1) * 8;
+        // Slots are XOR-swizzled with (tile >> 2) & 3: an operand read takes one 16-byte slot of 32 consecutive tiles, 64 bytes
+        // apart -- tiles t and t + 4 on the same 16 banks; unswizzled, SQ_LDS_BANK_CONFLICT was 70 % of this kernel's LDS cycles.
+        const int sw = (tl >> 2) & 3;
+        char* ub = (char*)(vb + (size_t)buf * VBUF + (size_t)tl * F4) + (j & 1) * 8;
+        char* ob = ub + (((j >> 1) ^ sw) * 16);                  // hi piece; the lo piece: slot (2 + (j >> 1)) ^ sw
+        const int lo_delta = ((((j >> 1) + 2) ^ sw) - ((j >> 1) ^ sw)) * 16;
         // (written out on 32-bit words: two v_cvt_pk_bf16_f32 give hi, a shift / a mask turn each packed half back into the
         // f32 it stands for, two packed subtractions and two more packed conversions give lo -- 10 vector instructions per
         // position; the vector-typed form of the same arithmetic compiled to 7 % more instructions in this phase)
@@ -250,7 +255,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
             const float l2 = v[2] - __builtin_bit_cast(float, p23 << 16), l3 = v[3] - __builtin_bit_cast(float, p23 & 0xffff0000u);
             char* p = ob + (size_t)xi * 32 * F4 * 16;
             *(uint2*)p = make_uint2(p01, p23);
-            *(uint2*)(p + 32) = make_uint2(pk(l0, l1), pk(l2, l3));
+            *(uint2*)(p + lo_delta) = make_uint2(pk(l0, l1), pk(l2, l3));
         };
         auto cols = [&](int i, const v4f (&R)[4]) {
             put(i * 4 + 0, sub(R[0], R[2]));
@@ -324,14 +329,15 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
 #pragma unroll 1
     for (int ch = ch0; ch < ch1; ++ch) {
         if (stager && ch + 1 < ch1) stage_load((ch + 1) * KCH);   // in flight under this chunk's MFMAs
-        const float4* pb = vb + (size_t)(ch & 1) * VBUF + (size_t)(8 * wx * 32 + c) * F4 + h;
-        float4 bh = pb[0], bl = pb[2];
+        const int sh = h ^ ((c >> 2) & 3), sl = sh ^ 2;          // swizzled slots of this lane's hi / lo operand (transform_write)
+        const float4* pb = vb + (size_t)(ch & 1) * VBUF + (size_t)(8 * wx * 32 + c) * F4;
+        float4 bh = pb[sh], bl = pb[sl];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const v8bf ahi = __builtin_bit_cast(v8bf, wq[e & 1][0]), alo = __builtin_bit_cast(v8bf, wq[e & 1][1]);
             const v8bf vh = __builtin_bit_cast(v8bf, bh), vl = __builtin_bit_cast(v8bf, bl);
             const int en = e < 7 ? e + 1 : e;               // next position's operands are read under this one's MFMAs
-            bh = pb[(size_t)en * 32 * F4], bl = pb[(size_t)en * 32 * F4 + 2];
+            bh = pb[(size_t)en * 32 * F4 + sh], bl = pb[(size_t)en * 32 * F4 + sl];
             acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, vh, acc[e], 0, 0, 0);
             acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, vl, acc[e], 0, 0, 0);
             acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, vh, acc[e], 0, 0, 0);
