@@ -627,11 +627,9 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
         // four channel tiles x 32 pixels with 64-channel chunks (a ragged last one for DenseNet's widths): with 16-channel
         // chunks a 1x1 layer has only 8 MFMAs per wave between barriers. Measured on the batch-8 DenseNet layers
         // (64..1024 -> 128..640 at 9 k..154 k pixels): forward 45 -> 56, data gradient 55 -> 59 TFLOP/s over the set
-        static const int exp1 = getenv("OSSID_CONV1_EXP") ? atoi(getenv("OSSID_CONV1_EXP")) : 0;   // A/B experiments only
-        if (tiles >= 4 && px >= 4096 && exp1 == 2) return launch_conv<2, 2, 1, false, 4, 1, 128>(a, B, s);
-        if (tiles >= 4 && px >= 4096 && exp1 == 3) return launch_conv<1, 4, 1, false, 8, 1, 256>(a, B, s);
-        if (tiles >= 4 && px >= 4096 && exp1 == 4) return launch_conv<4, 1, 2, false, 4, 1, 64>(a, B, s);
-        if (tiles >= 4 && px >= 4096 && exp1 != 1) return launch_conv<4, 1, 1, false, 2, 1, 64>(a, B, s);
+        // (measured against: two channel tiles x split-K, one tile x split-K in 256-channel chunks, two pixel tiles per wave,
+        // 128- / 256-channel chunks -- DESIGN.md 5c / 5e; none of them is compiled in any more)
+        if (tiles >= 4 && px >= 4096) return launch_conv<4, 1, 1, false, 2, 1, 64>(a, B, s);
         if (plain_wgs < 160) return launch_conv<1, 4, 1, false, 8, 1, 256>(a, B, s);
         if (tiles >= 4)
             return px >= 128L * 512 ? launch_conv<4, 1, 4, false, 2, 1, 16>(a, B, s)
@@ -680,14 +678,10 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
     // two waves per SIMD and a ragged tail): one channel tile x 32 flat pixels per workgroup, reduction split over the
     // four waves in 32-channel chunks -> 8x as many, 4x shorter work items
     const int rows32 = (32 + W - 2) / W + 3;                          // patch rows of a 32-pixel flat run
-    static const int exp_variant = getenv("OSSID_CONV_EXP") ? atoi(getenv("OSSID_CONV_EXP")) : 0;   // A/B experiments only
     if (plain_wgs < OSSID_MEDIUM_WGS && (Cin % 32) == 0 && (rows32 < H + 2 ? rows32 : H + 2) * (W + 2) * 8 <= 6 * 256) {
-        if (exp_variant == 1 && tiles >= 4) return launch_conv<4, 1, 1, 0, 8, 9, 16>(a, B, s);
-        if (exp_variant == 2 && tiles >= 4) return launch_conv<4, 1, 2, 0, 8, 9, 16>(a, B, s);
-        if (exp_variant == 4 && tiles >= 2) return launch_conv<2, 1, 1, 0, 8, 9, 16>(a, B, s);
         // two channel tiles x 32 pixels, the reduction split over two waves: measured 5-8 % faster than one tile split
         // over four on the batch-8 head layers (256..640 -> 256/512 at 29x39), fewer partial tiles through LDS
-        if (exp_variant != 5 && tiles >= 2) return launch_conv<2, 2, 1, false, 6, 9, 32>(a, B, s);
+        if (tiles >= 2) return launch_conv<2, 2, 1, false, 6, 9, 32>(a, B, s);
         if (a.split) return launch_conv<1, 4, 1, false, 12, 9, 64>(a, B, s);   // a wave's share of a chunk must be a whole 16-channel unit
         return launch_conv<1, 4, 1, false, 6, 9, 32>(a, B, s);
     }
