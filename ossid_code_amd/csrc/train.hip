@@ -115,38 +115,6 @@ __global__ __launch_bounds__(256) void chan_op_kernel(const ChanOpArgs A) {
     }
 }
 
-// sums[s][c] = sum over the P row-chunk partials, in a fixed order, accumulated in double. A block owns 64 columns; its
-// four waves each take a quarter of the partials (independent, unrolled loads), the quarters meet in LDS.
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int P, int C,
-                                                              float* __restrict__ sums, int row_stride,
-                                                              const float* __restrict__ pivot) {
-    __shared__ double red[4][64];
-    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + col;
-    const int C2 = 2 * C;
-    double s = 0.0;
-    if (i < C2) {
-        const int per = (P + 3) / 4, p0 = part * per, p1 = min(P, p0 + per);
-        const float* src = partials + i;
-        int p = p0;
-        for (; p + 8 <= p1; p += 8) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(p + k) * C2];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s += (double)v[k];
-        }
-        for (; p < p1; ++p) s += (double)src[(size_t)p * C2];
-    }
-    red[part][col] = s;
-    __syncthreads();
-    if (part == 0 && i < C2) {
-        const double t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-        sums[i < C ? i : row_stride + (i - C)] = (float)t;
-        if (pivot && i < C) sums[2 * row_stride + i] = pivot[i];      // third row: the pivot the sums are about
-    }
-}
-
 // =====================================================================================================================
 // training-mode BatchNorm as a folded affine. The two column sums of a channel come either finished (sums[c],
 // sums[row_stride + c]) or as the P per-block partials an ossid_chan_op launch with defer_finalize left behind
@@ -254,16 +222,32 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const float* __restric
     }
 }
 
-// stand-alone finalize of partial rows into a (possibly strided) sums table, many rows: 16 channels x 16 partial sums
-__global__ __launch_bounds__(256) void colsum_finalize16_kernel(const float* __restrict__ partials, int P, int C,
-                                                                float* __restrict__ sums, int row_stride) {
-    __shared__ double red[16][16][2];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+// stand-alone finalize of partial rows into a (possibly strided) sums table: 256 / PARTS channels per block, PARTS threads per
+// channel. These launches sit on the step's critical chain ~300 times: their time is the number of dependent rounds of loads
+// a thread makes (P / PARTS / 8), so PARTS follows P -- 512 partial rows: 64 threads per channel, one round of 8 loads each.
+template <int PARTS>
+__global__ __launch_bounds__(256) void colsum_finalize_p_kernel(const float* __restrict__ partials, int P, int C,
+                                                                float* __restrict__ sums, int row_stride,
+                                                                const float* __restrict__ pivot) {
+    constexpr int CPB = 256 / PARTS;
+    __shared__ double red[PARTS][CPB][2];
+    const int c = blockIdx.x * CPB + (threadIdx.x % CPB), part = threadIdx.x / CPB;
     double s0, s1;
-    column_sums<16>(nullptr, 0, partials, P, C, c, part, red, s0, s1);
+    column_sums<PARTS>(nullptr, 0, partials, P, C, c, part, red, s0, s1);
     if (part != 0 || c >= C) return;
     sums[c] = (float)s0;
     sums[row_stride + c] = (float)s1;
+    if (pivot) sums[2 * row_stride + c] = pivot[c];          // third row: the pivot the sums are about
+}
+static int launch_colsum_finalize(const float* partials, int P, int C, float* sums, int row_stride, const float* pivot,
+                                  hipStream_t s) {
+    if (P > 128)
+        hipLaunchKernelGGL(colsum_finalize_p_kernel<64>, dim3((C + 3) / 4), dim3(256), 0, s, partials, P, C, sums, row_stride, pivot);
+    else if (P > 16)
+        hipLaunchKernelGGL(colsum_finalize_p_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, s, partials, P, C, sums, row_stride, pivot);
+    else
+        hipLaunchKernelGGL(colsum_finalize_p_kernel<4>, dim3((C + 63) / 64), dim3(256), 0, s, partials, P, C, sums, row_stride, pivot);
+    return ossid_launch_status();
 }
 
 // =====================================================================================================================
@@ -1358,11 +1342,8 @@ int ossid_chan_op(const ossid_chan_op_desc* d, void* stream) {
     else if (C4 <= 32) rc = launch_chan_op<32>(a, P, s);
     else rc = launch_chan_op<64>(a, P, s);
     if (rc != OSSID_OK || d->sum_mode == 0 || d->defer_finalize) return rc;
-    const int C2 = 2 * d->channels;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C2 + 63) / 64), dim3(256), 0, s, (const float*)d->partials, P,
-                       d->channels, d->sums, d->sums_row_stride > 0 ? d->sums_row_stride : d->channels,
-                       d->sum_mode == 3 ? d->pivot : nullptr);
-    return ossid_launch_status();
+    return launch_colsum_finalize((const float*)d->partials, P, d->channels, d->sums,
+                                  d->sums_row_stride > 0 ? d->sums_row_stride : d->channels, d->sum_mode == 3 ? d->pivot : nullptr, s);
 }
 
 int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, const float* partials, int n_partials, const float* pivot, int C,
@@ -1371,7 +1352,11 @@ int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, const float* parti
     if ((!sums && n_partials <= 0) || (n_partials > 0 && !partials) || C <= 0 || n <= 0 || !scale || !shift || !mean_out ||
         !rstd_out || (!running_mean != !running_var))
         return OSSID_EINVAL;
-    if (n_partials > 64)
+    if (n_partials > 128)
+        hipLaunchKernelGGL(bn_fold_fwd_kernel<64>, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, sums,
+                           sums_row_stride > 0 ? sums_row_stride : C, partials, n_partials, pivot, C, n, gamma, beta, eps,
+                           momentum, running_mean, running_var, scale, shift, mean_out, rstd_out);
+    else if (n_partials > 16)
         hipLaunchKernelGGL(bn_fold_fwd_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, sums,
                            sums_row_stride > 0 ? sums_row_stride : C, partials, n_partials, pivot, C, n, gamma, beta, eps,
                            momentum, running_mean, running_var, scale, shift, mean_out, rstd_out);
@@ -1388,7 +1373,10 @@ int ossid_bn_fold_bwd(const float* dscale, const float* dshift, const float* par
     if (((!dscale || !dshift) && n_partials <= 0) || (n_partials > 0 && !partials) || !mean || !rstd || C <= 0 || n <= 0 ||
         !coef_x || !coef_1)
         return OSSID_EINVAL;
-    if (n_partials > 64)
+    if (n_partials > 128)
+        hipLaunchKernelGGL(bn_fold_bwd_kernel<64>, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, dscale, dshift,
+                           partials, n_partials, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate);
+    else if (n_partials > 16)
         hipLaunchKernelGGL(bn_fold_bwd_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, dscale, dshift,
                            partials, n_partials, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate);
     else
@@ -1400,9 +1388,8 @@ int ossid_bn_fold_bwd(const float* dscale, const float* dshift, const float* par
 
 int ossid_colsum_finalize(const float* partials, int n_partials, int C, float* sums, int sums_row_stride, void* stream) {
     if (!partials || n_partials <= 0 || C <= 0 || !sums) return OSSID_EINVAL;
-    hipLaunchKernelGGL(colsum_finalize16_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, n_partials,
-                       C, sums, sums_row_stride > 0 ? sums_row_stride : C);
-    return ossid_launch_status();
+    return launch_colsum_finalize(partials, n_partials, C, sums, sums_row_stride > 0 ? sums_row_stride : C, nullptr,
+                                  (hipStream_t)stream);
 }
 
 int ossid_conv_pack_weights_table(const ossid_pack_row* rows_device, int n_rows, long long total_blocks, void* stream) {
