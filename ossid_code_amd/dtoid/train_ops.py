@@ -422,6 +422,20 @@ def upsample_bwd(dup, B, Hs, Ws, H, W, C):
 
 
 # ---- autograd Functions -----------------------------------------------------------------------------------------------
+_ZEROS = {}
+
+
+def _zeros(C, device):
+    """A read-only all-zero [C] vector per (size, device): a per-channel coefficient that is zero (saves a fill launch per use)."""
+    key = (int(C), str(device))
+    z = _ZEROS.get(key)
+    if z is None:
+        z = torch.zeros(int(C), dtype=torch.float32, device=device)
+        if not torch.cuda.is_current_stream_capturing():       # (memory allocated under a capture belongs to that graph's pool)
+            _ZEROS[key] = z
+    return z
+
+
 class ColStats(torch.autograd.Function):
     """x [B,C,H,W] channels-last -> stats [3,C] = (sum (x - p), sum (x - p)^2, p) over B*H*W with p = x's first row (the
     pivot: a channel whose spread is small against its mean loses nothing to E[x^2] - E[x]^2). The gradient arriving on
@@ -441,8 +455,7 @@ class ColStats(torch.autograd.Function):
         B, C, H, W = x.shape
         g = g.contiguous()
         dx = torch.empty_like(x)
-        zero = torch.zeros(C, dtype=torch.float32, device=x.device)
-        chan_op(x, B * H * W, C, x=x, out=dx, alpha=zero, beta=g[1], kappa=g[0])
+        chan_op(x, B * H * W, C, x=x, out=dx, alpha=_zeros(C, x.device), beta=g[1], kappa=g[0])
         return dx
 
 
