@@ -216,6 +216,7 @@ class Seq:
 
     def __init__(self):
         self.ops, self.keep, self.uses_side = [], [], False
+        self.scratch = {}          # (purpose, device, stream slot) -> the sequence's OWN scratch buffer (record.scratch)
 
     def __len__(self):
         return len(self.ops)
@@ -271,6 +272,18 @@ class record:
 
     def keep(self, *tensors):
         self.seq.keep.extend(t for t in tensors if t is not None)
+
+    def scratch(self, name, nbytes, device):
+        """Scratch memory owned by the sequence being recorded, per purpose and stream slot (launches of one slot are
+        ordered among themselves at every replay, whatever streams the replay runs on). A request larger than the buffer
+        gets a new one; launches recorded earlier keep the old one alive through `keep`."""
+        key = (name, str(device), self.cur_slot)
+        t = self.seq.scratch.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+            self.seq.scratch[key] = t
+            self.seq.keep.append(t)
+        return t
 
 
 def recording():

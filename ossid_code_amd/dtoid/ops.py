@@ -251,13 +251,14 @@ def wino_workspace(descs, device):
         n = _lib.fn("ossid_conv3x3_wino_pair_workspace_bytes")(C_byref(descs[0]), C_byref(descs[1]))
     if not n:
         return
-    key = (str(device), _lib.stream())
-    buf = _WINO_WS.get(key)
-    if buf is None or buf.numel() < n:
-        buf = _WINO_WS[key] = torch.empty(max(int(n), 16 << 20), dtype=torch.uint8, device=device)
     rec = _lib.recording()
-    if rec is not None:
-        rec.keep(buf)
+    if rec is not None:                        # a recorded sequence owns its scratch (train_ops._scratch has the reason)
+        buf = rec.scratch("wino", n, device)
+    else:
+        key = (str(device), _lib.stream())
+        buf = _WINO_WS.get(key)
+        if buf is None or buf.numel() < n:
+            buf = _WINO_WS[key] = torch.empty(max(int(n), 16 << 20), dtype=torch.uint8, device=device)
     descs[0].scratch, descs[0].scratch_bytes = buf.data_ptr(), buf.numel()
 
 
@@ -345,12 +346,17 @@ class PackedConv:
         d.src_height, d.src_width = int(src_hw[0]), int(src_hw[1])
         d.in_channel_stride, d.out_channel_stride, d.out_channel_offset = in_cs, out_cs, out_coff
         name = "ossid_conv_nhwc_fwd"
-        if self.wpk_wino is not None and d.src_height in (0, H) and d.src_width in (0, W):
-            # workgroups of the Winograd launch (32 tiles of 2x2 outputs x 64 channels each): under one per CU the direct
-            # kernel's split-reduction variants are the better fit
-            if ((B * ((H + 1) // 2) * ((W + 1) // 2) + 31) // 32) * ((self.cout + 63) // 64) >= WINO_MIN_WGS:
-                name, d.wpk = "ossid_conv3x3_wino_fwd", self.wpk_wino.data_ptr()
+        if d.src_height in (0, H) and d.src_width in (0, W) and self.use_wino(B, H, W):
+            name, d.wpk = "ossid_conv3x3_wino_fwd", self.wpk_wino.data_ptr()
         return d, name
+
+    def use_wino(self, B, H, W):
+        """Does a launch on [B][H][W] (no fused up-sampling) take the Winograd kernel? The layer must have the layout, and
+        the launch enough workgroups (32 tiles of 2x2 outputs x 64 channels each): under one per CU the direct kernel's
+        split-reduction variants are the better fit."""
+        if self.wpk_wino is None:
+            return False
+        return ((B * ((H + 1) // 2) * ((W + 1) // 2) + 31) // 32) * ((self.cout + 63) // 64) >= WINO_MIN_WGS
 
     def run(self, x_nhwc, B, H, W, out_nhwc, in_cs=0, out_cs=0, out_coff=0, src_hw=(0, 0), in_bs=-1, pre=None):
         """Raw call on physical [B][H][W][C] buffers (tensors only provide pointers). in_bs = 0: x is ONE image shared by

@@ -377,7 +377,7 @@ class TemplateEncoderTrain(torch.autograd.Function):
         dev = gout.device
         weights = [p for p in params if p.dim() == 4]
         side = T._wgrad_side_ok(dev, weights)
-        direct = all(w.grad is None for w in weights)
+        direct = all(T._grad_taken_unread(w) for w in weights)
         if plan is not None and ctx.gen != plan.gen:
             raise RuntimeError("TemplateEncoderTrain: this encoder ran another training forward since the one being "
                                "differentiated; its persistent buffers hold the later pass")

@@ -47,19 +47,24 @@ def flat(t, offset=0):
     return v[offset:]
 
 
-# ---- per-(device, stream) scratch: column-sum partials, split-K slabs -------------------------------------------------
+# ---- scratch: column-sum partials, split-K slabs ------------------------------------------------------------------------
+# Eager launches share one grow-only buffer per (purpose, device, stream): launches on one stream are ordered, so the next
+# user finds the previous one done. A RECORDED launch sequence owns its scratch instead (_lib.Seq.scratch, per stream slot):
+# the addresses are baked into the recorded arguments, and a replay runs on whatever stream is current THEN -- two sequences
+# recorded on one stream (a capture's warm-up, a step with the branches off) and replayed side by side on the branch streams
+# would otherwise write the same partials buffer.
 _SCRATCH = {}
 
 
 def _scratch(name, nbytes, device):
+    rec = _lib.recording()
+    if rec is not None:
+        return rec.scratch(name, nbytes, device)
     key = (name, str(device), _lib.stream())
     t = _SCRATCH.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _SCRATCH[key] = t
-    rec = _lib.recording()
-    if rec is not None:
-        rec.keep(t)          # the recorded launches hold its address: it must outlive a later, larger request
     return t
 
 
@@ -527,7 +532,15 @@ def _wgrad_side_ok(device, weights=()):
     under a graph capture (a captured graph does not run a side branch to any profit: measured 48.4 vs 47.3 ms)."""
     if not WGRAD_SIDE or device.type != "cuda" or torch.cuda.is_current_stream_capturing():
         return False
-    return not any(w is not None and w.grad is not None for w in weights)
+    return all(w is None or _grad_taken_unread(w) for w in weights)
+
+
+def _grad_taken_unread(w):
+    """Will autograd hand the gradient returned for `w` to AccumulateGrad, which takes it over without reading it? Only for
+    a LEAF that holds no gradient yet. A non-leaf `w` (a relaid / padded / concatenated view of a parameter) always has
+    .grad None, but the tensor returned for it is READ by the next backward nodes (reshape / pad / permute backward) on the
+    caller's stream straight away: its gradient must be complete on that stream when backward() returns."""
+    return w.is_leaf and w.grad is None
 
 
 def _wgrad_async(tensors, fn, device, weights=(), side=None):
@@ -662,7 +675,7 @@ class FusedConv(torch.autograd.Function):
         # 2. weight gradient on the (prologue'd, up-sampled) input
         dw = None
         if need[1]:
-            dwb = grad_home(w, w.grad is None)            # straight into the flat gradient buffer when autograd will take it over
+            dwb = grad_home(w, _grad_taken_unread(w))     # straight into the flat gradient buffer when autograd will take it over
             _wgrad_async([x, dv, ps, pt, dwb], lambda: wgrad_raw(x, dv, B, H, W, Cin, Cout, taps, dwb, pre=pre, pre_relu=pre_relu,
                                                                  src_hw=(Hs, Ws) if (H, W) != (Hs, Ws) else (0, 0)), dev,
                          weights=(w,))
@@ -925,7 +938,7 @@ class DenseBlockTrain(torch.autograd.Function):
         dev = buf.device
         weights = [params[6 * li + k] for li in range(block.nlayers) for k in (2, 5)]
         side = _wgrad_side_ok(dev, weights)
-        direct = all(w.grad is None for w in weights)              # (the plan's `side` slot holds the pair)
+        direct = all(_grad_taken_unread(w) for w in weights)      # (the plan's `side` slot holds the pair)
         if plan is not None and ctx.gen != plan.gen:
             raise RuntimeError("DenseBlockTrain: this block ran another training forward since the one being differentiated; "
                                "its persistent buffers hold the later pass (run backward before the next forward, or set "
@@ -1075,7 +1088,7 @@ class Conv3x3C1(torch.autograd.Function):
         dx = dw = db = None
         with _lib.on_device(dev):
             if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-                dwb = grad_home(w, w.grad is None)
+                dwb = grad_home(w, _grad_taken_unread(w))
                 dbb = torch.empty(1, dtype=torch.float32, device=dev)
                 nbytes = _lib.fn("ossid_conv3x3_c1_wgrad_workspace_bytes")()
 

@@ -121,3 +121,90 @@ def test_whole_test_time_call_on_fixture_weights_finds_the_reference_detections(
     assert stable.sum() >= TOPK // 2
     assert np.array_equal(obj[stable], F["post_obj"][stable])
     assert np.allclose(boxes[stable], F["post_boxes"][stable], rtol=1e-4, atol=0.05)
+
+
+# ---- BASELINE configs[2]'s template count: 21 templates in ONE chunk (tests/golden/dtoid_head_full_nt21.npz) ---------------
+F21 = np.load(os.path.join(ROOT, "tests", "golden", "dtoid_head_full_nt21.npz"))
+X2S21, SEGS21, SPS21, ROWS21 = (int(v) for v in F21["strides"])
+CHUNKS21 = tuple(int(c) for c in F21["chunks"])
+
+
+def inputs21(device="cpu"):
+    g = torch.Generator().manual_seed(int(F21["input_seed"]))
+    feat = torch.randn(1, 640, *GRID, generator=g)
+    tmpl = [torch.randn(n, 640, 7, 7, generator=g) for n in CHUNKS21]
+    return feat.to(device), [t.to(device) for t in tmpl]
+
+
+def check_dense21(x2, heat, seg, cls, reg, tol):
+    n = sum(CHUNKS21)
+    assert tuple(x2.shape) == (n, 512, 29, 39) and tuple(seg.shape) == (n, 1, 480, 640)
+    assert tuple(cls.shape) == (n, 27144, 2) and tuple(reg.shape) == (n, 27144, 4)
+    for name, got, want in (("x2", x2[:, ::X2S21], F21["x2"]), ("heat", heat, F21["heat"]),
+                            ("seg", seg[:, :, ::SEGS21, ::SEGS21], F21["seg"]), ("cls", cls[:, ::ROWS21], F21["cls"]),
+                            ("reg", reg[:, ::ROWS21], F21["reg"])):
+        assert rel(got, want) < tol, (name, rel(got, want))
+
+
+def check_detections21(out, score_rtol):
+    """The reference's detection list, wherever its scores are separated by more than the f32 reordering noise."""
+    score, boxes, obj = out[0].cpu().numpy(), out[1].cpu().numpy(), out[2].cpu().numpy()
+    assert score.shape[0] == F21["post_score"].shape[0] == TOPK
+    assert np.allclose(score, F21["post_score"], rtol=score_rtol, atol=1e-6)
+    gaps = np.abs(np.diff(F21["post_score"])) > 1e-4
+    stable = np.concatenate([[True], gaps]) & np.concatenate([gaps, [True]])
+    assert stable.sum() >= TOPK // 2
+    assert np.array_equal(obj[stable], F21["post_obj"][stable])
+    assert np.allclose(boxes[stable], F21["post_boxes"][stable], rtol=1e-4, atol=0.05)
+    # the segmentation / heat map rows gathered for those detections
+    seg, heat = out[3][:, ::SPS21, ::SPS21].cpu().numpy(), out[4].cpu().numpy()
+    for i in np.nonzero(stable)[0]:
+        assert rel(seg[i], F21["post_seg"][i]) < 2e-4 and rel(heat[i], F21["post_heat"][i]) < 2e-4, i
+
+
+def test_module_path_matches_nt21_reference_fixture():
+    net = build_net()
+    feat, tmpl = inputs21()
+    with dtoid_oracle.cpu_ops(), torch.no_grad():
+        parts = [net.correlation_model(feat.expand(t.shape[0], -1, -1, -1), t, True) for t in tmpl]
+        x2, heat, seg = (torch.cat([p[i] for p in parts]) for i in range(3))
+        cls, reg = net.classification(x2)[0], net.regression(x2)
+        check_dense21(x2, heat, seg, cls, reg, 2e-5)
+        check_detections21(net.postprocess(cls, reg, seg, heat, GRID, IMG, topk=TOPK), 1e-5)
+
+
+@pytest.mark.gpu
+def test_fused_head_product_dispatch_matches_nt21_reference_fixture(hiplib):
+    """FusedHead exactly as forward_all_templates drives it at 21 templates, with NO threshold overridden: the product's own
+    choices -- Winograd with 128 output channels per workgroup (>= 128 tile groups), its tail split, the direct `dot`
+    convolution (21 < DOT_GEMM_MIN_TEMPLATES), merged first trunk layer and paired trunk launches -- against the reference."""
+    from ossid_code_amd.dtoid import ops
+    net = build_net("cuda")
+    feat, tmpl = inputs21("cuda")
+    fused = net._fused_head()
+    n_t = sum(CHUNKS21)
+    # what this test is about: the dispatcher's own decisions at this size (they are not forced here)
+    assert fused.cf.use_wino(n_t, GRID[0], GRID[1]) and n_t < fused.DOT_GEMM_MIN_TEMPLATES
+    frame = {}
+    with torch.no_grad():
+        parts = []
+        for t in tmpl:
+            x2, heat, seg = fused.correlation(feat, t, None, frame)
+            parts.append((x2, heat, seg) + fused.detection(x2))
+        x2, heat, seg, cls, reg = (torch.cat([p[i] for p in parts]) for i in range(5))
+        check_dense21(x2, heat, seg, cls, reg, 1e-4)
+        check_detections21(net.postprocess(cls, reg, seg, heat, GRID, IMG, topk=TOPK), 2e-4)
+
+
+@pytest.mark.gpu
+def test_whole_test_time_call_at_21_templates_finds_the_reference_detections(hiplib):
+    """forward_all_templates (graph capture + replay) on the fixture's weights and 21 templates, backbone swapped for the
+    fixture's feature map."""
+    net = build_net("cuda")
+    feat, tmpl = inputs21("cuda")
+    net.use_fused_backbone = False
+    net.image_feature_extractor.forward = lambda image, g: feat
+    with torch.no_grad():
+        out = net.forward_all_templates(torch.zeros(1, 3, *IMG, device="cuda"), tmpl,
+                                        [torch.zeros(1, 64, 3, 3, device="cuda")], topk=TOPK)
+    check_detections21(out, 2e-4)

@@ -678,7 +678,7 @@ def test_hip_training_head_matches_reference_golden(hiplib, wino, monkeypatch):
     feat, tmpl, ann, heat_t, mask_t = (t.cuda() for t in seeded_inputs(SEED + 10))
     feat.requires_grad_(True)
     tmpl.requires_grad_(True)
-    c, r, anc, heat, seg = net._head_train_hip(feat, tmpl)
+    c, r, anc, heat, seg = net._head_train_hip(feat.view_as(feat), tmpl.view_as(tmpl))      # (non-leaf, as in the product)
     boxes = dtoid.BBoxTransform()(anc, r)
     lc, lr = dtoid.DetectionLoss()(c, r, anc, ann)
     l_center = torch.nn.L1Loss()(heat_t, heat)
@@ -882,7 +882,12 @@ def test_template_encoder_training_node_matches_module_path(hiplib, which, repla
     every parameter gradient, every BatchNorm running statistic, three rounds with fresh templates. With `replay` round 0
     records the launch sequences and rounds 1 and 2 replay them from the persistent buffers (a launch missing from the
     recording, or a torch kernel inside it, would leave round 1 with round 0's values). One ReLU decision of tens of
-    thousands can flip between two float32 paths, so gradients are compared in the relative L2 norm."""
+    thousands can flip between two float32 paths, so gradients are compared in the relative L2 norm.
+    Anchor: a float64 run of the same module on the CPU. This repo's path must be at least as close to it as the
+    nn.Module path on MIOpen is, within a factor of 3 (output and every parameter gradient); a flipped ReLU / max-pool
+    decision moves BOTH float32 paths percents away from float64 on the layers in front of it -- a kernel fault is
+    systematic, a flipped kink is not -- so at most one of the three rounds may miss the float64 bound, and it still has
+    to hold the module-path bound."""
     import copy
     from ossid_code_amd.dtoid import train_encoders as TE
     from ossid_code_amd.dtoid import train_ops
@@ -901,39 +906,51 @@ def test_template_encoder_training_node_matches_module_path(hiplib, which, repla
                 torch.nn.init.kaiming_normal_(m.weight, nonlinearity="relu")
                 m.bias.normal_(0, 0.1)
     ref = copy.deepcopy(mod)
+    ref64 = copy.deepcopy(mod).double().cpu()
     B = 3
 
     def l2(a, b):
-        a, b = a.detach().double(), b.detach().double()
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
         return float((a - b).norm() / b.norm().clamp(min=1e-30))
+    missed64 = []
     for rnd in range(3):
         img = torch.rand(B, 4, 124, 124, device="cuda") * (0.5 + 0.5 * rnd)
-        for m in (mod, ref):
+        for m in (mod, ref, ref64):
             for p in m.parameters():
                 p.grad = None
         y_ref = ref(img)
         go = torch.randn_like(y_ref)
         y_ref.backward(go)
+        y64 = ref64(img.double().cpu())
+        y64.backward(go.double().cpu())
         y = TE.template_encoder_train(mod, img)
         y.backward(go)
         torch.cuda.synchronize()
         assert y.shape == y_ref.shape == ((B, 640, 7, 7) if which == "local" else (B, 64, 3, 3))
         assert l2(y, y_ref) < 2e-4, rnd
+        assert l2(y, y64) < max(2e-5, 3 * l2(y_ref, y64)), (rnd, l2(y, y64), l2(y_ref, y64))
         used = {id(p) for p in TE.encoder_params(mod)}
-        for (n, p), q in zip(mod.named_parameters(), ref.parameters()):
+        bad64 = []
+        for (n, p), q, q64 in zip(mod.named_parameters(), ref.parameters(), ref64.parameters()):
             if id(p) not in used:
                 assert p.grad is None and q.grad is None, n      # the SqueezeNet classifier / 3-channel stem never run
                 continue
             assert p.grad is not None and p.grad.shape == p.shape, n
+            mine, theirs = l2(p.grad, q64.grad), l2(q.grad, q64.grad)
+            if not mine < max(1e-4, 3 * theirs):
+                bad64.append((n, "%.2e" % mine, "%.2e" % theirs))
             # (rounds 0 and 1 sit at 2e-5; in round 2 one max-pool / ReLU decision of the global encoder falls differently in
             # torch's path and puts 2.0e-3 on the layers in front of it -- in the exact-f32 build (1.99e-3) as in the default
             # one (2.01e-3), tools/debug_encoder_tol.py)
             assert l2(p.grad, q.grad) < 3e-3, (rnd, n, l2(p.grad, q.grad))
-        for (n, b), q in zip(mod.named_buffers(), ref.buffers()):
+        if bad64:
+            missed64.append((rnd, bad64))
+        for (n, b), q, q64 in zip(mod.named_buffers(), ref.buffers(), ref64.buffers()):
             if b.dtype.is_floating_point:
-                assert l2(b, q) < 1e-4, (rnd, n)
+                assert l2(b, q) < 1e-4 and l2(b, q64) < 1e-4, (rnd, n)
             else:
                 assert int(b) == int(q), (rnd, n)
+    assert len(missed64) <= 1, missed64
 
 
 @pytest.mark.gpu

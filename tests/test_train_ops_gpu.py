@@ -418,3 +418,31 @@ def test_one_output_channel_conv3x3_matches_torch(hiplib, B, C, H, W):
     assert rel(dw, ref.weight.grad) < 1e-5 and rel(db, ref.bias.grad) < 1e-5
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_weight_gradient_of_a_non_leaf_weight_is_complete_when_backward_returns_it(hiplib):
+    """FusedConv handed a NON-LEAF weight (a re-laid / scaled view of a parameter: `.grad` is always None there,
+    which the side-stream guard used to read as "AccumulateGrad will take it unread"). The next autograd node (here the
+    multiplication's backward) reads dw on the caller's stream straight away, so the launch must stay in line. With the
+    weight-gradient stream kept busy by a long kernel, a side-stream launch would hand over an unwritten buffer."""
+    torch.manual_seed(5)
+    dev = torch.device("cuda")
+    x = cl(torch.randn(2, 32, 20, 24))
+    w = torch.nn.Parameter(torch.randn(64, 32, 3, 3, device=dev) * 0.1)
+    go = cl(torch.randn(2, 64, 20, 24))
+    scale = torch.full((64, 1, 1, 1), 1.5, device=dev)
+    assert T.WGRAD_SIDE
+    side = T.side_streams(dev)["wgrad"]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(int(4e8))                      # ~0.2 s: anything queued behind it is late
+    wn = w * scale                                      # non-leaf
+    assert not wn.is_leaf and not T._grad_taken_unread(wn) and T._grad_taken_unread(w)
+    y = T.FusedConv.apply(x, wn, None, None, None, False, 0, None, False)
+    y.backward(go)
+    got = w.grad.clone()                                # read on the main stream, as an optimizer would
+    torch.cuda.synchronize()
+    w64 = w.detach().double().cpu().requires_grad_(True)
+    y64 = F.conv2d(x.double().cpu(), w64 * scale.double().cpu(), padding=1)
+    y64.backward(go.double().cpu())
+    assert rel(got, w64.grad) < 5e-5

@@ -12,6 +12,11 @@ oracle/dtoid_oracle.py (torchvision's published algorithm) is installed on the p
 
 Only data is stored (inputs re-derived from seeds at test time; dense outputs stored whole where small, strided where
 large). Run from the repo root:   python tools/gen_golden_dtoid_full.py
+
+`--nt21` writes tests/golden/dtoid_head_full_nt21.npz instead: BASELINE configs[2]'s 21 templates in ONE chunk (the chunk
+size of DtoidNet.forwardTestTime is 120, models/dtoid/__init__.py:92), the template count at which the product's own
+dispatch picks the 128-channel Winograd workgroups, the tail split and the direct `dot` convolution -- with dense scores /
+deltas stored row-strided (the whole tensors would be 14 MB) and the reference's detection list beside them.
 """
 import os
 import sys
@@ -33,14 +38,18 @@ TOPK = 20
 X2_CH_STRIDE, SEG_STRIDE, SEGPRED_STRIDE = 8, 4, 8
 
 
-def seeded_inputs(seed=SEED + 10):
+# the 21-template variant: (chunks, x2 channel stride, seg pixel stride, post_seg pixel stride, cls / reg row stride)
+NT21 = dict(chunks=(21,), x2s=64, segs=8, sps=8, rows=13, seed=SEED + 100, name="dtoid_head_full_nt21.npz")
+
+
+def seeded_inputs(seed=SEED + 10, chunks=CHUNKS):
     g = torch.Generator().manual_seed(seed)
     feat = torch.randn(1, 640, *GRID, generator=g)
-    tmpl = [torch.randn(n, 640, 7, 7, generator=g) for n in CHUNKS]
+    tmpl = [torch.randn(n, 640, 7, 7, generator=g) for n in chunks]
     return feat, tmpl
 
 
-def main():
+def main(variant=None):
     network, loss_mod, anchors_mod, utils = ref_import.load()
     from oracle import dtoid_oracle
     sys.modules["torchvision.ops.boxes"].nms = lambda b, s, t: dtoid_oracle.nms(b, s, t)
@@ -52,7 +61,7 @@ def main():
     for i, m in enumerate((corr, cls, reg)):
         m.load_state_dict(seeded_state(m, SEED + i))
         m.eval()
-    feat, tmpl = seeded_inputs()
+    feat, tmpl = seeded_inputs() if variant is None else seeded_inputs(variant["seed"], variant["chunks"])
     base = anchors_mod.generate_anchors(base_size=30, ratios=np.array([0.5, 1, 2]), scales=np.array([1, 2, 3, 4, 5, 6, 7, 8]))
 
     class Holder:       # the attributes Network.forward_all_templates reads from `self`
@@ -74,17 +83,21 @@ def main():
             x2.append(a), heat.append(b), seg.append(s)
             c.append(cls(a)[0]), r.append(reg(a))
         x2, heat, seg, c, r = (torch.cat(v, 0) for v in (x2, heat, seg, c, r))
+    x2s, segs, sps, rows, chunks, name = (X2_CH_STRIDE, SEG_STRIDE, SEGPRED_STRIDE, 1, CHUNKS, "dtoid_head_full.npz") \
+        if variant is None else tuple(variant[k] for k in ("x2s", "segs", "sps", "rows", "chunks", "name"))
     out = dict(
-        x2=x2[:, ::X2_CH_STRIDE].numpy(), heat=heat.numpy(), seg=seg[:, :, ::SEG_STRIDE, ::SEG_STRIDE].numpy(),
-        cls=c.numpy(), reg=r.numpy(),
+        x2=x2[:, ::x2s].numpy(), heat=heat.numpy(), seg=seg[:, :, ::segs, ::segs].numpy(),
+        cls=c[:, ::rows].numpy(), reg=r[:, ::rows].numpy(),
         post_score=score.numpy(), post_boxes=boxes.numpy(), post_obj=obj.numpy(),
-        post_seg=seg_pred[:, ::SEGPRED_STRIDE, ::SEGPRED_STRIDE].numpy(), post_heat=heat_pred.numpy(),
-        seed=SEED, topk=TOPK, chunks=np.asarray(CHUNKS))
-    path = os.path.join(ROOT, "tests", "golden", "dtoid_head_full.npz")
+        post_seg=seg_pred[:, ::sps, ::sps].numpy(), post_heat=heat_pred.numpy(),
+        seed=SEED, topk=TOPK, chunks=np.asarray(chunks))
+    if variant is not None:
+        out.update(input_seed=variant["seed"], strides=np.asarray([x2s, segs, sps, rows]))
+    path = os.path.join(ROOT, "tests", "golden", name)
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
     print(path, os.path.getsize(path), "bytes; kept", len(score), "boxes; top score", float(score[0]),
           "templates fired", sorted(set(obj.reshape(-1).tolist())))
 
 
 if __name__ == "__main__":
-    main()
+    main(NT21 if "--nt21" in sys.argv else None)
