@@ -32,7 +32,7 @@ extern "C" {
 
 /* The version of the struct layouts and signatures below; bumped whenever one changes (3: ossid_conv_desc gained
  * scratch / scratch_bytes / exact). A binding compares it with ossid_abi_version() when it loads the library. */
-#define OSSID_ABI_VERSION 3
+#define OSSID_ABI_VERSION 4
 
 /* library / device probe: returns OSSID_ABI_VERSION of the build; arch_out_host (may be NULL, >=32 bytes)
  * receives the gcnArchName of the current device, e.g. "gfx950:sramecc+:xnack-". */
@@ -439,6 +439,21 @@ int ossid_focal_smoothl1_loss_bwd(const float* dcls_raw, const float* dreg_raw, 
  * [Cout][Kpad] in the same column order. */
 int ossid_im2col_stem(const float* img_nchw, int B, int Cin, int H, int W, int k, int stride, int pad, int Kpad,
                       const float* mean, const float* inv_std, float* out, void* stream);
+/* D4  DenseNet-121 conv0 = nn.Conv2d(3, 64, 7, stride 2, padding 3) of ImageFeatExtract (network.py:164-170, :175-177) as an
+ * IMPLICIT-im2col convolution on the f32 matrix cores (csrc/stem.hip; exact f32: an fmaf chain), and its weight gradient
+ * (the image is an input: there is no data gradient). img NCHW [B][3][H][W] as the caller holds it; mean / inv_std [3]
+ * (device, NULL = none) = normalizeImageRange (utils/__init__.py:33-39) applied to real pixels while staging, zero padding
+ * in normalised space as the reference has it; weight / dweight [64][3][7][7] = the parameter's own layout (no packing);
+ * out / dy [B][Ho][Wo][64] channels-last, Ho = (H - 1) / 2 + 1; bias [64] or NULL. Only this geometry is accepted
+ * (Cin 3, Cout 64, k 7, stride 2, pad 3): anything else returns OSSID_EINVAL. The weight gradient sums per-workgroup
+ * partial slabs in a fixed order (bit-reproducible); workspace >= ossid_stem_conv_wgrad_workspace_bytes(B, H, W), 16-byte
+ * aligned; accumulate != 0 adds to dweight. */
+int ossid_stem_conv_fwd(const float* img_nchw, int B, int Cin, int H, int W, const float* weight, int Cout, int k, int stride,
+                        int pad, const float* bias, const float* mean, const float* inv_std, float* out, void* stream);
+size_t ossid_stem_conv_wgrad_workspace_bytes(int B, int H, int W);
+int ossid_stem_conv_wgrad(const float* img_nchw, const float* dy, int B, int Cin, int H, int W, int Cout, int k, int stride,
+                          int pad, const float* mean, const float* inv_std, void* workspace, size_t workspace_bytes,
+                          float* dweight, int accumulate, void* stream);
 /* D4  relu(scale[c] * (x0 + conv2d_dw_group(x0, kernels)) + shift[c]) (network.py:178-181: the global-template modulation
  * of the stem output, norm0 in eval mode, relu0), channels-last; kernels [B or 1][C][3][3], kernels_batch_stride = C*9 or
  * 0 (one kernel set for the whole batch). */
@@ -468,7 +483,26 @@ int ossid_resample_taps_nhwc(const float* x, int B, int Hin, int Win, int C, int
  *   each input pixel -- no atomics. */
 int ossid_dw_add_nhwc(const float* x, const float* kernels, int kernels_batch_stride, int B, int H, int W, int C, int flip,
                       float* out, void* stream);
-size_t ossid_dw_bwd_k_workspace_floats(int B, int H, int C);
+/* ossid_dw_add_nhwc that also leaves the column sums of its OUTPUT y about pivot[c] = y[0][0][0][c] -- (sum (y - pivot),
+ * sum (y - pivot)^2), the batch statistics of the BatchNorm that follows (norm0) -- as ossid_dw_add_stats_partials(B, H, W, C)
+ * partial rows [P][2][C] for ossid_bn_fold_fwd (n_partials = P, pivot = pivot_out [C]): the statistics cost no pass of
+ * their own. C / 4 must be a power of two <= 64 (these four entry points). partials / pivot_out both NULL: no statistics. */
+int ossid_dw_add_stats_partials(int B, int H, int W, int C);
+int ossid_dw_add_stats_nhwc(const float* x, const float* kernels, int kernels_batch_stride, int B, int H, int W, int C, int flip,
+                            float* out, float* partials, float* pivot_out, void* stream);
+/* D4  norm0 + relu0 + pool0 of the training stem without ever writing the normalised tensor (network.py:180-181 with
+ * torchvision's MaxPool2d(3, 2, 1)):  out [B][Ho][Wo][C] = maxpool(relu(scale[c] * m + shift[c])), argmax = the window
+ * position (ky * 3 + kx, uint8) of the first maximum, Ho = (H - 1) / 2 + 1.
+ * Backward in two passes over m, the un-pooled gradient gm = [scale m + shift > 0] * (sum of dpooled whose maximum sat at
+ * this pixel) formed on the fly both times: dm == NULL: (sum gm, sum gm * m) -> ossid_stem_pool_bwd_partials(B, H, W, C)
+ * partial rows for ossid_bn_fold_bwd; partials == NULL: dm = scale gm + coef_x m + coef_1 (coefficients from that fold). */
+int ossid_stem_pool_fwd(const float* m, const float* scale, const float* shift, int B, int H, int W, int C, float* out,
+                        uint8_t* argmax, void* stream);
+int ossid_stem_pool_bwd_partials(int B, int H, int W, int C);
+int ossid_stem_pool_bwd(const float* m, const uint8_t* argmax, const float* dpooled, const float* scale, const float* shift,
+                        const float* coef_x, const float* coef_1, int B, int H, int W, int C, float* partials, float* dm,
+                        void* stream);
+size_t ossid_dw_bwd_k_workspace_floats(int B, int H, int W, int C);
 int ossid_dw_bwd_k_nhwc(const float* x, const float* g, int B, int H, int W, int C, float* workspace, float* dk, void* stream);
 int ossid_maxpool_idx_nhwc(const float* x, int B, int H, int W, int C, int k, int stride, int pad, int ceil_mode, float* out,
                            uint8_t* argmax, void* stream);

@@ -123,10 +123,18 @@ _PROTOS = {
     "ossid_focal_smoothl1_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_focal_smoothl1_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ossid_im2col_stem": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ossid_stem_conv_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ossid_stem_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ossid_stem_conv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _i, _vp]),
     "ossid_stem_tail_nhwc": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ossid_maxpool_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ossid_dw_add_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "ossid_dw_bwd_k_workspace_floats": (_sz, [_i, _i, _i]),
+    "ossid_dw_add_stats_partials": (_i, [_i, _i, _i, _i]),
+    "ossid_dw_add_stats_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ossid_stem_pool_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ossid_stem_pool_bwd_partials": (_i, [_i, _i, _i, _i]),
+    "ossid_stem_pool_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ossid_dw_bwd_k_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "ossid_dw_bwd_k_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ossid_resample_taps_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "ossid_maxpool_idx_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -144,7 +152,7 @@ _PROTOS = {
 }
 
 
-ABI_VERSION = 3      # OSSID_ABI_VERSION of include/ossid_hip.h: the struct layouts below (tests/test_abi.py compares the two)
+ABI_VERSION = 4      # OSSID_ABI_VERSION of include/ossid_hip.h: the struct layouts below (tests/test_abi.py compares the two)
 
 
 def exported_symbols():
@@ -202,13 +210,15 @@ RECORDABLE = frozenset((
     "ossid_upsample_nearest_bwd_nhwc", "ossid_maxpool_idx_nhwc", "ossid_maxpool_bwd_nhwc", "ossid_dw_add_nhwc",
     "ossid_dw_bwd_k_nhwc", "ossid_im2col_stem", "ossid_conv_pack_weights", "ossid_conv_pack_weights_dgrad", "ossid_conv_pack_weights_form",
     "ossid_conv_pack_weights_wino", "ossid_fill_zero", "ossid_resample_taps_nhwc",
-    "ossid_stem_weight_relayout"))
+    "ossid_stem_weight_relayout", "ossid_stem_conv_fwd", "ossid_stem_conv_wgrad",
+    "ossid_dw_add_stats_nhwc", "ossid_stem_pool_fwd", "ossid_stem_pool_bwd"))
 # entry points that only compute sizes / return static data: called through, never stored
 _QUERIES = frozenset((
     "ossid_conv_packed_floats", "ossid_conv_packed_floats_form", "ossid_conv_wino_packed_floats", "ossid_chan_op_partials", "ossid_conv_wgrad_workspace_bytes",
     "ossid_conv_wgrad_group_workspace_bytes", "ossid_dw_bwd_k_workspace_floats",
     "ossid_conv3x3_wgrad_splits", "ossid_abi_version", "ossid_conv3x3_wino_workspace_bytes",
-    "ossid_conv3x3_wino_pair_workspace_bytes"))
+    "ossid_conv3x3_wino_pair_workspace_bytes", "ossid_stem_conv_wgrad_workspace_bytes",
+    "ossid_dw_add_stats_partials", "ossid_stem_pool_bwd_partials"))
 
 
 class Seq:

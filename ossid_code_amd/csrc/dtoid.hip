@@ -886,89 +886,10 @@ int ossid_maxpool_nhwc(const float* x, int B, int H, int W, int C, int k, int st
 
 // =====================================================================================================================
 // Training-side companions of the stem kernels above (the finetune step, channels-last):
-//   dw_add_nhwc        y = x + conv2d_dw_group(x, k) with optional 180-degree-rotated taps (= the data gradient:
-//                      dx = g + conv2d_dw_group(g, rot180 k)), no affine, no ReLU
-//   dw_bwd_k_nhwc      dk[b][c][tap] = sum_px g[b][px][c] * x[b][px + tap][c]  (per-chunk partials + fixed-order finalize)
+//   (x + conv2d_dw_group(x, k), its two gradients and the fused norm0 / pool0 passes live in csrc/stem.hip)
 //   maxpool with argmax index (uint8, position inside the window) and its backward as a gather over the <= ceil(k/s)^2
 //   windows that contain an input pixel (no atomics)
 namespace {
-
-__global__ __launch_bounds__(256) void dw_add_nhwc_kernel(const float4* __restrict__ x, const float* __restrict__ kern, int kern_bs,
-                                                          int H, int W, int C4, int flip, size_t total, float4* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int c4 = (int)(i % C4);
-    size_t r = i / C4;
-    const int xx = (int)(r % W);
-    r /= W;
-    const int yy = (int)(r % H), b = (int)(r / H);
-    const float* kk = kern + (size_t)b * kern_bs + (size_t)c4 * 36;
-    float4 acc = x[i];
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-        const int y = yy + dy - 1;
-        if (y < 0 || y >= H) continue;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int xq = xx + dx - 1;
-            if (xq < 0 || xq >= W) continue;
-            const float4 v = x[(((size_t)b * H + y) * W + xq) * C4 + c4];
-            const int t = flip ? 8 - (dy * 3 + dx) : dy * 3 + dx;
-            acc.x = fmaf(v.x, kk[t], acc.x), acc.y = fmaf(v.y, kk[9 + t], acc.y);
-            acc.z = fmaf(v.z, kk[18 + t], acc.z), acc.w = fmaf(v.w, kk[27 + t], acc.w);
-        }
-    }
-    out[i] = acc;
-}
-
-// grid (row chunks, C4, B); 256 threads stride over the pixels of the chunk; 36 partial sums per thread
-__global__ __launch_bounds__(256) void dw_bwd_k_nhwc_kernel(const float4* __restrict__ x, const float4* __restrict__ g, int H, int W,
-                                                            int C4, int rows_per_chunk, float* __restrict__ partials) {
-    __shared__ float red[4][36];
-    const int chunk = blockIdx.x, c4 = blockIdx.y, b = blockIdx.z;
-    const int y0 = chunk * rows_per_chunk, y1 = min(H, y0 + rows_per_chunk);
-    float s[36];
-#pragma unroll
-    for (int t = 0; t < 36; ++t) s[t] = 0.0f;
-    for (int p = y0 * W + threadIdx.x; p < y1 * W; p += 256) {
-        const int yy = p / W, xx = p - yy * W;
-        const float4 gv = g[(((size_t)b * H + yy) * W + xx) * C4 + c4];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int y = yy + dy - 1;
-            if (y < 0 || y >= H) continue;
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int xq = xx + dx - 1;
-                if (xq < 0 || xq >= W) continue;
-                const float4 v = x[(((size_t)b * H + y) * W + xq) * C4 + c4];
-                const int t = dy * 3 + dx;
-                s[t] = fmaf(gv.x, v.x, s[t]), s[9 + t] = fmaf(gv.y, v.y, s[9 + t]);
-                s[18 + t] = fmaf(gv.z, v.z, s[18 + t]), s[27 + t] = fmaf(gv.w, v.w, s[27 + t]);
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 36; ++t)
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s[t] += __shfl_xor(s[t], m);
-    if ((threadIdx.x & 63) == 0)
-#pragma unroll
-        for (int t = 0; t < 36; ++t) red[threadIdx.x >> 6][t] = s[t];
-    __syncthreads();
-    if (threadIdx.x < 36)
-        partials[(((size_t)chunk * gridDim.z + b) * C4 + c4) * 36 + threadIdx.x] =
-            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-
-__global__ __launch_bounds__(256) void dw_bwd_k_finalize_kernel(const float* __restrict__ partials, int chunks, int n,
-                                                                float* __restrict__ dk) {
-    const int i = blockIdx.x * 256 + threadIdx.x;       // n = B * C4 * 36 = B * C * 9 in [b][c][tap] order already
-    if (i >= n) return;
-    float s = 0.0f;
-    for (int c = 0; c < chunks; ++c) s += partials[(size_t)c * n + i];
-    dk[i] = s;
-}
 
 __global__ __launch_bounds__(256) void maxpool_idx_nhwc_kernel(const float4* __restrict__ x, int H, int W, int C4, int k, int stride,
                                                                int pad, int Ho, int Wo, size_t total, float4* __restrict__ out,
@@ -1063,31 +984,6 @@ __global__ __launch_bounds__(256) void resample_taps_kernel(const float4* __rest
 }  // namespace
 
 extern "C" {
-
-int ossid_dw_add_nhwc(const float* x, const float* kernels, int kernels_batch_stride, int B, int H, int W, int C, int flip,
-                      float* out, void* stream) {
-    if (!x || !kernels || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || kernels_batch_stride < 0) return OSSID_EINVAL;
-    const size_t total = (size_t)B * H * W * (C / 4);
-    hipLaunchKernelGGL(dw_add_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)x, kernels, kernels_batch_stride, H, W, C / 4, flip, total, (float4*)out);
-    return ossid_launch_status();
-}
-
-size_t ossid_dw_bwd_k_workspace_floats(int B, int H, int C) {
-    const int chunks = (H + 7) / 8;
-    return (size_t)chunks * B * C * 9;
-}
-
-int ossid_dw_bwd_k_nhwc(const float* x, const float* g, int B, int H, int W, int C, float* workspace, float* dk, void* stream) {
-    if (!x || !g || !workspace || !dk || B <= 0 || B > 65535 || H <= 0 || W <= 0 || C <= 0 || C % 4 || C / 4 > 65535) return OSSID_EINVAL;
-    const int rows = 8, chunks = (H + rows - 1) / rows;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(dw_bwd_k_nhwc_kernel, dim3(chunks, C / 4, B), dim3(256), 0, s, (const float4*)x, (const float4*)g, H, W, C / 4,
-                       rows, workspace);
-    const int n = B * C * 9;
-    hipLaunchKernelGGL(dw_bwd_k_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)workspace, chunks, n, dk);
-    return ossid_launch_status();
-}
 
 int ossid_resample_taps_nhwc(const float* x, int B, int Hin, int Win, int C, int x_channel_stride, int Hout, int Wout,
                              const int32_t* taps_y_idx, const float* taps_y_w, const int32_t* taps_x_idx, const float* taps_x_w,

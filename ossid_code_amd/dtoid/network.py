@@ -586,17 +586,16 @@ class FusedBackbone:
     """Test-time execution plan of the DenseNet-121 part of ImageFeatExtract on csrc/conv.hip. Each dense layer is two
     launches -- 1x1 conv with norm1+ReLU folded into its input staging, 3x3 conv with norm2+ReLU folded likewise -- and
     writes its 32 channels straight into the block's resident channels-last buffer; transitions are one fused 1x1 conv
-    plus the average pool; norm5 -> c1 (1x1) -> ELU -> n1 is ONE launch. The stem (7x7 stride-2 conv, template
-    modulation, norm0/ReLU/max-pool) stays on torch ops. Rebuilt whenever the parameters change."""
+    plus the average pool; norm5 -> c1 (1x1) -> ELU -> n1 is ONE launch. The stem: csrc/stem.hip's 7x7 stride-2 kernel,
+    then template modulation + norm0 + ReLU in one pass and the max-pool. Rebuilt whenever the parameters change."""
 
     def __init__(self, ife):
         P = ops.PackedConv
         self.ife = ife
         seq = list(ife.backdense_1) + list(ife.backdense_2)      # norm0 relu0 pool0 block1 | trans1 block2 ... norm5
         self.stem = seq[:3]
-        # stem on this repo's kernels: im2col (+ normalizeImageRange) -> 1x1 conv on the MFMA kernel -> template
-        # modulation + norm0 + ReLU in one pass -> max-pool, channels-last from the first kernel on
-        self.conv0 = P(ops._StemAsMatrix(ife.backdense_0[0], 160))
+        # stem on this repo's kernels: implicit-im2col 7x7 / 2 MFMA convolution (+ normalizeImageRange; reads the parameter
+        # itself: nothing to pack) -> template modulation + norm0 + ReLU in one pass -> max-pool, channels-last throughout
         self.norm0 = self.stem[0]
         self.norm0_affine = [t.clone() for t in ops._bn_affine(self.norm0)]
         self.stages = []
@@ -615,7 +614,6 @@ class FusedBackbone:
             for pk in ([p for pair in packed for p in pair] if kind == "block" else [packed]):
                 pk.refresh()
         self.final.refresh()
-        self.conv0.refresh()
         for dst, src in zip(self.norm0_affine, ops._bn_affine(self.norm0)):
             dst.copy_(src)
 
@@ -625,8 +623,7 @@ class FusedBackbone:
         """raw_image: `image` is in [0, 1] and normalizeImageRange is applied inside the stem's gather (D1)."""
         ife = self.ife
         if self.use_fused_stem:
-            cols = ops.im2col_stem(image, 7, 2, 3, 160, normalize=raw_image)
-            x0 = self.conv0(cols)
+            x0 = ops.stem_conv(image, ife.backdense_0[0], normalize=raw_image)
             x = ops.maxpool_nhwc(ops.stem_tail(x0, template_feat, *self.norm0_affine), 3, 2, 1)
         else:
             if raw_image:
@@ -756,9 +753,10 @@ class Network(nn.Module):
     # sequences (dtoid/train_encoders.py; round 3 -- round 2's form, ~25 autograd nodes per encoder, was 0.3-1.1 ms slower
     # than torch / MIOpen because of its host cost). OSSID_TRAIN_TEMPLATES=0: the nn.Module path (MIOpen).
     use_hip_template_training = os.environ.get("OSSID_TRAIN_TEMPLATES", "1") != "0"
-    # The 7x7 stem + norm0 + pool0 on this repo's kernels (im2col + 1x1 MFMA conv / wgrad, DwXcorrAdd, MaxPoolNHWC,
-    # bn_act_train; tested against the module path).
-    use_hip_stem_training = os.environ.get("OSSID_TRAIN_STEM", "0") != "0"
+    # The 7x7 stem + template modulation + norm0 + pool0 on this repo's kernels (csrc/stem.hip: implicit-im2col MFMA
+    # convolution and weight gradient, fused statistics / pooling passes; train_ops.StemConv / StemTail). False = the
+    # nn.Module path (MIOpen) for these layers: what the tests compare against.
+    use_hip_stem_training = True
 
     # Independent branches of the training step on side HIP streams (eager execution only -- under a graph capture the
     # branches run in line): the local template encoder beside the image backbone, the three correlation convolutions
@@ -817,16 +815,12 @@ class Network(nn.Module):
         self.__dict__["_pack_event"] = pack_event
         seq = list(ife.backdense_1) + list(ife.backdense_2)      # norm0 relu0 pool0 block1 | trans1 block2 ... norm5
         if self.use_hip_stem_training:
-            # stem on this repo's kernels, channels-last from the first one: im2col -> 1x1 MFMA conv (weight gradient
-            # by the same 1x1 wgrad kernel), template modulation, training BatchNorm + ReLU, max-pool
-            conv0 = ife.backdense_0[0]
-            with T.exact_forward():                               # BatchNorm + ReLU + max-pool decide on its output
-                x0 = T.FusedConv.apply(ops.im2col_stem(image, 7, 2, 3, 160), T.relaid_stem_weight(conv0, 160), conv0.bias, None,
-                                       None, False, 0, None, False)
+            # stem on this repo's kernels, channels-last from the first one
+            x0 = T.stem_conv(image, ife.backdense_0[0])           # implicit-im2col 7x7 / 2 kernel, exact f32 (csrc/stem.hip)
             if lazy_g is not None:
                 g, s_g = lazy_g()
                 self._join(s_g, [g])
-            x = T.MaxPoolNHWC.apply(T.bn_act_train(T.DwXcorrAdd.apply(x0, g), seq[0], relu=True), 3, 2, 1, False)
+            x = T.stem_tail(x0, g, seq[0])                        # modulation + norm0 + ReLU + pool0: three passes
         else:
             x0 = ife.backdense_0(image)
             if lazy_g is not None:

@@ -145,6 +145,34 @@ def im2col_stem(img, k, stride, pad, kpad, normalize=False, out=None):
     return out
 
 
+def _imnorm(device):
+    key = str(device)
+    if key not in _IMNORM:
+        _IMNORM[key] = (torch.tensor([0.485, 0.456, 0.406], device=device), 1.0 / torch.tensor([0.229, 0.224, 0.225], device=device))
+    return _IMNORM[key]
+
+
+def stem_conv(img, conv, normalize=False):
+    """DenseNet conv0 (nn.Conv2d(3, 64, 7, stride 2, padding 3)) on the NCHW image -> channels-last [B,64,Ho,Wo], no autograd:
+    ossid_stem_conv_fwd reads the parameter's own layout (nothing to pack or refresh; a captured graph sees weight updates)
+    and applies normalizeImageRange while staging when `normalize`."""
+    _lib.require_cuda(img, conv.weight)
+    img = img.float().contiguous()
+    B, Cin, H, W = img.shape
+    w = conv.weight.detach()
+    k = int(w.shape[2])
+    Ho, Wo = (H + 6 - k) // 2 + 1, (W + 6 - k) // 2 + 1
+    out = torch.empty((B, int(w.shape[0]), Ho, Wo), dtype=torch.float32, device=img.device, memory_format=torch.channels_last)
+    mean, inv = _imnorm(img.device) if normalize else (None, None)
+    with _lib.on_device(img.device):
+        rc = _lib.fn("ossid_stem_conv_fwd")(img.data_ptr(), B, Cin, H, W, w.data_ptr(), int(w.shape[0]), k, conv.stride[0],
+                                            conv.padding[0], None if conv.bias is None else conv.bias.detach().data_ptr(),
+                                            None if mean is None else mean.data_ptr(), None if inv is None else inv.data_ptr(),
+                                            out.data_ptr(), _lib.stream())
+    _lib.check(rc, "ossid_stem_conv_fwd")
+    return out
+
+
 def stem_tail(x0, kernels, scale, shift):
     """relu(scale * (x0 + dw_xcorr(x0, kernels)) + shift) on a channels-last x0 [B,C,H,W]; kernels [B or 1, C, 3, 3]."""
     B, C, H, W = x0.shape

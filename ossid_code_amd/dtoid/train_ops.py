@@ -992,7 +992,7 @@ class DwXcorrAdd(torch.autograd.Function):
                 _lib.check(_lib.fn("ossid_dw_add_nhwc")(g.data_ptr(), k.data_ptr(), C * 9 if k.shape[0] > 1 else 0, B, H, W, C, 1,
                                                         dx.data_ptr(), _lib.stream()), "ossid_dw_add_nhwc")
             if ctx.needs_input_grad[1]:
-                ws = _scratch("dwk", _lib.fn("ossid_dw_bwd_k_workspace_floats")(B, H, C) * 4, x.device)
+                ws = _scratch("dwk", _lib.fn("ossid_dw_bwd_k_workspace_floats")(B, H, W, C) * 4, x.device)
                 dkb = torch.empty((B, C, 3, 3), dtype=torch.float32, device=x.device)
                 _lib.check(_lib.fn("ossid_dw_bwd_k_nhwc")(x.data_ptr(), g.data_ptr(), B, H, W, C, ws.data_ptr(), dkb.data_ptr(),
                                                           _lib.stream()), "ossid_dw_bwd_k_nhwc")
@@ -1117,12 +1117,134 @@ def bn_act_train(x, bn, relu=False):
     return AffineAct.apply(x, scale, shift, bool(relu))
 
 
-def relaid_stem_weight(conv, kpad):
-    """[Cout, Cin, k, k] -> [Cout, kpad, 1, 1] in ossid_im2col_stem's column order (differentiable torch ops)."""
-    w = conv.weight
-    cout = w.shape[0]
-    flat = w.permute(0, 2, 3, 1).reshape(cout, -1)
-    return torch.nn.functional.pad(flat, (0, kpad - flat.shape[1])).reshape(cout, kpad, 1, 1).contiguous()
+class StemConv(torch.autograd.Function):
+    """DenseNet conv0 = nn.Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (network.py:164-170) on the NCHW image as the
+    caller holds it -> channels-last [B,64,Ho,Wo]: implicit-im2col MFMA kernel of csrc/stem.hip, exact f32. Backward: the
+    weight gradient only (the image is an input), on the weight-gradient stream; written straight into the flat gradient
+    buffer when autograd will take it over unread."""
+
+    @staticmethod
+    def forward(ctx, img, w, bias):
+        img = img.float().contiguous()
+        B, Cin, H, W = img.shape
+        Cout, k = int(w.shape[0]), int(w.shape[2])
+        Ho, Wo = (H + 6 - k) // 2 + 1, (W + 6 - k) // 2 + 1
+        out = empty_nhwc(B, Cout, Ho, Wo, img.device)
+        wd = w.detach()
+        assert wd.is_contiguous()
+        with _lib.on_device(img.device):
+            _lib.check(_lib.fn("ossid_stem_conv_fwd")(img.data_ptr(), B, Cin, H, W, wd.data_ptr(), Cout, k, 2, 3,
+                                                      _p(None if bias is None else bias.detach()), None, None, out.data_ptr(),
+                                                      _lib.stream()), "ossid_stem_conv_fwd")
+        ctx.save_for_backward(img, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        img, w = ctx.saved_tensors
+        B, Cin, H, W = img.shape
+        Cout, k = int(w.shape[0]), int(w.shape[2])
+        dev = img.device
+        g = nhwc(g)
+        dw = db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g.sum((0, 2, 3))
+        if ctx.needs_input_grad[1]:
+            dwb = grad_home(w, _grad_taken_unread(w))
+            nbytes = _lib.fn("ossid_stem_conv_wgrad_workspace_bytes")(B, H, W)
+
+            def run():
+                ws = _scratch("stem_wgrad", nbytes, dev)
+                _lib.check(_lib.fn("ossid_stem_conv_wgrad")(img.data_ptr(), g.data_ptr(), B, Cin, H, W, Cout, k, 2, 3, None, None,
+                                                            ws.data_ptr(), ws.numel(), dwb.data_ptr(), 0, _lib.stream()),
+                           "ossid_stem_conv_wgrad")
+            with _lib.on_device(dev):
+                _wgrad_async([img, g, dwb], run, dev, weights=(w,))
+            dw = _alias(dwb)
+        return None, dw, db
+
+
+class StemTail(torch.autograd.Function):
+    """pool0(relu(norm0(x0 + conv2d_dw_group(x0, k)))) in training mode (network.py:177-181 with torchvision's densenet121
+    features norm0 / relu0 / pool0 = BatchNorm2d(64), ReLU, MaxPool2d(3, 2, 1)) on the channels-last stem output x0
+    [B,64,H,W], k [B or 1,64,3,3], in three passes over the 157 MB tensor forward and four backward (csrc/stem.hip):
+      forward   m = x0 + dw(x0, k) with norm0's batch statistics as column-sum partials in the same pass; fold; max-pool of
+                relu(scale m + shift) with argmax bytes -- the normalised tensor is never written
+      backward  pass 1 re-forms the masked un-pooled gradient on the fly for (d shift, d scale); fold; pass 2 re-forms it
+                again and writes dm through BatchNorm's output and statistics; dx0 = dm + dw(dm, rot180 k); dk.
+    Returns the pooled tensor; gradients for x0, k, gamma, beta."""
+
+    @staticmethod
+    def forward(ctx, x0, k, gamma, beta, bn):
+        x0 = nhwc(x0)
+        B, C, H, W = x0.shape
+        dev = x0.device
+        kc = k.detach().float().contiguous()
+        kbs = C * 9 if kc.shape[0] > 1 else 0
+        n = B * H * W
+        m = torch.empty_like(x0)
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = empty_nhwc(B, C, Ho, Wo, dev)
+        idx = torch.empty(B * Ho * Wo * C, dtype=torch.uint8, device=dev)
+        with _lib.on_device(dev):
+            P = _lib.fn("ossid_dw_add_stats_partials")(B, H, W, C)
+            if P <= 0:
+                raise ValueError("StemTail: unsupported shape %s" % (tuple(x0.shape),))
+            part = _scratch("stem_stats", P * 2 * C * 4, dev)
+            pivot = new_buf((C,), dev)
+            _lib.check(_lib.fn("ossid_dw_add_stats_nhwc")(x0.data_ptr(), kc.data_ptr(), kbs, B, H, W, C, 0, m.data_ptr(),
+                                                          part.data_ptr(), pivot.data_ptr(), _lib.stream()), "ossid_dw_add_stats_nhwc")
+            f = bn_fold_fwd((part, P, pivot), C, n, gamma, beta, bn.eps, _mom(bn),
+                            bn.running_mean if bn.track_running_stats else None,
+                            bn.running_var if bn.track_running_stats else None)
+            _lib.check(_lib.fn("ossid_stem_pool_fwd")(m.data_ptr(), f[0].data_ptr(), f[1].data_ptr(), B, H, W, C, out.data_ptr(),
+                                                      idx.data_ptr(), _lib.stream()), "ossid_stem_pool_fwd")
+        ctx.save_for_backward(x0, m, kc, idx, f, gamma)
+        ctx.k_shape = tuple(k.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dp):
+        x0, m, kc, idx, f, gamma = ctx.saved_tensors
+        B, C, H, W = x0.shape
+        dev = x0.device
+        n = B * H * W
+        dp = nhwc(dp)
+        kbs = C * 9 if kc.shape[0] > 1 else 0
+        pool_bwd = _lib.fn("ossid_stem_pool_bwd")
+        with _lib.on_device(dev):
+            P = _lib.fn("ossid_stem_pool_bwd_partials")(B, H, W, C)
+            part = _scratch("stem_stats", P * 2 * C * 4, dev)
+            _lib.check(pool_bwd(m.data_ptr(), idx.data_ptr(), dp.data_ptr(), f[0].data_ptr(), f[1].data_ptr(), None, None,
+                                B, H, W, C, part.data_ptr(), None, _lib.stream()), "ossid_stem_pool_bwd")
+            r = torch.empty((4, C), dtype=torch.float32, device=dev)            # dgamma, dbeta, coef_x, coef_1
+            bn_fold_bwd(None, None, gamma, f[2], f[3], C, n, r[0], r[1], r[2], r[3], partials=(part, P))
+            dm = torch.empty_like(m)
+            _lib.check(pool_bwd(m.data_ptr(), idx.data_ptr(), dp.data_ptr(), f[0].data_ptr(), f[1].data_ptr(), r[2].data_ptr(),
+                                r[3].data_ptr(), B, H, W, C, None, dm.data_ptr(), _lib.stream()), "ossid_stem_pool_bwd")
+            dx0 = dk = None
+            if ctx.needs_input_grad[0]:
+                dx0 = torch.empty_like(x0)
+                _lib.check(_lib.fn("ossid_dw_add_nhwc")(dm.data_ptr(), kc.data_ptr(), kbs, B, H, W, C, 1, dx0.data_ptr(), _lib.stream()),
+                           "ossid_dw_add_nhwc")
+            if ctx.needs_input_grad[1]:
+                ws = _scratch("dwk", _lib.fn("ossid_dw_bwd_k_workspace_floats")(B, H, W, C) * 4, dev)
+                dkb = torch.empty((B, C, 3, 3), dtype=torch.float32, device=dev)
+                _lib.check(_lib.fn("ossid_dw_bwd_k_nhwc")(x0.data_ptr(), dm.data_ptr(), B, H, W, C, ws.data_ptr(), dkb.data_ptr(),
+                                                          _lib.stream()), "ossid_dw_bwd_k_nhwc")
+                dk = dkb if ctx.k_shape[0] > 1 else dkb.sum(0, keepdim=True)
+        return dx0, dk, r[0], r[1], None
+
+
+def stem_tail(x0, k, bn):
+    """Template modulation + training norm0 + ReLU + pool0 behind the stem convolution (StemTail)."""
+    return StemTail.apply(x0, k, bn.weight, bn.bias, bn)
+
+
+def stem_conv(img, conv):
+    """Apply DenseNet's conv0 (7x7 / stride 2 / padding 3, 3 -> 64) through StemConv."""
+    return StemConv.apply(img, conv.weight, conv.bias)
 
 
 def dense_block_train(x, block):

@@ -446,3 +446,80 @@ def test_weight_gradient_of_a_non_leaf_weight_is_complete_when_backward_returns_
     y64 = F.conv2d(x.double().cpu(), w64 * scale.double().cpu(), padding=1)
     y64.backward(go.double().cpu())
     assert rel(got, w64.grad) < 5e-5
+
+
+@pytest.mark.parametrize("B,H,W,normalize", [(2, 480, 640, False), (1, 480, 640, True), (3, 53, 77, False), (1, 16, 40, True),
+                                             (2, 7, 9, False)])
+def test_stem_conv7x7s2_implicit_im2col_forward_and_weight_gradient(hiplib, B, H, W, normalize):
+    """csrc/stem.hip: DenseNet conv0 (3 -> 64, 7x7, stride 2, padding 3; network.py:164-170) as an implicit-im2col MFMA
+    kernel on the NCHW image, and its weight gradient, against float64 conv2d / autograd on the CPU. Exact-f32 products
+    (an fmaf chain per output): 2e-6 of the output scale; the weight gradient sums up to 600 k products per element in a
+    fixed order: 2e-5. Ragged sizes exercise the tile masks; `normalize` = normalizeImageRange fused into the staging
+    (test time)."""
+    from ossid_code_amd.dtoid import ops
+    g = torch.Generator().manual_seed(B * 1000 + H + W)
+    conv = torch.nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(64, 3, 7, 7, generator=g) * 0.1)
+    img = torch.rand(B, 3, H, W, generator=g)
+    ref_in = img.double()
+    if normalize:
+        mean = torch.tensor([0.485, 0.456, 0.406], dtype=torch.float64)[None, :, None, None]
+        std = torch.tensor([0.229, 0.224, 0.225], dtype=torch.float64)[None, :, None, None]
+        ref_in = (ref_in - mean) / std
+    w64 = conv.weight.detach().double().requires_grad_(True)
+    want = F.conv2d(ref_in, w64, stride=2, padding=3)
+    convg = copy.deepcopy(conv).cuda()
+    got = ops.stem_conv(img.cuda(), convg, normalize=normalize)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert rel(got, want) < (2e-5 if normalize else 2e-6)          # (normalised: (x - m) * (1/s) in f32 vs (x - m) / s in f64)
+    if not normalize:
+        go = torch.randn(want.shape, generator=g)
+        want.backward(go.double())
+        y = T.stem_conv(img.cuda(), convg)
+        assert torch.equal(y, got)
+        y.backward(cl(go))
+        torch.cuda.synchronize()
+        assert rel(convg.weight.grad, w64.grad) < 2e-5
+        # bit-reproducible: fixed-order sums
+        g1 = convg.weight.grad.clone()
+        convg.weight.grad = None
+        T.stem_conv(img.cuda(), convg).backward(cl(go))
+        torch.cuda.synchronize()
+        assert torch.equal(convg.weight.grad, g1)
+
+
+@pytest.mark.parametrize("B,C,H,W,kb", [(2, 64, 30, 44, 2), (3, 16, 21, 27, 1), (1, 64, 240, 320, 1), (2, 8, 5, 6, 2)])
+def test_stem_tail_fused_modulation_batchnorm_relu_pool_matches_torch_autograd(hiplib, B, C, H, W, kb):
+    """train_ops.StemTail (csrc/stem.hip: modulation with the batch statistics in the same pass, pool of relu(norm0) without
+    the normalised tensor, the two-pass backward) against torch autograd of
+    max_pool2d(relu(batch_norm(x + conv2d_dw_group(x, k))), 3, 2, 1) in float64 on the CPU: output, gradients with respect to
+    x, k, gamma, beta, and the running statistics. A pre-activation within rounding of zero may take the other side of the
+    ReLU in f32: compared in relative L2 with a handful of flips allowed for."""
+    from oracle import dtoid_oracle
+    g = torch.Generator().manual_seed(B * 100 + C + H)
+    x = torch.randn(B, C, H, W, generator=g)
+    k = torch.randn(kb, C, 3, 3, generator=g) * 0.3
+    bn = torch.nn.BatchNorm2d(C).train()
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(C, generator=g))
+        bn.weight[0] = -0.7                                   # a negative gamma: relu(affine) is then decreasing in m
+        bn.bias.copy_(0.3 * torch.randn(C, generator=g))
+    rbn = copy.deepcopy(bn).double()
+    xr, kr = x.double().requires_grad_(True), k.double().requires_grad_(True)
+    yr = F.max_pool2d(F.relu(rbn(xr + dtoid_oracle.dw_xcorr(xr, kr.expand(B, -1, -1, -1)))), 3, 2, 1)
+    go = torch.randn(yr.shape, generator=g)
+    yr.backward(go.double())
+    bn = bn.cuda()
+    xm, km = cl(x).requires_grad_(True), k.cuda().requires_grad_(True)
+    y = T.stem_tail(xm, km, bn)
+    y.backward(cl(go))
+    torch.cuda.synchronize()
+
+    def l2(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float((a - b).norm() / b.norm().clamp(min=1e-30))
+    assert y.shape == yr.shape and rel(y, yr) < 1e-5
+    assert l2(xm.grad, xr.grad) < 1e-4, l2(xm.grad, xr.grad)
+    assert l2(km.grad, kr.grad) < 1e-4 and l2(bn.weight.grad, rbn.weight.grad) < 1e-4 and l2(bn.bias.grad, rbn.bias.grad) < 1e-4
+    assert rel(bn.running_mean, rbn.running_mean) < 1e-5 and rel(bn.running_var, rbn.running_var) < 1e-5
