@@ -245,34 +245,44 @@ def dtoid_leg(a, dev, dist, world):
     finally:
         m.model.use_hip_training = True
     nominal, executed = dtoid_flops(nt)
-    note = ("frac_mfma = the MFMA pipe's busy fraction: matrix-core multiply-adds the leg ISSUES (counted at the launch "
-            "sites of one eager pass, ossid_code_amd._lib.count_mfma: Winograd layers at their 16 multiplies per 2x2 tile, "
-            "reassociated layers at what they run, weight gradients included), each launch in units of f32-pipe time -- "
-            "launches on v_mfma_f32_32x32x2_f32 1:1, split-bf16 launches (three v_mfma_f32_32x32x16_bf16 per f32 product, an "
-            "instruction with 16x the f32 one's rate: every test-time convolution, the Winograd layers, data and weight "
-            "gradients) 3/16 -- "
-            "/ wall time / 157.3 TFLOP/s, over the whole "
-            "call incl. top-k / NMS / host latency: <= 1 by construction. achieved_mfma = the same multiply-adds as f32 "
-            "arithmetic / time (mfma_gflop_per_call; pipe-weighted: mfma_pipe_gflop_per_call). frac = the reference's NOMINAL flops "
-            "(39.7 + 45.96 n_t GFLOP per frame; 258 GFLOP per finetune sample) / time / peak: a throughput in the "
-            "reference's units that can exceed 1 because Winograd and the exact reassociations of DESIGN.md 5 execute "
-            "fewer multiplies. frac_executed = nominal minus the reassociations only (kept from round 2). peak = the "
-            "guide's dense f32 MFMA figure at 2.4 GHz. Arithmetic: f32 tensors and f32 accumulation everywhere; the DTOID "
-            "convolutions form each f32 product from three bf16 matrix-core products (~5e-6 of the output scale vs float64, "
-            "DESIGN.md 5e) except the training forward of the ReLU / max-pool networks, which stays on the exact-f32 "
-            "instruction")
+    note = ("frac_mfma: matrix-core multiply-adds the leg ISSUES (counted at the launch sites of one eager pass, "
+            "ossid_code_amd._lib.count_mfma: Winograd layers at 16 multiplies per 2x2 tile, reassociated layers at what they "
+            "run, weight gradients included), each launch in units of f32-pipe time (v_mfma_f32_32x32x2_f32 launches 1:1, "
+            "split-bf16 launches 3/16, three-way-split launches 6/16) / wall / 157.3 TFLOP/s, over the whole call incl. "
+            "top-k / NMS / host latency: <= 1 by construction. hbm_frac: (2 x FETCH_SIZE + WRITE_SIZE) per call from "
+            "profiles/r04_dtoid_traffic.json / wall / 8 TB/s. achieved_mfma: the same multiply-adds as f32 arithmetic / wall")
 
-    def mfma_fields(counted_pair, t):
+    # bytes beyond L2 and launches per call of each leg, from the committed rocprofv3 passes (separate --pmc FETCH_SIZE /
+    # WRITE_SIZE runs, tools/pmc_dtoid_traffic.py; read = 2 x FETCH_SIZE on gfx950, Infinity-Cache hits included: an upper
+    # bound on HBM bytes)
+    try:
+        leg_pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_dtoid_traffic.json")))["legs"]
+    except Exception:
+        leg_pmc = {}
+    SPLIT = "f32 tensors, f32 accumulate; each f32 product = 3 bf16 matrix-core products (v_mfma_f32_32x32x16_bf16)"
+
+    def roof(leg, flops_nom, t, counted_pair, dtype, flops_exec=None, calls_per_t=1):
+        """What bounds a DTOID leg. frac_mfma: the matrix pipe's busy fraction (counted launches in f32-pipe time / wall /
+        157.3 TFLOP/s); hbm_frac: counter bytes beyond L2 per call / wall / 8 TB/s; bound = the larger of the two, or
+        "latency" when both are under one half (then the launch count beside it is the number to look at).
+        nominal_over_f32_peak: the reference's nominal flops / wall / peak -- a throughput in the reference's units, NOT a
+        fraction of anything these kernels run against (Winograd and the reassociations execute fewer multiplies, split-bf16
+        products run at 16/3 of the f32 instruction's rate): it can exceed 1."""
         arith, pipe = counted_pair
-        return {"achieved_mfma": arith / t / 1e12, "frac_mfma": pipe / t / 1e12 / PEAK_F32_MATRIX_TFLOPS,
-                "mfma_gflop_per_call": arith / 1e9, "mfma_pipe_gflop_per_call": pipe / 1e9}
-
-    def roof(flops_nom, flops_exec, t, flops_mfma=None):
-        r = {"bound": "mfma", "achieved": flops_nom / t / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-             "frac": flops_nom / t / 1e12 / PEAK_F32_MATRIX_TFLOPS, "achieved_executed": flops_exec / t / 1e12,
-             "frac_executed": flops_exec / t / 1e12 / PEAK_F32_MATRIX_TFLOPS, "note": note}
-        if flops_mfma is not None:
-            r.update(mfma_fields(flops_mfma, t))
+        frac_mfma = pipe / t / 1e12 / PEAK_F32_MATRIX_TFLOPS
+        pm = leg_pmc.get(leg) or {}
+        traffic = pm.get("traffic_bytes_per_call")
+        launches = pm.get("launches_per_call")
+        hbm_frac = None if traffic is None else traffic * calls_per_t / t / 1e9 / PEAK_HBM_GBS
+        top = max(frac_mfma, hbm_frac or 0.0)
+        bound = "latency" if top < 0.5 else ("mfma" if frac_mfma >= (hbm_frac or 0.0) else "hbm")
+        r = {"bound": bound, "frac_mfma": frac_mfma, "hbm_frac": hbm_frac, "launches_per_call": launches,
+             "traffic": traffic, "achieved_mfma": arith / t / 1e12, "mfma_gflop_per_call": arith / 1e9,
+             "mfma_pipe_gflop_per_call": pipe / 1e9, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+             "peak_hbm_gbs": PEAK_HBM_GBS, "achieved_nominal": flops_nom / t / 1e12,
+             "nominal_over_f32_peak": flops_nom / t / 1e12 / PEAK_F32_MATRIX_TFLOPS, "dtype": dtype, "note": note}
+        if flops_exec is not None:
+            r["executed_over_f32_peak"] = flops_exec / t / 1e12 / PEAK_F32_MATRIX_TFLOPS
         return r
     pair_flops = (39.7e9 + 45.96e9 + 0.36e9) * B32          # + the two template encoders per pair
     # per-pair images: only the decoder reassociations apply (phase convs 4/9, tail rows 2/3)
@@ -281,19 +291,19 @@ def dtoid_leg(a, dev, dist, world):
                         "config": "forward_all_templates, 1 image x %d local templates per rank, 480x640, topk 500, f32; "
                                   "hand-written MFMA conv head + hipGraph" % nt,
                         "tflops": world * nominal / t_fwd / 1e12,
-                        "roofline": roof(nominal, executed, t_fwd, mf_fwd),
+                        "roofline": roof("forward", nominal, t_fwd, mf_fwd, SPLIT, executed),
                         "cpu_baseline": cpu_fwd},
             "forward_batch": {"metric": "DTOID imgs/sec", "value": world * B32 / t_b32, "unit": "img/s",
                               "ms_per_batch": 1e3 * t_b32, "ms_per_image": 1e3 * t_b32 / B32,
                               "config": "BASELINE configs[2]: batch=%d images 640x480 x %d templates per rank "
                                         "(forwardTestTimeBatch: forward_all_templates semantics per image, backbone "
                                         "batched, head graph per image), topk 500, f32" % (B32, nt),
-                              "roofline": roof(B32 * nominal, B32 * executed, t_b32, mf_b32)},
+                              "roofline": roof("forward_batch", B32 * nominal, t_b32, mf_b32, SPLIT, B32 * executed)},
             "forward_pairs": {"metric": "DTOID (image, template) pairs/sec", "value": world * B32 / t_pairs,
                               "unit": "pair/s", "ms_per_batch": 1e3 * t_pairs,
                               "config": "Network.forward on %d (image, template) pairs per rank, eval, f32 (template "
                                         "encoders + backbone + head, dense outputs)" % B32,
-                              "roofline": roof(pair_flops, pair_flops - pair_saved, t_pairs, mf_pairs)},
+                              "roofline": roof("forward_pairs", pair_flops, t_pairs, mf_pairs, SPLIT, pair_flops - pair_saved)},
             "finetune": {"metric": "DTOID finetune samples/sec", "value": world * B / t_ft, "unit": "sample/s",
                          "ms_per_step": 1e3 * t_ft,
                          "ms_per_step_module_path_miopen": 1e3 * t_ft_module, "global_batch": world * B,
@@ -306,14 +316,10 @@ def dtoid_leg(a, dev, dist, world):
                                     " (RCCL all-reduce of the flat 136 MB buffer)" if world > 1 else ""),
                          "tflops": world * B * 258e9 / t_ft / 1e12,
                          "cpu_baseline": cpu_ft,
-                         "roofline": {"bound": "mfma", "achieved": B * 258e9 / t_ft / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
-                                      "unit": "TFLOP/s", "frac": B * 258e9 / t_ft / 1e12 / PEAK_F32_MATRIX_TFLOPS,
-                                      **mfma_fields(mf_ft, t_ft),
-                                      "note": "frac: nominal 258 GFLOP per sample (3 x the 86 GFLOP forward, SURVEY.md 8d) over "
-                                              "the whole step incl. losses and optimizer; frac_mfma: the matrix-core work "
-                                              "the step issues (forward, data and weight gradients; Winograd layers at 16/36), "
-                                              "counted at the launch sites; per-layer rates and per-kernel step time in "
-                                              "profiles/"}}}
+                         "roofline": roof("finetune", B * 258e9, t_ft, mf_ft,
+                                          SPLIT + " in data / weight gradients and the ELU head; the training forward of the ReLU / "
+                                          "max-pool networks at f32 level (six products of a three-way split; exact-f32 instruction for "
+                                          "the stem and the template encoders)")}}
 
 
 def resolve_world(a, environ=None, spawn=None):
@@ -389,7 +395,8 @@ def make_line(names, stage_ms, feat_ms, elapsed, world, steps, warmup, n_streams
         "stage_ms_sum": round(float(sum(stage_ms)), 4),
         "featurize": {"bound": "hbm", "avg_launch_ms": feat_ms, "achieved": feat_bytes / (feat_ms * 1e-3) / 1e9,
                       "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": feat_bytes / (feat_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                      "bytes_per_launch": feat_bytes},
+                      "bytes_per_launch": feat_bytes,
+                      "measured": "HIP events around the launch in the one-frame-in-flight pass, like the scorer's stages"},
         "cpu_baseline": base,
         "dtoid": dtoid_out,
     }
@@ -441,14 +448,14 @@ def main():
     # (scoring.networkInferenceMany). Per-kernel HIP events are taken in a second pass (below), one frame at a time.
     feat_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
-    def step(i=None, events=None):
+    def step(events=None, feat_pair=None):
         rgbd = zephyr.stage_frame(img, depth, dev, blur=True)
         tab = zephyr.stage_model(pts, nrm, col, dev)
-        if i is not None:
-            feat_evs[i][0].record()
+        if feat_pair is not None:
+            feat_pair[0].record()
         px, uv = zephyr.featurize(rgbd, T, tab, cam, want_uv=True)
-        if i is not None:
-            feat_evs[i][1].record()
+        if feat_pair is not None:
+            feat_pair[1].record()
         scores = model.score(px, stage_events=events)
         return scores, scores.argmax()
 
@@ -465,7 +472,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         with torch.cuda.stream(streams[i % len(streams)]):
-            scores, top = step(i)
+            scores, top = step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -475,15 +482,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    feat_ms = float(np.mean([s0.elapsed_time(s1) for s0, s1 in feat_evs]))
     # The roofline leg: the same K frames once more, ONE frame in flight, HIP events recorded on the launch stream around
-    # every stage (ossid_pn2_score's stage_events_host) -- each kernel alone on the chip, which is what a per-kernel
-    # fraction of peak means. (rocprofv3's per-kernel averages over this command mix both passes: launches of the timed
-    # region run beside another frame's kernels and take a few per cent longer.)
+    # every stage (ossid_pn2_score's stage_events_host) and around the featurize kernel -- each kernel alone on the chip,
+    # which is what a per-kernel fraction of peak means. (rocprofv3's per-kernel averages over this command mix both
+    # passes: launches of the timed region run beside another frame's kernels and take a few per cent longer.)
     clean = [_lib.StageEvents() for _ in range(a.steps)]
     for i in range(a.steps):
-        step(None, clean[i])
+        step(clean[i], feat_evs[i])
     torch.cuda.synchronize()
+    feat_ms = float(np.mean([s0.elapsed_time(s1) for s0, s1 in feat_evs]))
     stage_ms = np.mean([e.elapsed_ms() for e in clean], axis=0)
     for e in clean:
         e.close()

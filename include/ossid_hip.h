@@ -439,6 +439,22 @@ int ossid_focal_smoothl1_loss_bwd(const float* dcls_raw, const float* dreg_raw, 
  * [Cout][Kpad] in the same column order. */
 int ossid_im2col_stem(const float* img_nchw, int B, int Cin, int H, int W, int k, int stride, int pad, int Kpad,
                       const float* mean, const float* inv_std, float* out, void* stream);
+/* D6  the small remainders of the correlation head, deterministic (fixed-order sums):
+ * ossid_conv1x1_c1_fwd: nn.Conv2d(C, 1, 1) on channels-last x [rows][C] (`corr_conv_heatmap`, network.py:334, :349):
+ *   out[r] = sum_c w[c] x[r][c] + bias[0], through a sigmoid when sigmoid != 0 (heat_map = torch.sigmoid(...)); C % 4 == 0.
+ * ossid_conv1x1_c1_bwd: dx[r][c] = g[r] w[c] (dx may be NULL), dw_db [C + 1] = (sum_r g[r] x[r][c], sum_r g[r]); C / 4 a power
+ *   of two <= 256; workspace >= ossid_conv1x1_c1_bwd_workspace_floats(rows, C) floats.
+ * ossid_spatial_mean: F.avg_pool2d(x, full window) (`avg_pool2d(template_feat, 7)`, network.py:343): x [B][C][HW] (NCHW) or
+ *   [B][HW][C] (channels_last != 0) -> out [B][C]; backward != 0: x = g [B][C] -> out = g / HW broadcast in x's layout.
+ * ossid_small_matmul: out [M][N] = a [M][K] b [K][N] (row-major, M <= 65535: a handful of rows against a wide matrix). */
+int ossid_conv1x1_c1_fwd(const float* x, long long rows, int C, const float* w, const float* bias, int sigmoid, float* out,
+                         void* stream);
+size_t ossid_conv1x1_c1_bwd_workspace_floats(long long rows, int C);
+int ossid_conv1x1_c1_bwd(const float* x, const float* g, long long rows, int C, const float* w, float* workspace, float* dx,
+                         float* dw_db, void* stream);
+int ossid_spatial_mean(const float* x, int B, int HW, int C, int channels_last, int backward, float* out, void* stream);
+int ossid_small_matmul(const float* a, const float* b, int M, int K, int N, float* out, void* stream);
+
 /* D4  DenseNet-121 conv0 = nn.Conv2d(3, 64, 7, stride 2, padding 3) of ImageFeatExtract (network.py:164-170, :175-177) as an
  * IMPLICIT-im2col convolution on the f32 matrix cores (csrc/stem.hip; exact f32: an fmaf chain), and its weight gradient
  * (the image is an input: there is no data gradient). img NCHW [B][3][H][W] as the caller holds it; mean / inv_std [3]

@@ -44,8 +44,12 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+LAST_BUILD = {"compiled": 0, "linked": False}     # what the last build_lib() call did (objects compiled; library linked)
+
+
 def build_lib(force=False, verbose=False):
-    """Compile every HIP source into ossid_code_amd/libossid_hip.so; returns its path."""
+    """Compile every HIP source into ossid_code_amd/libossid_hip.so; returns its path. LAST_BUILD says what was done."""
+    LAST_BUILD.update(compiled=0, linked=False)
     if not force and not is_stale():
         return LIB_PATH
     extra = os.environ.get("OSSID_HIPCC_EXTRA", "").split()       # A/B builds of ablation switches (-DOSSID_...)
@@ -71,6 +75,7 @@ def build_lib(force=False, verbose=False):
             list(ex.map(run, jobs))
     run([hipcc] + FLAGS + ["-shared", "-o", LIB_PATH + ".tmp"] + objs)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    LAST_BUILD.update(compiled=len(jobs), linked=True)
     return LIB_PATH
 
 

@@ -123,6 +123,11 @@ _PROTOS = {
     "ossid_focal_smoothl1_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_focal_smoothl1_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ossid_im2col_stem": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ossid_conv1x1_c1_fwd": (_i, [_vp, C.c_longlong, _i, _vp, _vp, _i, _vp, _vp]),
+    "ossid_conv1x1_c1_bwd_workspace_floats": (_sz, [C.c_longlong, _i]),
+    "ossid_conv1x1_c1_bwd": (_i, [_vp, _vp, C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ossid_spatial_mean": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ossid_small_matmul": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ossid_stem_conv_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ossid_stem_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "ossid_stem_conv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _i, _vp]),

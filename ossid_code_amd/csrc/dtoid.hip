@@ -1030,3 +1030,179 @@ int ossid_maxpool_bwd_nhwc(const float* dout, const uint8_t* argmax, int B, int 
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// D6  the last library calls of the correlation head, as own kernels (deterministic: fixed-order sums):
+//   conv1x1_c1     nn.Conv2d(C, 1, 1) on a channels-last x [rows][C] -- `corr_conv_heatmap` 512 -> 1 (network.py:334, :349) --
+//                  with the sigmoid of `heat_map = torch.sigmoid(...)` optionally fused; backward: dx = g * w, and per-
+//                  workgroup partial sums of (g * x per channel, g) for the weight / bias gradient
+//   spatial_mean   F.avg_pool2d(template_feat, 7) on 7x7 template features (network.py:343) = the mean over the HW positions
+//                  of [B][C][HW] (NCHW) or [B][HW][C] (channels-last) -> [B][C]; backward = broadcast of g / HW
+//   small_matmul   out [M][N] = a [M][K] b [K][N] for a handful of rows (conv_sub's response to the per-template constant
+//                  image: 21 x 640 x 2304) -- no library GEMM on the per-object path
+namespace {
+
+// one wave per row: lanes stride over the channels in float4
+__global__ __launch_bounds__(256) void conv1x1_c1_fwd_kernel(const float4* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, long long rows, int C4, int sigmoid,
+                                                             float* __restrict__ out) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.0f;
+    for (int c = lane; c < C4; c += 64) {
+        const float4 a = x[(size_t)r * C4 + c];          // (w: a slice of the flat parameter buffer, any 4-byte alignment)
+        s = fmaf(a.x, w[4 * c], s), s = fmaf(a.y, w[4 * c + 1], s), s = fmaf(a.z, w[4 * c + 2], s), s = fmaf(a.w, w[4 * c + 3], s);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (lane == 0) {
+        s += bias ? bias[0] : 0.0f;
+        out[r] = sigmoid ? 1.0f / (1.0f + expf(-s)) : s;
+    }
+}
+
+// grid = row chunks; thread (c4, strip): dx[r][c] = g[r] * w[c]; partial sums over the chunk's rows of g[r] * x[r][c]
+// -> partials[chunk][0..C), of g[r] -> partials[chunk][C]
+__global__ __launch_bounds__(256) void conv1x1_c1_bwd_kernel(const float4* __restrict__ x, const float* __restrict__ g,
+                                                             const float* __restrict__ w, long long rows, int C4,
+                                                             int rows_per_block, float4* __restrict__ dx,
+                                                             float* __restrict__ partials) {
+    __shared__ float red[256][4];
+    __shared__ float redg[256];
+    const int c4 = threadIdx.x % C4, strip = threadIdx.x / C4, nstrips = 256 / C4;
+    const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    const float4 wv = make_float4(w[4 * c4], w[4 * c4 + 1], w[4 * c4 + 2], w[4 * c4 + 3]);
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, sg = 0.f;
+    for (long long r = r0 + strip; r < r1; r += nstrips) {
+        const float gv = g[r];
+        const float4 xv = x[(size_t)r * C4 + c4];
+        if (dx) dx[(size_t)r * C4 + c4] = make_float4(gv * wv.x, gv * wv.y, gv * wv.z, gv * wv.w);
+        s[0] = fmaf(gv, xv.x, s[0]), s[1] = fmaf(gv, xv.y, s[1]), s[2] = fmaf(gv, xv.z, s[2]), s[3] = fmaf(gv, xv.w, s[3]);
+        if (c4 == 0) sg += gv;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[strip * C4 + c4][i] = s[i];
+    redg[threadIdx.x] = sg;
+    __syncthreads();
+    const int C = 4 * C4;
+    if (strip == 0) {
+        float t[4] = {red[c4][0], red[c4][1], red[c4][2], red[c4][3]};
+        for (int y = 1; y < nstrips; ++y)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] += red[y * C4 + c4][i];
+        float* row = partials + (size_t)blockIdx.x * (C + 1);
+        row[4 * c4] = t[0], row[4 * c4 + 1] = t[1], row[4 * c4 + 2] = t[2], row[4 * c4 + 3] = t[3];
+        if (c4 == 0) {
+            float tg = redg[0];
+            for (int y = 1; y < nstrips; ++y) tg += redg[y * C4];
+            row[C] = tg;
+        }
+    }
+}
+
+// out[i] = sum over chunks of partials[chunk][i], fixed order (32 outputs x 8 chunk ranges per workgroup)
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ partials, int nparts, int n, float* __restrict__ out) {
+    __shared__ float red[8][32];
+    const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + col;
+    const int per = (nparts + 7) / 8, g0 = part * per, g1 = min(nparts, g0 + per);
+    float s = 0.0f;
+    if (i < n)
+        for (int g = g0; g < g1; ++g) s += partials[(size_t)g * n + i];
+    red[part][col] = s;
+    __syncthreads();
+    if (part == 0 && i < n) {
+        float t = red[0][col];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) t += red[u][col];
+        out[i] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void spatial_mean_kernel(const float* __restrict__ x, int HW, int C, int channels_last, int backward,
+                                                           size_t total, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;     // forward: i over [B][C]; backward: i over x's elements
+    if (i >= total) return;
+    const float inv = 1.0f / (float)HW;
+    if (!backward) {
+        const size_t b = i / C, c = i % C;
+        const float* p = channels_last ? x + b * HW * C + c : x + i * HW;
+        const size_t st = channels_last ? C : 1;
+        float s = 0.0f;
+        for (int k = 0; k < HW; ++k) s += p[k * st];
+        out[i] = s * inv;
+    } else {                                                      // x = g [B][C]; out = dx in the forward input's layout
+        size_t b, c;
+        if (channels_last) b = i / ((size_t)HW * C), c = i % C;
+        else b = i / ((size_t)HW * C), c = (i / HW) % C;
+        out[i] = x[b * C + c] * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void small_matmul_kernel(const float* __restrict__ a, const float* __restrict__ b, int K, int N,
+                                                           float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+    if (n >= N) return;
+    const float* ar = a + (size_t)m * K;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= K; k += 4) {
+        s0 = fmaf(ar[k], b[(size_t)k * N + n], s0), s1 = fmaf(ar[k + 1], b[(size_t)(k + 1) * N + n], s1);
+        s2 = fmaf(ar[k + 2], b[(size_t)(k + 2) * N + n], s2), s3 = fmaf(ar[k + 3], b[(size_t)(k + 3) * N + n], s3);
+    }
+    for (; k < K; ++k) s0 = fmaf(ar[k], b[(size_t)k * N + n], s0);
+    out[(size_t)m * N + n] = (s0 + s1) + (s2 + s3);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ossid_conv1x1_c1_fwd(const float* x, long long rows, int C, const float* w, const float* bias, int sigmoid, float* out,
+                         void* stream) {
+    if (!x || !w || !out || rows < 0 || C <= 0 || C % 4 || ((uintptr_t)x & 15)) return OSSID_EINVAL;
+    if (rows == 0) return OSSID_OK;
+    hipLaunchKernelGGL(conv1x1_c1_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                       w, bias, rows, C / 4, sigmoid, out);
+    return ossid_launch_status();
+}
+
+static int conv1x1_c1_rows_per_block(long long rows) { return rows > 65536 ? 256 : 64; }
+
+size_t ossid_conv1x1_c1_bwd_workspace_floats(long long rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    const int rpb = conv1x1_c1_rows_per_block(rows);
+    return (size_t)((rows + rpb - 1) / rpb) * (C + 1);
+}
+
+int ossid_conv1x1_c1_bwd(const float* x, const float* g, long long rows, int C, const float* w, float* workspace, float* dx,
+                         float* dw_db, void* stream) {
+    const int C4 = C / 4;
+    if (!x || !g || !w || !workspace || !dw_db || rows <= 0 || C <= 0 || C % 4 || C4 > 256 || (C4 & (C4 - 1)) ||
+        ((uintptr_t)x & 15) || ((uintptr_t)dx & 15))
+        return OSSID_EINVAL;
+    const int rpb = conv1x1_c1_rows_per_block(rows);
+    const int chunks = (int)((rows + rpb - 1) / rpb);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv1x1_c1_bwd_kernel, dim3(chunks), dim3(256), 0, s, (const float4*)x, g, w, rows, C4, rpb,
+                       (float4*)dx, workspace);
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3((C + 1 + 31) / 32), dim3(256), 0, s, (const float*)workspace, chunks, C + 1, dw_db);
+    return ossid_launch_status();
+}
+
+int ossid_spatial_mean(const float* x, int B, int HW, int C, int channels_last, int backward, float* out, void* stream) {
+    if (!x || !out || B <= 0 || HW <= 0 || C <= 0) return OSSID_EINVAL;
+    const size_t total = backward ? (size_t)B * HW * C : (size_t)B * C;
+    hipLaunchKernelGGL(spatial_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, HW, C,
+                       channels_last, backward, total, out);
+    return ossid_launch_status();
+}
+
+int ossid_small_matmul(const float* a, const float* b, int M, int K, int N, float* out, void* stream) {
+    if (!a || !b || !out || M <= 0 || M > 65535 || K <= 0 || N <= 0) return OSSID_EINVAL;
+    hipLaunchKernelGGL(small_matmul_kernel, dim3((N + 255) / 256, M), dim3(256), 0, (hipStream_t)stream, a, b, K, N, out);
+    return ossid_launch_status();
+}
+
+}  // extern "C"

@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv_fwd_kernel(StemArgs a) {
                 const int co = 8 * q + 4 * k;
                 float4 v = make_float4(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
                 if (a.bias) {
-                    const float4 bb = *(const float4*)(a.bias + 32 * mt + co);
-                    v.x += bb.x, v.y += bb.y, v.z += bb.z, v.w += bb.w;
+                    const float* bb = a.bias + 32 * mt + co;          // (a slice of the flat parameter buffer: any alignment)
+                    v.x += bb[0], v.y += bb[1], v.z += bb[2], v.w += bb[3];
                 }
                 *(float4*)(myep + n * F_EPS + co) = v;
             }
@@ -616,7 +616,7 @@ extern "C" {
 int ossid_stem_conv_fwd(const float* img_nchw, int B, int Cin, int H, int W, const float* weight, int Cout, int k, int stride,
                         int pad, const float* bias, const float* mean, const float* inv_std, float* out, void* stream) {
     if (!img_nchw || !weight || !out || !stem_shape_ok(B, Cin, H, W, Cout, k, stride, pad) || (!mean != !inv_std) ||
-        ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15)))
+        ((uintptr_t)out & 15))
         return OSSID_EINVAL;
     StemArgs a{};
     a.img = img_nchw, a.w = weight, a.bias = bias, a.mean = mean, a.inv_std = inv_std, a.out = out;

@@ -459,9 +459,10 @@ class FusedHead:
             t2 = self.tc2(self.tc1(template_feat)[:, :, 1:-1, 1:-1])[:, :, 1:-1, 1:-1].contiguous()      # 7 -> 5 -> 3
         else:
             t2 = corr._cab(corr.c2, corr.n2, corr._cab(corr.c1, corr.n1, template_feat)).contiguous()
-        avg = F.avg_pool2d(template_feat, 7)
+        avg = ops.spatial_mean(template_feat) if tuple(template_feat.shape[2:]) == (7, 7) else F.avg_pool2d(template_feat, 7)
         a2 = avg.reshape(avg.shape[0], avg.shape[1]).float().contiguous()
-        csub = (a2 @ self.sub_wsum()).contiguous()            # [n_t, 9*256]: conv_sub's response to the constant image a_t
+        # [n_t, 9*256]: conv_sub's response to the constant image a_t
+        csub = ops.small_matmul(a2, self.sub_wsum()) if a2.is_cuda else (a2 @ self.sub_wsum()).contiguous()
         return [t2, avg, a2, csub]
 
     def correlation(self, image_feat, template_feat, side=None, frame=None, decoder=True):
@@ -524,7 +525,8 @@ class FusedHead:
         else:
             x = torch.cat([self.dot(image_feat * avg), self.sub(image_feat - avg), self.dot3(dot3x3)], dim=1)
         x2 = self.cf(x)
-        heat_map = torch.sigmoid(corr.corr_conv_heatmap(x2))
+        heat_map = ops.conv1x1_c1(x2, corr.corr_conv_heatmap, sigmoid=True) if x2.is_cuda else \
+            torch.sigmoid(corr.corr_conv_heatmap(x2))
         return x2, heat_map, (self.decoder(x2) if decoder else None)
 
     def decoder(self, x2):
@@ -652,7 +654,8 @@ class FusedBackbone:
                     c += mod.growth
                 x = buf
             else:
-                x = mod.pool(packed(x))
+                st = mod.pool.stride if isinstance(mod.pool.stride, int) else mod.pool.stride[0]
+                x = ops.avgpool2_nhwc(packed(x), st)
         return self.final(x)
 
 
@@ -930,7 +933,7 @@ class Network(nn.Module):
         for conv, bn in ((corr.c1, corr.n1), (corr.c2, corr.n2)):
             t2 = T.bn_act_train(T.fused_conv(t2, conv, act_elu=True)[:, :, 1:-1, 1:-1], bn)
         dot3x3 = ops.dw_xcorr(feat, t2)
-        avg = F.avg_pool2d(local, 7)
+        avg = ops.spatial_mean(local)                        # F.avg_pool2d(local, 7) on the 7x7 template features
         par = self._branches_on(feat.device)
         if par:
             (p1, s_a) = self._fork(0, [feat, avg], lambda: cab(feat - avg, corr.corr_conv_sub, corr.norm_corr_sub))
@@ -956,7 +959,7 @@ class Network(nn.Module):
             (cls_raw, s_a) = self._fork(0, [u2, s2, t2_], lambda: trunk(self.classification))
             (reg_raw, s_b) = self._fork(1, [u2, s2, t2_], lambda: trunk(self.regression))
         x2 = T.AffineAct.apply(u2, s2, t2_, False)                          # materialised once, for the 1-channel heat conv
-        heat_map = torch.sigmoid(corr.corr_conv_heatmap(x2))
+        heat_map = torch.sigmoid(T.conv1x1_c1(x2, corr.corr_conv_heatmap))
         u, sc, sh = cab(u2, corr.s1, corr.ns1, pre=(s2, t2_))
         for i in (2, 3, 4):
             u, sc, sh = cab(u, getattr(corr, "s%d" % i), getattr(corr, "ns%d" % i), pre=(sc, sh),

@@ -145,6 +145,80 @@ def im2col_stem(img, k, stride, pad, kpad, normalize=False, out=None):
     return out
 
 
+def conv1x1_c1(x, conv, sigmoid=False):
+    """nn.Conv2d(C, 1, 1) (`corr_conv_heatmap`, network.py:334) on a channels-last x [B,C,H,W] -> [B,1,H,W], no autograd,
+    optionally through the sigmoid that follows it (network.py:349): one deterministic pass (ossid_conv1x1_c1_fwd)."""
+    _lib.require_cuda(x)
+    B, C, H, W = x.shape
+    x = x.float().contiguous(memory_format=torch.channels_last)
+    w = conv.weight.detach().float().reshape(-1).contiguous()
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    with _lib.on_device(x.device):
+        _lib.check(_lib.fn("ossid_conv1x1_c1_fwd")(x.data_ptr(), B * H * W, C, w.data_ptr(),
+                                                   None if conv.bias is None else conv.bias.detach().data_ptr(), 1 if sigmoid else 0,
+                                                   out.data_ptr(), _lib.stream()), "ossid_conv1x1_c1_fwd")
+    return out
+
+
+class SpatialMean(torch.autograd.Function):
+    """F.avg_pool2d(x, (H, W)) of a [B,C,H,W] tensor in either memory format -> [B,C,1,1] (network.py:343: the average of the
+    7x7 template features), ossid_spatial_mean forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C, H, W = x.shape
+        cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+        if not cl:
+            x = x.contiguous()
+        x = x.float()
+        out = torch.empty((B, C, 1, 1), dtype=torch.float32, device=x.device)
+        with _lib.on_device(x.device):
+            _lib.check(_lib.fn("ossid_spatial_mean")(x.data_ptr(), B, H * W, C, 1 if cl else 0, 0, out.data_ptr(), _lib.stream()),
+                       "ossid_spatial_mean")
+        ctx.cfg = (B, C, H, W, cl)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W, cl = ctx.cfg
+        g = g.float().contiguous()
+        dx = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device,
+                         memory_format=torch.channels_last if cl else torch.contiguous_format)
+        with _lib.on_device(g.device):
+            _lib.check(_lib.fn("ossid_spatial_mean")(g.data_ptr(), B, H * W, C, 1 if cl else 0, 1, dx.data_ptr(), _lib.stream()),
+                       "ossid_spatial_mean")
+        return dx
+
+
+def spatial_mean(x):
+    """F.avg_pool2d(x, full window) on the GPU through SpatialMean; torch on the CPU."""
+    if not x.is_cuda:
+        return torch.nn.functional.avg_pool2d(x, (x.shape[2], x.shape[3]))
+    return SpatialMean.apply(x)
+
+
+def small_matmul(a, b):
+    """a [M,K] @ b [K,N] for a handful of rows, no autograd (ossid_small_matmul: no library GEMM on the per-object path)."""
+    _lib.require_cuda(a, b)
+    a, b = a.float().contiguous(), b.float().contiguous()
+    M, K = a.shape
+    N = b.shape[1]
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with _lib.on_device(a.device):
+        _lib.check(_lib.fn("ossid_small_matmul")(a.data_ptr(), b.data_ptr(), M, K, N, out.data_ptr(), _lib.stream()), "ossid_small_matmul")
+    return out
+
+
+def avgpool2_nhwc(x, stride):
+    """nn.AvgPool2d(2, stride) on a channels-last tensor, no autograd (DenseNet transitions at test time)."""
+    B, C, H, W = x.shape
+    Ho, Wo = (H - 2) // stride + 1, (W - 2) // stride + 1
+    out = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with _lib.on_device(x.device):
+        _lib.check(_lib.fn("ossid_avgpool2_nhwc")(x.data_ptr(), B, H, W, C, stride, out.data_ptr(), 0, _lib.stream()), "ossid_avgpool2_nhwc")
+    return out
+
+
 def _imnorm(device):
     key = str(device)
     if key not in _IMNORM:

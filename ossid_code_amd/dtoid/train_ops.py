@@ -1110,6 +1110,46 @@ def conv3x3_c1(x, conv):
     return Conv3x3C1.apply(x, conv.weight, conv.bias)
 
 
+class Conv1x1C1(torch.autograd.Function):
+    """nn.Conv2d(C, 1, 1) on a channels-last x [B,C,H,W] -> [B,1,H,W] (`corr_conv_heatmap` 512 -> 1, network.py:334, :349) on the
+    deterministic vector-ALU kernels ossid_conv1x1_c1_fwd / _bwd: MIOpen's implicit-GEMM kernels for this one-row layer were
+    the last library convolutions of the step (forward, data and weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = nhwc(x)
+        B, C, H, W = x.shape
+        wf = w.detach().reshape(-1).contiguous()
+        out = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+        with _lib.on_device(x.device):
+            _lib.check(_lib.fn("ossid_conv1x1_c1_fwd")(x.data_ptr(), B * H * W, C, wf.data_ptr(), _p(None if bias is None else bias.detach()),
+                                                       0, out.data_ptr(), _lib.stream()), "ossid_conv1x1_c1_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dev = x.device
+        rows = B * H * W
+        g = g.float().contiguous()
+        wf = w.detach().reshape(-1).contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws = _scratch("c1x1_bwd", _lib.fn("ossid_conv1x1_c1_bwd_workspace_floats")(rows, C) * 4, dev)
+        dwb = torch.empty(C + 1, dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            _lib.check(_lib.fn("ossid_conv1x1_c1_bwd")(x.data_ptr(), g.data_ptr(), rows, C, wf.data_ptr(), ws.data_ptr(), _p(dx),
+                                                       dwb.data_ptr(), _lib.stream()), "ossid_conv1x1_c1_bwd")
+        return dx, dwb[:C].reshape(w.shape), (dwb[C:] if ctx.has_bias else None)
+
+
+def conv1x1_c1(x, conv):
+    """Apply an nn.Conv2d(C, 1, 1) through Conv1x1C1."""
+    return Conv1x1C1.apply(x, conv.weight, conv.bias)
+
+
 def bn_act_train(x, bn, relu=False):
     """Training-mode BatchNorm (+ReLU) with a materialised output, on this repo's passes: column sums -> fold -> apply."""
     B, C, H, W = x.shape
