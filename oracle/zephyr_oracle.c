@@ -405,6 +405,7 @@ static void ball_query(const float* xyz, int stride, int n, const float* cen, in
     }
 }
 
+#define SBLK 64
 static const int CANON[8] = {0, 4, 1, 5, 2, 6, 3, 7};
 
 /* y[o] = relu?( b[o] + sum_k W[o][k] x[k] ), canonical fmaf chain; W is [cout][kpad], kpad % 8 == 0 */
@@ -418,11 +419,78 @@ static inline void dense(const float* W, const float* b, int kpad, int cout, con
     }
 }
 
+/* EXPERIMENT ONLY (tools/six_product_emulation.py): product mode 2 emulates on the CPU the arithmetic a
+ * six-product split-bf16 form of SA1 / SA2 would have on the matrix cores -- x = p0 + p1 + p2 with bf16 pieces (24
+ * significant bits), the six products with i + j <= 2, every v_mfma_f32_32x32x16_bf16 modelled as "the exact dot product
+ * of one 16-deep slice, added to the f32 accumulator with one rounding", smallest terms first -- to measure whether the
+ * hypothesis rank order would survive it. Mode 0 (default) is SPEC.md's fmaf chain, the only arithmetic the product and
+ * every parity test use. */
+static int g_product_mode = 0;
+int ozr_set_product_mode(int mode) {
+    g_product_mode = mode;
+    return OZR_OK;
+}
+static inline float bf16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    float y;
+    memcpy(&y, &u, 4);
+    return y;
+}
+static inline void split3(float x, float* p0, float* p1, float* p2) {
+    *p0 = bf16_rne(x);
+    float r = x - *p0;
+    *p1 = bf16_rne(r);
+    r -= *p1;
+    *p2 = bf16_rne(r);
+}
+static const int SIX_I[6] = {2, 0, 1, 1, 0, 0}, SIX_J[6] = {0, 2, 1, 0, 1, 0}; /* smallest terms first */
+
+/* mode-2 form of dense_block: acc[s] continues from acc0[s] (NULL: the bias) over input channels [k0, k1) of W's rows */
+static void dense_block_six(const float* W, const float* b, int kpad, int cout, const float* xs, float* ys, int S, int relu,
+                            const float* acc0, int k0, int k1, int finish) {
+    const int K = k1 - k0, K16 = (K + 15) / 16 * 16;
+    float* xp = (float*)calloc((size_t)3 * K16 * S, sizeof(float));
+    float* wp = (float*)calloc((size_t)3 * K16, sizeof(float));
+    for (int k = 0; k < K; ++k)
+        for (int s = 0; s < S; ++s)
+            split3(xs[(size_t)(k0 + k) * S + s], xp + ((size_t)0 * K16 + k) * S + s, xp + ((size_t)1 * K16 + k) * S + s,
+                   xp + ((size_t)2 * K16 + k) * S + s);
+    for (int o = 0; o < cout; ++o) {
+        const float* w = W + (size_t)o * kpad + k0;
+        for (int k = 0; k < K; ++k) split3(w[k], wp + k, wp + K16 + k, wp + 2 * K16 + k);
+        float acc[SBLK];
+        for (int s = 0; s < S; ++s) acc[s] = acc0 ? acc0[(size_t)o * S + s] : b[o];
+        for (int sl = 0; sl < K16; sl += 16)
+            for (int t = 0; t < 6; ++t) {
+                const float* wi = wp + (size_t)SIX_I[t] * K16 + sl;
+                const float* xj = xp + ((size_t)SIX_J[t] * K16 + sl) * S;
+                double d[SBLK];
+                for (int s = 0; s < S; ++s) d[s] = 0.0;
+                for (int k = 0; k < 16; ++k) {
+                    const double wk = (double)wi[k];
+                    const float* xk = xj + (size_t)k * S;
+                    for (int s = 0; s < S; ++s) d[s] += wk * (double)xk[s];
+                }
+                for (int s = 0; s < S; ++s) acc[s] = (float)((double)acc[s] + d[s]);
+            }
+        float* yo = ys + (size_t)o * S;
+        for (int s = 0; s < S; ++s) yo[s] = (relu && finish) ? fmaxf(acc[s], 0.0f) : acc[s];
+    }
+    free(xp);
+    free(wp);
+}
+
 /* same layer over a block of S samples held channel-major xs[k][S]; the inner loop runs over
  * samples so the compiler can vectorise while every sample keeps its own exact fmaf chain. */
-#define SBLK 64
+#define SBLK_IS_DEFINED_ABOVE 1
 static void dense_block(const float* W, const float* b, int kpad, int cout, const float* xs, float* ys, int S,
                         int relu) {
+    if (g_product_mode == 2 && kpad <= 136) {          /* SA1 / SA2 layers only (kpad 8, 64, 128, 136) */
+        dense_block_six(W, b, kpad, cout, xs, ys, S, relu, NULL, 0, kpad, 1);
+        return;
+    }
     for (int o = 0; o < cout; ++o) {
         const float* w = W + (size_t)o * kpad;
         float acc[SBLK];
@@ -517,6 +585,16 @@ int ozr_pn2_score(const float* point_x, int B, int M, const ozr_pn2* P, float* s
             for (int j = 0; j < np2; ++j)
                 for (int c = 0; c < 3; ++c) xyz2[3 * j + c] = xyz1[3 * fps2[j] + c];
             ball_query(xyz1, 3, np1, xyz2, np2, P->radius2, ns2, ball2);
+            if (g_product_mode == 2) {                 /* experiment: the per-point part of SA2 L1 on six products */
+                for (int i0 = 0; i0 < np1; i0 += SBLK) {
+                    const int S = (np1 - i0) < SBLK ? (np1 - i0) : SBLK;
+                    for (int s = 0; s < S; ++s)
+                        for (int c = 0; c < 128; ++c) bufa[(size_t)c * S + s] = feat1[(size_t)(i0 + s) * 128 + c];
+                    dense_block_six(P->W[3], P->b[3], 136, 128, bufa, bufb, S, 0, NULL, 0, 128, 0);
+                    for (int s = 0; s < S; ++s)
+                        for (int o = 0; o < 128; ++o) p2[(size_t)(i0 + s) * 128 + o] = bufb[(size_t)o * S + s];
+                }
+            } else
             for (int i = 0; i < np1; ++i) {
                 const float* g = feat1 + (size_t)i * 128;
                 for (int o = 0; o < 128; ++o) {
@@ -528,6 +606,18 @@ int ozr_pn2_score(const float* point_x, int B, int M, const ozr_pn2* P, float* s
                 }
             }
             for (int j = 0; j < np2; ++j) {
+                if (g_product_mode == 2) {             /* experiment: continue every sample's chain with its offset slice */
+                    float* xo = bufb;                  /* [8][ns2] offsets (dx,dy,dz,0..), acc0 [128][ns2] behind it */
+                    float* a0 = bufb + 8 * ns2;
+                    for (int s = 0; s < ns2; ++s) {
+                        int i = ball2[(size_t)j * ns2 + s];
+                        for (int c = 0; c < 3; ++c) xo[(size_t)c * ns2 + s] = xyz1[3 * i + c] - xyz2[3 * j + c];
+                        for (int c = 3; c < 8; ++c) xo[(size_t)c * ns2 + s] = 0.0f;
+                        for (int o = 0; o < 128; ++o) a0[(size_t)o * ns2 + s] = p2[(size_t)i * 128 + o];
+                    }
+                    /* W rows are [136]: the offset block sits at columns 128..135; xs is indexed from k0 */
+                    dense_block_six(P->W[3], P->b[3], 136, 128, xo - (size_t)128 * ns2, bufa, ns2, 1, a0, 128, 136, 1);
+                } else
                 for (int s = 0; s < ns2; ++s) {
                     int i = ball2[(size_t)j * ns2 + s];
                     float dx = xyz1[3 * i] - xyz2[3 * j], dy = xyz1[3 * i + 1] - xyz2[3 * j + 1],

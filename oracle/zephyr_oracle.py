@@ -50,6 +50,12 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def set_product_mode(mode):
+    """0 = SPEC.md's fmaf chains (the oracle); 2 = EXPERIMENT: emulate six-product split-bf16 arithmetic in SA1 / SA2
+    (tools/six_product_emulation.py only; no parity test and no product code path uses it)."""
+    return lib().ozr_set_product_mode(C.c_int(int(mode)))
+
+
 def set_threads(n):
     return lib().ozr_set_threads(C.c_int(int(n)))
 

@@ -11,6 +11,12 @@ static inline int ossid_launch_status() {
     return e == hipSuccess ? OSSID_OK : OSSID_ELAUNCH;
 }
 
+// csrc/wgrad_fc.hip: the decoder's few-channel 3x3 weight gradients from 2-D pixel tiles (internal: reached through
+// ossid_conv_wgrad / ossid_conv_wgrad_workspace_bytes of csrc/train.hip)
+bool ossid_wgrad_fewch_takes(int Cin, int Cout, int taps, int in_cs, int dy_cs);
+size_t ossid_wgrad_fewch_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int ossid_wgrad_fewch(const ossid_wgrad_desc* d, void* stream);
+
 // Kernels that declare more dynamic LDS than the default limit need hipFuncAttributeMaxDynamicSharedMemorySize. It is a
 // property of the FUNCTION, not of a launch: raise it to the hardware maximum ONCE per (function, device), the first
 // time the function is launched (always a warm-up pass, never inside a stream capture), instead of before every launch.

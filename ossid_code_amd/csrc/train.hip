@@ -1431,10 +1431,19 @@ int ossid_conv_pack_weights_dgrad(const float* w, int Cout, int Cin, int taps, f
     return ossid_conv_pack_weights_form(w, Cout, Cin, taps, 1, 0, wpk, stream);
 }
 
+#ifndef OSSID_WGRAD_FEWCH
+#define OSSID_WGRAD_FEWCH 1      // the decoder's few-channel 3x3 layers on csrc/wgrad_fc.hip (0: the general kernel, for A/B runs)
+#endif
+
 size_t ossid_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps) {
     WgradPlan p;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !wgrad_plan(B, H, W, Cin, Cout, taps, p)) return 0;
-    return (size_t)p.nsplit * p.wk * taps * Cout * Cin * sizeof(float);
+    size_t n = (size_t)p.nsplit * p.wk * taps * Cout * Cin * sizeof(float);
+    if (OSSID_WGRAD_FEWCH && ossid_wgrad_fewch_takes(Cin, Cout, taps, Cin, Cout)) {
+        const size_t m = ossid_wgrad_fewch_workspace_bytes(B, H, W, Cin, Cout);
+        if (m > n) n = m;
+    }
+    return n;
 }
 
 int ossid_conv_wgrad_split_bf16(void) { return OSSID_WGRAD_SB; }
@@ -1444,6 +1453,11 @@ int ossid_conv_wgrad(const ossid_wgrad_desc* d, void* stream) {
     const int B = d->batch, H = d->height, W = d->width, Cin = d->cin, Cout = d->cout, taps = d->taps;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 4) || (Cout % 4)) return OSSID_EINVAL;
     if (!d->x || !d->dy || !d->dw || !d->workspace || (d->pre_scale && !d->pre_shift)) return OSSID_EINVAL;
+    if (OSSID_WGRAD_FEWCH && ossid_wgrad_fewch_takes(Cin, Cout, taps, d->in_channel_stride > 0 ? d->in_channel_stride : Cin,
+                                                     d->dy_channel_stride > 0 ? d->dy_channel_stride : Cout) &&
+        d->workspace_bytes >= ossid_wgrad_fewch_workspace_bytes(B, H, W, Cin, Cout) && !((uintptr_t)d->x & 15) &&
+        !((uintptr_t)d->dy & 15) && !((uintptr_t)d->workspace & 15))
+        return ossid_wgrad_fewch(d, stream);                 // 2-D pixel tiles, every tap from one staged patch (csrc/wgrad_fc.hip)
     WgradPlan p;
     if (!wgrad_plan(B, H, W, Cin, Cout, taps, p)) return OSSID_EINVAL;
     if (d->workspace_bytes < (size_t)p.nsplit * p.wk * taps * Cout * Cin * sizeof(float)) return OSSID_EINVAL;

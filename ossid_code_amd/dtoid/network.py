@@ -804,18 +804,22 @@ class Network(nn.Module):
         # every conv weight -> MFMA layouts, one launch (0.64 ms: 136 MB read, 272 MB written). Nothing needs it before the
         # first dense block and the template encoders, so with side streams on it runs on the weight-gradient stream (idle
         # at the start of a step: the previous step's weight gradients were joined before its optimizer ran) beside the stem
-        pack_event = None
+        # In two launches: the backbone's and the encoders' weights (7 of the 34 M) first, with an event of their own -- the stem
+        # on this repo's kernels takes 0.5 ms, not the 1.5 ms that used to cover the whole packing -- then the head's.
+        pack_event = pack_event_all = None
         if self._branches_on(image.device):
             main = torch.cuda.current_stream(image.device)
             ps = T.side_streams(image.device)["wgrad"]
             ps.wait_stream(main)                                 # behind the optimizer step that wrote the weights
             with torch.cuda.stream(ps):
-                self._train_pack_plan().run()
-            pack_event = torch.cuda.Event()
-            pack_event.record(ps)
+                pack_event = self._train_pack_plan().run(want_first_event=True)
+            pack_event_all = torch.cuda.Event()
+            pack_event_all.record(ps)
+            if pack_event is None:
+                pack_event = pack_event_all
         else:
             self._train_pack_plan().run()
-        self.__dict__["_pack_event"] = pack_event
+        self.__dict__["_pack_event"] = pack_event                # what a fork waits for (the encoders: the first part)
         seq = list(ife.backdense_1) + list(ife.backdense_2)      # norm0 relu0 pool0 block1 | trans1 block2 ... norm5
         if self.use_hip_stem_training:
             # stem on this repo's kernels, channels-last from the first one
@@ -856,6 +860,9 @@ class Network(nn.Module):
         feat = T.AffineAct.apply(u, s, t, False)                             # n1(elu(c1(norm5(.)))), [B,640,29,39]: one pass
         if join_local is not None:
             self._join(join_local, [local])
+        if pack_event_all is not None:                           # the head's weights: packed long since
+            torch.cuda.current_stream(image.device).wait_event(pack_event_all)
+            self.__dict__["_pack_event"] = pack_event_all
         out = self._head_train_hip(feat, local)
         # the folded BatchNorms update running_mean / running_var in their kernel; the counters in one launch
         ts = self.__dict__.get("_folded_bn_counters")
@@ -879,13 +886,15 @@ class Network(nn.Module):
                     convs += [layer.conv1, layer.conv2]
             elif isinstance(m, Transition):
                 convs.append(m.conv)
-        convs += [ife.c1, corr.c1, corr.c2, corr.corr_conv_dot, corr.corr_conv_sub, corr.corr_conv_dot3x3, corr.cf] + \
-            [getattr(corr, "s%d" % i) for i in (1, 2, 3, 4, 5)]
-        for mod in (self.classification, self.regression):
-            convs += [getattr(mod, "conv%d" % i) for i in (1, 2, 3, 4)] + [mod.output]
+        convs.append(ife.c1)
         if self.use_hip_template_training:
             from .train_encoders import encoder_convs
             convs += encoder_convs(self.template_feature_extractor_global) + encoder_convs(self.template_feature_extractor)
+        n_first = len(convs)                                     # packed by the first launch: everything in front of the head
+        convs += [corr.c1, corr.c2, corr.corr_conv_dot, corr.corr_conv_sub, corr.corr_conv_dot3x3, corr.cf] + \
+            [getattr(corr, "s%d" % i) for i in (1, 2, 3, 4, 5)]
+        for mod in (self.classification, self.regression):
+            convs += [getattr(mod, "conv%d" % i) for i in (1, 2, 3, 4)] + [mod.output]
         plan = self.__dict__.get("_pack_plan")
         if plan is None or not plan.valid_for(convs):
             # which layouts the step asks for at finetune batch sizes (train_ops.wino_fits): the head's plain 3x3 layers run
@@ -909,7 +918,7 @@ class Network(nn.Module):
                     for cv in encoder_convs(enc):
                         final = any(cv is getattr(enc, n, None) for n in ("final_conv_1", "final_conv_2"))
                         kinds[cv] = ("fwd_exact", "dgrad_exact") if final else (T.FWD_ENCODER, "dgrad")
-            plan = self.__dict__["_pack_plan"] = T.PackPlan(convs, kinds)
+            plan = self.__dict__["_pack_plan"] = T.PackPlan(convs, kinds, split_at=n_first)
         return plan
 
     def _head_train_hip(self, feat, local):

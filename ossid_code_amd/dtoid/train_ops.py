@@ -231,12 +231,18 @@ class PackPlan:
     of the forward pass instead of two small launches per layer. Built once per set of weight tensors (their addresses
     are stable: FlatParams views); `run()` marks them fresh so the per-layer _pack() calls only look the buffers up."""
 
-    def __init__(self, convs, kinds=None):
+    def __init__(self, convs, kinds=None, split_at=None):
         """kinds: optional {conv: tuple of layouts} -- which of ("fwd", "fwd_exact", "dgrad", "wino_fwd", "wino_dgrad") the step will ask
-        for (a layout left out is simply packed by its layer's own _pack() launch if it is asked for after all)."""
-        rows, keys, first = [], [], 0
-        self.bufs, self.buf_ptr = [], {}       # strong references: the table below holds raw addresses of these buffers
-        for conv in convs:
+        for (a layout left out is simply packed by its layer's own _pack() launch if it is asked for after all).
+        split_at: the first `split_at` convolutions are packed by a launch of their own, in front of the rest (run() can
+        hand back an event between the two: what the step needs first -- the backbone, 7 of the 34 M weights -- is ready
+        after a fifth of the packing time)."""
+        rows, keys = [], []
+        self.bufs, self.buf_ptr = [], {}       # strong references: the tables below hold raw addresses of these buffers
+        parts = [[], []]
+        firsts = [0, 0]
+        for ci, conv in enumerate(convs):
+            part = 0 if (split_at is None or ci < split_at) else 1
             w = conv.weight.detach()
             cout, cin, taps = int(w.shape[0]), int(w.shape[1]), int(w.shape[2] * w.shape[3])
             for kind in (("fwd", "dgrad") if kinds is None else kinds.get(conv, ("fwd", "dgrad"))):
@@ -249,19 +255,22 @@ class PackPlan:
                 if kind == "wino_dgrad" and not (USE_WINO and taps == 9 and cout % 16 == 0 and cin >= 64):
                     continue
                 buf = _Packed.get(w, kind)
-                rows.append((w.data_ptr(), buf.data_ptr(), first, cout, cin, taps,
-                             {"fwd": 0, "dgrad": 1, "wino_fwd": 2, "wino_dgrad": 3, "fwd_exact": 4, "dgrad_exact": 5, "fwd_x6": 6}[kind]))
+                parts[part].append((w.data_ptr(), buf.data_ptr(), firsts[part], cout, cin, taps,
+                                    {"fwd": 0, "dgrad": 1, "wino_fwd": 2, "wino_dgrad": 3, "fwd_exact": 4, "dgrad_exact": 5, "fwd_x6": 6}[kind]))
                 keys.append((w.data_ptr(), tuple(w.shape), kind))
                 self.bufs.append(buf)
                 self.buf_ptr[keys[-1]] = buf.data_ptr()
-                first += (buf.numel() // 4 + 255) // 256
-        arr = (_lib.PackRow * len(rows))()
-        for i, r in enumerate(rows):
-            arr[i].w, arr[i].wpk, arr[i].first_block, arr[i].cout, arr[i].cin, arr[i].taps, arr[i].kind = r
-        raw = bytes(arr)
+                firsts[part] += (buf.numel() // 4 + 255) // 256
         self.device = convs[0].weight.device
-        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
-        self.n_rows, self.total_blocks, self.keys = len(rows), first, keys
+        self.tables = []                       # (device table, rows, blocks) per launch
+        for rows, blocks in zip(parts, firsts):
+            if not rows:
+                continue
+            arr = (_lib.PackRow * len(rows))()
+            for i, r in enumerate(rows):
+                arr[i].w, arr[i].wpk, arr[i].first_block, arr[i].cout, arr[i].cin, arr[i].taps, arr[i].kind = r
+            self.tables.append((torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(rows), blocks))
+        self.keys = keys
         self.weights = [c.weight for c in convs]
         self.sig = tuple(w.data_ptr() for w in self.weights)
         self.fresh = {}
@@ -272,15 +281,23 @@ class PackPlan:
             return False
         return all(_Packed._cache.get(k) is b for k, b in zip(self.keys, self.bufs))
 
-    def run(self):
+    def run(self, want_first_event=False):
+        """Enqueue the packing launches on the current stream. want_first_event: return a torch.cuda.Event recorded behind
+        the first launch (the `split_at` part), else None."""
+        ev = None
         with _lib.on_device(self.device):
-            rc = _lib.fn("ossid_conv_pack_weights_table")(self.table.data_ptr(), self.n_rows, self.total_blocks, _lib.stream())
-        _lib.check(rc, "ossid_conv_pack_weights_table")
+            for i, (table, n_rows, blocks) in enumerate(self.tables):
+                rc = _lib.fn("ossid_conv_pack_weights_table")(table.data_ptr(), n_rows, blocks, _lib.stream())
+                _lib.check(rc, "ossid_conv_pack_weights_table")
+                if i == 0 and want_first_event and len(self.tables) > 1:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.device))
         global _ACTIVE_PLAN
         import weakref
         vers = {w.data_ptr(): w._version for w in self.weights}
         self.fresh = {k: vers[k[0]] for k in self.keys}
         _ACTIVE_PLAN = weakref.ref(self)
+        return ev
 
 
 def end_step():

@@ -80,6 +80,9 @@ def test_chan_op_sums_only_and_strided_sum_table(hiplib):
     (8, 16, 64, 30, 30, 9, 0, 0, False, None),
     (8, 48, 192, 7, 7, 1, 0, 0, False, None),
     (2, 160, 64, 24, 32, 1, 0, 0, False, None),        # the 7x7 stem as a 1x1 conv on im2col rows
+    (2, 32, 16, 61, 77, 9, 0, 0, True, (29, 37)),      # csrc/wgrad_fc.hip: ragged 4 x 32 pixel tiles, non-integer up-sampling
+    (3, 64, 32, 10, 70, 9, 0, 32, False, None),        # ... plain input, dy a channel slice of a wider buffer
+    (1, 32, 16, 3, 5, 9, 32, 0, True, None),           # ... smaller than one tile, x a channel prefix
 ])
 def test_wgrad_matches_torch(hiplib, B, Cin, Cout, H, W, taps, in_extra, dy_extra, pre, up):
     g = torch.Generator().manual_seed(Cin + Cout + H)

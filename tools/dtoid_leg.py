@@ -1,8 +1,8 @@
 """Runs exactly `--calls` calls of ONE DTOID bench leg (the shapes of bench.py's dtoid object), eagerly, for profiling:
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out/f -- python3 tools/dtoid_leg.py --leg forward --calls 3
 legs: forward (1 image x 21 templates), forward_batch (32 x 21), forward_pairs (32 pairs), finetune (batch 8 step).
-The template cache is filled and every plan recorded by ONE untimed call first; tools/pmc_dtoid_traffic.py divides by calls + 1
-for the legs whose first call does the same work, and says so."""
+The first call fills the template cache, packs the weights and records every launch plan; a marker launch (torch.cuda._sleep's
+spin kernel) in front of every call lets tools/pmc_dtoid_traffic.py take the LAST call alone."""
 import argparse
 import os
 import sys
@@ -61,7 +61,9 @@ def main():
         m.train()
         fn = lambda: finetune.finetune_step(m, batch, opt)                            # noqa: E731
     for _ in range(a.calls + 1):
+        torch.cuda._sleep(1000)                      # marker launch (spin kernel): tools/pmc_dtoid_traffic.py cuts the run at these
         fn()
+    torch.cuda._sleep(1000)
     torch.cuda.synchronize()
     print("done", a.leg, a.calls + 1)
 
