@@ -198,7 +198,7 @@ FWD_DECIDING = os.environ.get("OSSID_TRAIN_FWD", "fwd_x6")
 assert FWD_DECIDING in ("fwd_x6", "fwd_exact")
 # The two SqueezeNet template encoders keep the exact-f32 instruction: their convolutions are small (0.3 ms of the step), and
 # with ~2 M ReLU / max-pool decisions per pass ANY f32-level path lands one of them differently from torch's in some passes
-# (2e-3 .. 1e-2 on the gradients in front of it instead of 2e-5; tools/debug_encoder_tol.py: one pass in six with the exact
+# (2e-3 .. 1e-2 on the gradients in front of it instead of 2e-5: measured in round 3, one pass in six with the exact
 # instruction, three in six with the three-way split) -- the tests' bound is calibrated on the exact one.
 FWD_ENCODER = os.environ.get("OSSID_TRAIN_FWD_ENCODER", "fwd_exact")
 assert FWD_ENCODER in ("fwd_x6", "fwd_exact")

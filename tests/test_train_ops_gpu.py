@@ -251,29 +251,47 @@ def test_dense_block_training_path_matches_module_path(hiplib, L, C0, B, H, W, r
                 m.bias.normal_(0, 0.2)
     import copy
     ref = copy.deepcopy(blk)
+    ref64 = copy.deepcopy(blk).double().cpu()            # the anchor: the same module in float64 on the CPU
+
+    def module_path(mod, xx, g):
+        xr = xx.clone().requires_grad_(True)
+        feats = [xr]
+        for layer in mod.values():
+            feats.append(layer(torch.cat(feats, 1)))
+        yr = torch.cat(feats, 1)
+        yr.backward(g)
+        return yr, xr.grad
+
+    def l2(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float((a - b).norm() / b.norm().clamp(min=1e-30))
     for rnd in range(3):
         x = torch.randn(B, C0, H, W, device="cuda") * (1 + rnd)
         go = torch.randn(B, C0 + 32 * L, H, W, device="cuda")
-        for mod in (blk, ref):
+        for mod in (blk, ref, ref64):
             for p in mod.parameters():
                 p.grad = None
-        xr = x.clone().requires_grad_(True)
-        feats = [xr]
-        for layer in ref.values():
-            feats.append(layer(torch.cat(feats, 1)))
-        yr = torch.cat(feats, 1)
-        yr.backward(go)
+        yr, xr_grad = module_path(ref, x, go)
+        y64, x64_grad = module_path(ref64, x.double().cpu(), go.double().cpu())
         xm = x.clone().requires_grad_(True)
         y = T.dense_block_train(xm, blk)
         y.backward(go)
         assert rel(y, yr) < 5e-5, rnd
-        # (max-norm on the input gradient would trip over a single ReLU decision flipped between two float32 paths)
-        assert float((xm.grad.double() - xr.grad.double()).norm() / xr.grad.double().norm()) < 2e-3, rnd
-        for (n, p), q in zip(blk.named_parameters(), ref.parameters()):
-            assert float((p.grad.double() - q.grad.double()).norm() / q.grad.double().norm()) < 5e-3, (rnd, n)
-        for (n, b), q in zip(blk.named_buffers(), ref.buffers()):
+        # against float64: this path (three-way-split forward: f32-level) must be as close as torch's own f32 path is, within 3x
+        # (max-norm for the output; the gradients in L2 -- a single ReLU decision flipped between two float32 paths moves single
+        # elements by O(1) in either path -- with the floor at what such a flip costs; what tools/debug_dense_sb.py used to print)
+        assert rel(y, y64) < max(2e-6, 3 * rel(yr, y64)), (rnd, rel(y, y64), rel(yr, y64))
+        # (floors = the split-bf16 allowance of the data / weight gradients, 5-7e-6 per product through L layers and sums over
+        # thousands of pixels with cancellation: measured 1e-3 on the input gradient and 2.1e-3 on a BatchNorm weight where
+        # torch's f32 path sits at 6e-7 of float64; the all-exact build holds 5e-4 / 1e-3, profiles/r03_split_vs_exact.txt)
+        assert l2(xm.grad, x64_grad) < max(2e-3, 3 * l2(xr_grad, x64_grad)), (rnd, l2(xm.grad, x64_grad), l2(xr_grad, x64_grad))
+        assert l2(xm.grad, xr_grad) < 2e-3, rnd
+        for (n, p), q, q64 in zip(blk.named_parameters(), ref.parameters(), ref64.parameters()):
+            assert l2(p.grad, q.grad) < 5e-3, (rnd, n)
+            assert l2(p.grad, q64.grad) < max(5e-3, 3 * l2(q.grad, q64.grad)), (rnd, n, l2(p.grad, q64.grad), l2(q.grad, q64.grad))
+        for (n, b), q, q64 in zip(blk.named_buffers(), ref.buffers(), ref64.buffers()):
             if b.dtype.is_floating_point:
-                assert rel(b, q) < 1e-4, (rnd, n)
+                assert rel(b, q) < 1e-4 and rel(b, q64) < 1e-4, (rnd, n)
     plans = blk.__dict__.get("_train_plans", {})
     if replay:
         (plan,) = plans.values()
