@@ -14,7 +14,10 @@
 // The column tiles are dealt to the four waves (each wave walks ALL pixels of the tile for its tiles: no cross-wave sums);
 // every operand is one conflict-free ds_read_b32. Persistent workgroups keep their accumulators over many tiles (the next
 // tile's loads in flight under this tile's MFMAs) and write ONE partial [Cout][Cin][9] slab each; a second kernel adds the
-// slabs in a fixed order (bit-reproducible). Exact f32: 22.6 / 21.3 GFLOP = 0.15 ms each of matrix pipe.
+// slabs in a fixed order (bit-reproducible). Exact f32: 22.6 / 21.3 GFLOP = 0.15 ms each of matrix pipe; measured 0.29 / 0.27 ms.
+// (Measured and NOT adopted: the same kernel at 128 -> 32 for the dense blocks' 3x3 layers, grouped per block -- 2.27 ms over the
+// four blocks against 1.64 ms for the split-bf16 grouped kernel of csrc/train.hip, tools/wgrad_group_bench.py: with 128 input
+// channels that kernel's staging is amortised over four column tiles per tap and the 3-product arithmetic wins.)
 #include "common.h"
 
 namespace {
@@ -29,10 +32,13 @@ struct FcArgs {
     float scale_h, scale_w;
 };
 
-constexpr int FC_TH = 4, FC_TW = 32, FC_PH = FC_TH + 2, FC_PW = FC_TW + 2;
+constexpr int FC_TW = 32, FC_PW = FC_TW + 2;
+constexpr int fc_th(int cin) { return cin >= 128 ? 2 : 4; }      // rows per tile: the patch must leave room for two workgroups per CU
 
+// workgroup `wg` of `nwg` that share the problem: tiles wg, wg + nwg, ...; one partial slab at index wg
 template <int COUT, int CIN>
-__global__ __launch_bounds__(256, 2) void wgrad_fewch_kernel(FcArgs a) {
+__device__ __forceinline__ void fewch_body(const FcArgs& a, const int wg, const int nwg) {
+    constexpr int FC_TH = fc_th(CIN), FC_PH = FC_TH + 2;
     constexpr bool SMALL = COUT == 16;                   // 16x16x4 tiles; else 32x32x2
     constexpr int TN = SMALL ? 16 : 32;                  // columns (input channels) per tile
     constexpr int NTILES = 9 * (CIN / TN);               // (tap, channel block) column tiles
@@ -69,17 +75,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_fewch_kernel(FcArgs a) {
         ps = make_float4(a.pre_scale[4 * xq], a.pre_scale[4 * xq + 1], a.pre_scale[4 * xq + 2], a.pre_scale[4 * xq + 3]);
         pt = make_float4(a.pre_shift[4 * xq], a.pre_shift[4 * xq + 1], a.pre_shift[4 * xq + 2], a.pre_shift[4 * xq + 3]);
     }
-    float4 sx[NX], sd[ND];
-    auto fetch = [&](int tile) {
+    // With 128 input channels the 17 staging registers of a prefetched patch do not fit beside the 144 accumulators: that
+    // shape stages at the top of its tile, in batches of NB loads (two workgroups per CU cover each other's loads instead).
+    constexpr bool PF = CIN < 128;
+    constexpr int NB = PF ? NX : 6;
+    float4 sx[NB], sd[ND];
+    auto fetch = [&](int tile, int e0) {                     // patch elements e0 .. e0 + NB - 1 (and, at e0 == 0, the dY tile)
         const int tx = tile % a.tiles_x, r1 = tile / a.tiles_x;
         const int b = r1 / a.tiles_y, oy0 = (r1 % a.tiles_y) * FC_TH, ox0 = tx * FC_TW;
 #pragma unroll
-        for (int e = 0; e < NX; ++e) {
+        for (int ee = 0; ee < NB; ++ee) {
+            const int e = e0 + ee;
             const int idx = (tid + e * 256) / X4;            // patch pixel
             const int py = idx / FC_PW, px = idx - py * FC_PW;
             const int yy = oy0 - 1 + py, xx = ox0 - 1 + px;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < FC_PH * FC_PW && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+            if (e < NX && idx < FC_PH * FC_PW && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
                 const int sy = (a.Hs == a.H) ? yy : min((int)floorf((float)yy * a.scale_h), a.Hs - 1);
                 const int sxx = (a.Ws == a.W) ? xx : min((int)floorf((float)xx * a.scale_w), a.Ws - 1);
                 v = *(const float4*)(a.x + ((size_t)(b * a.Hs + sy) * a.Ws + sxx) * a.in_cs + 4 * xq);
@@ -88,8 +99,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_fewch_kernel(FcArgs a) {
                     if (a.pre_relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
                 }
             }
-            sx[e] = v;
+            sx[ee] = v;
         }
+        if (e0 != 0) return;
 #pragma unroll
         for (int e = 0; e < ND; ++e) {
             const int idx = (tid + e * 256) / D4;            // tile pixel
@@ -100,17 +112,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_fewch_kernel(FcArgs a) {
             sd[e] = v;
         }
     };
-    if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        __syncthreads();                                     // the previous tile's readers are done
+    auto commit = [&](int e0) {
 #pragma unroll
-        for (int e = 0; e < NX; ++e)
-            if (tid + e * 256 < FC_PH * FC_PW * X4) xs4[tid + e * 256] = sx[e];
+        for (int ee = 0; ee < NB; ++ee)
+            if (e0 + ee < NX && tid + (e0 + ee) * 256 < FC_PH * FC_PW * X4) xs4[tid + (e0 + ee) * 256] = sx[ee];
+        if (e0 != 0) return;
 #pragma unroll
         for (int e = 0; e < ND; ++e)
             if (tid + e * 256 < FC_TH * FC_TW * D4) dys4[tid + e * 256] = sd[e];
+    };
+    if (PF && wg < a.ntiles) fetch(wg, 0);
+    for (int tile = wg; tile < a.ntiles; tile += nwg) {
+        __syncthreads();                                     // the previous tile's readers are done
+        if (PF) {
+            commit(0);
+        } else {
+#pragma unroll 1
+            for (int e0 = 0; e0 < NX; e0 += NB) {
+                fetch(tile, e0);
+                commit(e0);
+            }
+        }
         __syncthreads();
-        if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);      // in flight under this tile's MFMAs
+        if (PF && tile + nwg < a.ntiles) fetch(tile + nwg, 0);              // in flight under this tile's MFMAs
 #pragma unroll 1
         for (int r = 0; r < FC_TH; ++r) {
             const float* arow = dys + (r * FC_TW + kk) * COUT + n;          // A: dY[pixel KP j + kk][co n]
@@ -128,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fewch_kernel(FcArgs a) {
         }
     }
     // one partial slab per workgroup, [co][ci][tap] = the parameter's layout
-    float* slab = a.slabs + (size_t)blockIdx.x * (COUT * CIN * 9);
+    float* slab = a.slabs + (size_t)wg * (COUT * CIN * 9);
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         const int t = wave + 4 * i;
@@ -143,6 +167,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_fewch_kernel(FcArgs a) {
             for (int r = 0; r < 16; ++r) slab[((size_t)((r & 3) + 8 * (r >> 2) + 4 * kk) * CIN + ci) * 9 + tap] = acc32[i][r];
         }
     }
+}
+
+template <int COUT, int CIN>
+__global__ __launch_bounds__(256, 2) void wgrad_fewch_kernel(FcArgs a) {
+    fewch_body<COUT, CIN>(a, blockIdx.x, gridDim.x);
 }
 
 // dw[i] (+)= sum over slabs, fixed order: 32 outputs x 8 slab ranges per workgroup, 8 independent loads in flight per thread
@@ -196,7 +225,8 @@ bool ossid_wgrad_fewch_takes(int Cin, int Cout, int taps, int in_cs, int dy_cs) 
 }
 
 size_t ossid_wgrad_fewch_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
-    const long long nt = (long long)B * ((H + FC_TH - 1) / FC_TH) * ((W + FC_TW - 1) / FC_TW);
+    const int th = fc_th(Cin);
+    const long long nt = (long long)B * ((H + th - 1) / th) * ((W + FC_TW - 1) / FC_TW);
     if (nt <= 0 || nt > 0x7fffffff) return 0;
     const int grid = Cout == 16 ? fc_grid(wgrad_fewch_kernel<16, 32>, (int)nt, &g_grid_16_32)
                                 : fc_grid(wgrad_fewch_kernel<32, 64>, (int)nt, &g_grid_32_64);
@@ -216,7 +246,7 @@ int ossid_wgrad_fewch(const ossid_wgrad_desc* d, void* stream) {
         return OSSID_EINVAL;
     a.pre_relu = d->pre_relu;
     a.scale_h = (float)a.Hs / (float)H, a.scale_w = (float)a.Ws / (float)W;
-    a.tiles_y = (H + FC_TH - 1) / FC_TH, a.tiles_x = (W + FC_TW - 1) / FC_TW;
+    a.tiles_y = (H + fc_th(Cin) - 1) / fc_th(Cin), a.tiles_x = (W + FC_TW - 1) / FC_TW;
     const long long nt = (long long)B * a.tiles_y * a.tiles_x;
     if (nt > 0x7fffffff) return OSSID_EINVAL;
     a.ntiles = (int)nt;

@@ -544,3 +544,46 @@ def test_stem_tail_fused_modulation_batchnorm_relu_pool_matches_torch_autograd(h
     assert l2(xm.grad, xr.grad) < 1e-4, l2(xm.grad, xr.grad)
     assert l2(km.grad, kr.grad) < 1e-4 and l2(bn.weight.grad, rbn.weight.grad) < 1e-4 and l2(bn.bias.grad, rbn.bias.grad) < 1e-4
     assert rel(bn.running_mean, rbn.running_mean) < 1e-5 and rel(bn.running_var, rbn.running_var) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,L", [(2, 30, 40, 3), (1, 7, 9, 2), (8, 29, 39, 4)])
+def test_grouped_weight_gradients_of_a_dense_block_match_torch(hiplib, B, H, W, L):
+    """ossid_conv_wgrad_group on the 2 L problems of a dense block as DenseBlockTrain hands them over: the 3x3 layers (128 -> 32,
+    dy a 32-channel slice of the block's gradient buffer, BatchNorm + ReLU prologue) and the 1x1 layers (channel prefix of the
+    block buffer -> 128) in one call -- two tiling variants, one grouped launch each -- against float64 autograd; and
+    bit-reproducible."""
+    g = torch.Generator().manual_seed(B * 100 + H)
+    C0, Ct = 64, 64 + 32 * L
+    buf = torch.randn(B, Ct, H, W, generator=g)
+    G = torch.randn(B, Ct, H, W, generator=g)
+    items, want = [], []
+    bufd, Gd = cl(buf), cl(G)
+    for li in range(L):
+        c = C0 + 32 * li
+        y1 = torch.randn(B, 128, H, W, generator=g)
+        dz = torch.randn(B, 128, H, W, generator=g)
+        ps2, pt2 = torch.randn(128, generator=g), torch.randn(128, generator=g)
+        ps1, pt1 = torch.randn(c, generator=g), torch.randn(c, generator=g)
+        # 3x3: x = relu(y1 * ps2 + pt2), dy = G[:, c:c+32]
+        w2 = torch.zeros(32, 128, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(F.relu(y1.double() * ps2.double().view(1, -1, 1, 1) + pt2.double().view(1, -1, 1, 1)), w2, padding=1).backward(
+            G[:, c:c + 32].double())
+        # 1x1: x = relu(buf[:, :c] * ps1 + pt1), dy = dz
+        w1 = torch.zeros(128, c, 1, 1, dtype=torch.float64, requires_grad=True)
+        F.conv2d(F.relu(buf[:, :c].double() * ps1.double().view(1, -1, 1, 1) + pt1.double().view(1, -1, 1, 1)), w1).backward(dz.double())
+        y1d, dzd = cl(y1), cl(dz)
+        dw2, dw1 = torch.empty(32, 128, 3, 3, device="cuda"), torch.empty(128, c, 1, 1, device="cuda")
+        items.append(dict(x=y1d, dy=T.flat(Gd, c), B=B, H=H, W=W, cin=128, cout=32, taps=9, dw=dw2, pre=(ps2.cuda(), pt2.cuda()),
+                          pre_relu=True, dy_cs=Ct))
+        items.append(dict(x=bufd, dy=dzd, B=B, H=H, W=W, cin=c, cout=128, taps=1, dw=dw1, pre=(ps1.cuda(), pt1.cuda()),
+                          pre_relu=True, in_cs=Ct))
+        want += [w2.grad, w1.grad]
+    T.wgrad_group(items)
+    torch.cuda.synchronize()
+    first = [it["dw"].clone() for it in items]
+    for it, w in zip(items, want):
+        assert rel(it["dw"], w) < 5e-5, (it["cin"], it["cout"], rel(it["dw"], w))
+    T.wgrad_group(items)
+    torch.cuda.synchronize()
+    for it, f in zip(items, first):
+        assert torch.equal(it["dw"], f)
