@@ -1163,14 +1163,17 @@ __global__ __launch_bounds__(256) void small_matmul_kernel(const float* __restri
     const int n = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
     if (n >= N) return;
     const float* ar = a + (size_t)m * K;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int k = 0;
-    for (; k + 4 <= K; k += 4) {
-        s0 = fmaf(ar[k], b[(size_t)k * N + n], s0), s1 = fmaf(ar[k + 1], b[(size_t)(k + 1) * N + n], s1);
-        s2 = fmaf(ar[k + 2], b[(size_t)(k + 2) * N + n], s2), s3 = fmaf(ar[k + 3], b[(size_t)(k + 3) * N + n], s3);
+    for (; k + 16 <= K; k += 16) {           // 16 independent loads in flight per trip: the loop is a chain of L2 round trips
+        float bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) bv[u] = b[(size_t)(k + u) * N + n];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s[u & 7] = fmaf(ar[k + u], bv[u], s[u & 7]);
     }
-    for (; k < K; ++k) s0 = fmaf(ar[k], b[(size_t)k * N + n], s0);
-    out[(size_t)m * N + n] = (s0 + s1) + (s2 + s3);
+    for (; k < K; ++k) s[0] = fmaf(ar[k], b[(size_t)k * N + n], s[0]);
+    out[(size_t)m * N + n] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 }  // namespace

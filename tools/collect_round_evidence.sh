@@ -2,7 +2,7 @@
 # Collects the evidence files of a round on the GPU box into gpurun_out/<tag>/ (copied to profiles/ afterwards):
 #   tools/collect_round_evidence.sh r02
 set -e
-T=${1:-r03}
+T=${1:-r04}
 O=gpurun_out/$T/ev
 mkdir -p $O
 R=$PWD
@@ -20,4 +20,10 @@ python tools/train_layers_bench.py --what fwd,dgrad --wino > $O/train_layers_win
 for k in fwd_x6 fwd_exact; do python tools/train_layers_bench.py --what fwd --fwd-kind $k --only "^b[1-4]|^t[1-3]" > $O/train_layers_$k.txt 2>&1; done
 python tools/train_layers_bench.py --what fwd --wino --batch 21 --only . > $O/forward_layers_wino_nt21.txt 2>&1
 rm -rf $O/stats $O/ft $O/fw
+ls -la $O
+python tools/stem_bench.py > $O/stem_kernels.txt 2>&1
+python tools/wgrad_group_bench.py > $O/wgrad_group.txt 2>&1
+rocprofv3 --kernel-trace -d $O/ft2 --output-format csv -- python3 tools/bench_finetune.py --reps 3 --no-graph > $O/ft2.log 2>&1
+python tools/step_timeline.py $O/ft2/*/*kernel_trace.csv > $O/finetune_step_timeline.txt
+rm -rf $O/ft2
 ls -la $O
