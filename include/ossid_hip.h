@@ -455,6 +455,25 @@ int ossid_conv1x1_c1_bwd(const float* x, const float* g, long long rows, int C, 
 int ossid_spatial_mean(const float* x, int B, int HW, int C, int channels_last, int backward, float* out, void* stream);
 int ossid_small_matmul(const float* a, const float* b, int M, int K, int N, float* out, void* stream);
 
+/* D4  a DenseNet block of ImageFeatExtract at TEST time with one launch per layer (csrc/dense.hip; network.py:164-184 builds
+ * torchvision's densenet121: each _DenseLayer is norm1 -> ReLU -> conv1 1x1 (c -> 128) -> norm2 -> ReLU -> conv2 3x3
+ * (128 -> 32) on the concatenation of everything before it; eval mode, BatchNorms as per-channel scale / shift).
+ * The 1x1 is linear in its input channels, so the bottleneck sums y [L][pixels][128] of ALL layers are kept up to date
+ * incrementally: ossid_dense_entry writes every layer's share of the block's c0 input channels, and ossid_dense_layer(l)
+ * runs layer l's 3x3 on relu(norm2(y[l])), appends its 32 channels to buf [B][H][W][ctot] at channel c0 + 32 l, and adds
+ * their share to y[m] for every later layer m. Same values as ossid_conv_nhwc_fwd per layer up to the order of the f32
+ * summation (same three-product bf16 arithmetic, same packed weights).
+ * table: device array of nlayers records {const float* w1pk; const float* s1; const float* t1; int64 units} (32 bytes each,
+ * ossid_dense_table_bytes): conv1 packed by ossid_conv_pack_weights(w [128][c_m][1]), norm1 as scale / shift [c_m],
+ * units = c_m / 16 with c_m = c0 + 32 m. w2pk = ossid_conv_pack_weights(conv2.weight [32][128][9]); s2 / t2 [128] = norm2.
+ * c0 in {64, 128, 256, 512}; growth 32 and bottleneck 128 are fixed. ossid_dense_fused_available() = 0 in a
+ * -DOSSID_CONV_F32 build (no split form): both entries then return OSSID_EINVAL and the caller keeps the per-layer path. */
+int ossid_dense_fused_available(void);
+size_t ossid_dense_table_bytes(int nlayers);
+int ossid_dense_entry(const float* buf, int ctot, int c0, long long pixels, int nlayers, const void* table, float* y, void* stream);
+int ossid_dense_layer(float* y, float* buf, int B, int H, int W, int ctot, int c0, int layer, int nlayers, const float* w2pk,
+                      const float* s2, const float* t2, const void* table, void* stream);
+
 /* D4  DenseNet-121 conv0 = nn.Conv2d(3, 64, 7, stride 2, padding 3) of ImageFeatExtract (network.py:164-170, :175-177) as an
  * IMPLICIT-im2col convolution on the f32 matrix cores (csrc/stem.hip; exact f32: an fmaf chain), and its weight gradient
  * (the image is an input: there is no data gradient). img NCHW [B][3][H][W] as the caller holds it; mean / inv_std [3]

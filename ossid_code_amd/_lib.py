@@ -128,6 +128,10 @@ _PROTOS = {
     "ossid_conv1x1_c1_bwd": (_i, [_vp, _vp, C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp]),
     "ossid_spatial_mean": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ossid_small_matmul": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ossid_dense_fused_available": (_i, []),
+    "ossid_dense_table_bytes": (_sz, [_i]),
+    "ossid_dense_entry": (_i, [_vp, _i, _i, C.c_longlong, _i, _vp, _vp, _vp]),
+    "ossid_dense_layer": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ossid_stem_conv_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ossid_stem_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "ossid_stem_conv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _i, _vp]),
@@ -330,6 +334,8 @@ def _pipe_flops(name, args, flops):
     if name == "ossid_conv_nhwc_fwd":
         form = (args[0]._obj.exact if args else 0) if lib().ossid_conv_split_bf16() else 1
         return flops * (SPLIT_BF16_PIPE_WEIGHT if form == 0 else (2.0 * SPLIT_BF16_PIPE_WEIGHT if form == 2 else 1.0))
+    if name in ("ossid_dense_entry", "ossid_dense_layer"):
+        return flops * SPLIT_BF16_PIPE_WEIGHT
     if name == "ossid_seg_tail_fwd":
         return flops * (SPLIT_BF16_PIPE_WEIGHT if lib().ossid_seg_tail_split_bf16() else 1.0)
     if name == "ossid_conv_wgrad" and args:
@@ -361,6 +367,10 @@ _MFMA_RULES = {
     "ossid_conv_wgrad_group": lambda a: sum(_wgrad_flops_d(a[0][i]) for i in range(a[1])),
     # (x, B, Hs, Ws, C, H, W, ...): 32 -> 16 on the up-sampled image, kernel rows merged 3 -> 2 away from the border
     "ossid_seg_tail_fwd": lambda a: 2.0 * a[1] * a[5] * a[6] * 16 * a[4] * 6,
+    # (buf, ctot, c0, pixels, nlayers, ...): every layer's 1x1 share of the block's c0 input channels
+    "ossid_dense_entry": lambda a: 2.0 * a[3] * 128 * a[2] * a[4],
+    # (y, buf, B, H, W, ctot, c0, layer, nlayers, ...): the 3x3 plus the 32-channel shares of the later layers
+    "ossid_dense_layer": lambda a: 2.0 * a[2] * a[3] * a[4] * 128 * 32 * (9 + a[8] - 1 - a[7]),
 }
 
 

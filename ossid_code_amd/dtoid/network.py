@@ -606,6 +606,7 @@ class FusedBackbone:
                 layers = [(P(l.conv1, pre_bn=l.norm1, pre_relu=True), P(l.conv2, pre_bn=l.norm2, pre_relu=True))
                           for l in m.values()]
                 self.stages.append(("block", m, layers))
+                m.__dict__["_ossid_dense_table"] = ops.dense_block_table(layers, m.growth)
             elif isinstance(m, nn.BatchNorm2d):                  # norm5, folded into c1's input staging
                 self.final = P(ife.c1, bn=ife.n1, act=True, pre_bn=m, pre_relu=False)
             else:                                                # Transition: norm relu conv pool
@@ -620,6 +621,8 @@ class FusedBackbone:
             dst.copy_(src)
 
     use_fused_stem = os.environ.get("OSSID_FUSED_STEM", "1") != "0"
+    # a dense block of at most this many pixels (batch x height x width) takes the one-launch-per-layer form
+    DENSE_FUSED_MAX_PIXELS = int(os.environ.get("OSSID_DENSE_FUSED_MAX_PIXELS", "6000"))
 
     def __call__(self, image, template_feat, raw_image=False):
         """raw_image: `image` is in [0, 1] and normalizeImageRange is applied inside the stem's gather (D1)."""
@@ -645,13 +648,19 @@ class FusedBackbone:
                 buf = torch.empty((B, ctot, H, W), dtype=torch.float32, device=x.device,
                                   memory_format=torch.channels_last)
                 buf[:, :C] = x
-                tmp = torch.empty((B, 128, H, W), dtype=torch.float32, device=x.device,
-                                  memory_format=torch.channels_last)
-                c = C
-                for conv1, conv2 in packed:
-                    conv1.run(buf, B, H, W, tmp, in_cs=ctot)
-                    conv2.run(tmp, B, H, W, buf, out_cs=ctot, out_coff=c)
-                    c += mod.growth
+                table = mod.__dict__.get("_ossid_dense_table")
+                if table is not None and B * H * W <= self.DENSE_FUSED_MAX_PIXELS and C in (64, 128, 256, 512):
+                    # few pixels (a single frame): one launch per layer, the later layers' bottleneck sums kept up to date
+                    # incrementally (csrc/dense.hip) instead of two launches with the 1x1 over the whole prefix
+                    ops.dense_block_fused(buf, B, H, W, C, packed, table)
+                else:
+                    tmp = torch.empty((B, 128, H, W), dtype=torch.float32, device=x.device,
+                                      memory_format=torch.channels_last)
+                    c = C
+                    for conv1, conv2 in packed:
+                        conv1.run(buf, B, H, W, tmp, in_cs=ctot)
+                        conv2.run(tmp, B, H, W, buf, out_cs=ctot, out_coff=c)
+                        c += mod.growth
                 x = buf
             else:
                 st = mod.pool.stride if isinstance(mod.pool.stride, int) else mod.pool.stride[0]

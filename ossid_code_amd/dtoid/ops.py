@@ -521,6 +521,38 @@ class PackedConv:
         return True
 
 
+def dense_block_table(layers, growth):
+    """The device table ossid_dense_entry / ossid_dense_layer read for one DenseNet block: per layer conv1's packed weights,
+    norm1's scale / shift and the layer's input width in 16-channel units. layers: [(PackedConv conv1, PackedConv conv2)].
+    None when the block is not densenet121-shaped (growth 32, bottleneck 128) or the library has no split form: the caller
+    then keeps the two-launch path. The table holds ADDRESSES of the PackedConv buffers, which refresh() rewrites in place."""
+    if growth != 32 or not layers or not _lib.fn("ossid_dense_fused_available")():
+        return None
+    rows = []
+    for li, (c1, c2) in enumerate(layers):
+        if c1.cout != 128 or c1.taps != 1 or c2.cin != 128 or c2.cout != 32 or c2.taps != 9 or c1.cin != layers[0][0].cin + 32 * li:
+            return None
+        rows.append([c1.wpk.data_ptr(), c1.pre_scale.data_ptr(), c1.pre_shift.data_ptr(), c1.cin // 16])
+    return torch.tensor(rows, dtype=torch.int64).to(layers[0][0].wpk.device)
+
+
+def dense_block_fused(buf, B, H, W, C0, layers, table):
+    """A DenseNet block at test time on csrc/dense.hip: buf [B][H][W][ctot] (channels-last) holds the block's input in its
+    first C0 channels; every layer appends its 32 channels in place. One launch per layer plus the block entry."""
+    L = len(layers)
+    ctot = int(buf.shape[1])
+    P = B * H * W
+    y = torch.empty((L, P, 128), dtype=torch.float32, device=buf.device)
+    with _lib.on_device(buf.device):
+        s = _lib.stream()
+        _lib.check(_lib.fn("ossid_dense_entry")(buf.data_ptr(), ctot, C0, P, L, table.data_ptr(), y.data_ptr(), s), "ossid_dense_entry")
+        for li, (c1, c2) in enumerate(layers):
+            _lib.check(_lib.fn("ossid_dense_layer")(y.data_ptr(), buf.data_ptr(), B, H, W, ctot, C0, li, L, c2.wpk.data_ptr(),
+                                                    c2.pre_scale.data_ptr(), c2.pre_shift.data_ptr(), table.data_ptr(), s),
+                       "ossid_dense_layer")
+    return buf
+
+
 class SegTail:
     """The decoder's last two layers as ONE launch (csrc/segtail.hip): nearest up-sample to `size` -> conv3x3 32->16 ->
     ELU -> eval BatchNorm -> conv3x3 16->1 (network.py:357-362: s5/ns5 after F.interpolate, then seg_final).

@@ -381,6 +381,57 @@ def test_fused_backbone_matches_module_path(hiplib):
     assert float((got - ref).abs().max()) <= 1e-3 * float(ref.abs().max())   # 120 chained layers, two f32 sum orders
 
 
+@pytest.mark.parametrize("B,C0,L,H,W", [
+    (1, 256, 24, 30, 40),      # DenseNet-121 block 3 of one 480x640 frame: 6 groups per tile at the first layers
+    (1, 512, 16, 29, 39),      # block 4: ragged tiles in both directions
+    (1, 128, 12, 60, 80),      # block 2: the group count is capped by the workgroup budget
+    (2, 64, 6, 13, 9),         # two images, tiles cut by the right and bottom edge, the narrowest entry kernel
+    (1, 64, 1, 4, 8),          # a single layer: no later layer to feed
+])
+def test_dense_block_one_launch_per_layer_matches_float64_and_the_two_launch_path(hiplib, B, C0, L, H, W):
+    """csrc/dense.hip (incremental bottleneck sums, one launch per layer) against the same block in float64 on the CPU,
+    and against the per-layer path on csrc/conv.hip. Tolerance: the block is up to 48 chained convolutions on the
+    three-product bf16 form (~5e-6 of a layer's output scale each): the fused form has to be as close to float64 as the
+    two-launch form is, within 2x, and both within 1e-4 of the output scale."""
+    from ossid_code_amd.dtoid.backbones import DenseBlock
+    torch.manual_seed(C0 + L)
+    blk = DenseBlock(L, C0).eval()
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1), m.running_var.uniform_(0.5, 1.5), m.weight.normal_(1, 0.1), m.bias.normal_(0, 0.1)
+        x = torch.randn(B, C0, H, W)
+        ref = blk.double()(x.double())
+    blk = blk.float().cuda()
+    P = ops.PackedConv
+    layers = [(P(l.conv1, pre_bn=l.norm1, pre_relu=True), P(l.conv2, pre_bn=l.norm2, pre_relu=True)) for l in blk.values()]
+    table = ops.dense_block_table(layers, blk.growth)
+    assert table is not None and tuple(table.shape) == (L, 4)
+    ctot = C0 + 32 * L
+
+    def fresh():
+        buf = torch.empty((B, ctot, H, W), device="cuda").contiguous(memory_format=torch.channels_last)
+        buf.fill_(float("nan"))                                           # every appended channel must be written
+        buf[:, :C0] = x.cuda()
+        return buf
+    fused = ops.dense_block_fused(fresh(), B, H, W, C0, layers, table)
+    two = fresh()
+    tmp = torch.empty((B, 128, H, W), device="cuda").contiguous(memory_format=torch.channels_last)
+    c = C0
+    for c1, c2 in layers:
+        c1.run(two, B, H, W, tmp, in_cs=ctot)
+        c2.run(tmp, B, H, W, two, out_cs=ctot, out_coff=c)
+        c += 32
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    e_f = float((fused.cpu().double() - ref).abs().max()) / scale
+    e_t = float((two.cpu().double() - ref).abs().max()) / scale
+    assert torch.equal(fused[:, :C0], two[:, :C0])
+    assert e_t <= 1e-4 and e_f <= max(2 * e_t, 2e-5), (e_f, e_t)
+    again = ops.dense_block_fused(fresh(), B, H, W, C0, layers, table)     # fixed summation order: bit-reproducible
+    assert torch.equal(again, fused)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,Hs,Ws,H,W", [(2, 232, 312, 480, 640), (1, 29, 39, 61, 83), (3, 20, 24, 40, 48),
                                          (1, 7, 9, 30, 31)])
