@@ -43,6 +43,14 @@ __device__ __forceinline__ v16f mfma3(const float4& whi, const float4& wlo, cons
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
 }
 
+// Pointers read from the device table are generic to the compiler (flat_load: slower, and counted on lgkmcnt as well); they
+// are global addresses by contract.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg(const void* p) {
+    const v4f v = *(const v4f __attribute__((address_space(1)))*)(unsigned long long)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // eight f32 -> (hi, lo) bf16 octets: one MFMA operand each
 __device__ __forceinline__ void split8(const float (&v)[8], float4& hi, float4& lo) {
     union {
@@ -89,29 +97,30 @@ struct TargetRegs {
     float4 s[4], t[4];    // affine of this lane's 16 slab channels: [unit][half-quad]
 };
 
-__device__ __forceinline__ void target_load(const DenseArgs& A, int m, int lane, long long pix, bool valid, TargetRegs& R) {
+// pixc: an in-image pixel for every lane (a lane outside the image reads a neighbour's row and stores nothing): the loads are
+// unconditional, so nothing waits between them
+__device__ __forceinline__ void target_load(const DenseArgs& A, int m, int lane, long long pixc, TargetRegs& R) {
     const DenseTarget T = A.tab[m];
     const int h = lane >> 5;
     const int u0 = A.coff / 16;
-    const float* yrow = A.y + ((size_t)m * A.P + (valid ? pix : 0)) * MID + 4 * h;
+    const float* yrow = A.y + ((size_t)m * A.P + pixc) * MID + 4 * h;
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            R.yold[tt][q] = valid ? *(const float4*)(yrow + 32 * tt + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 4; ++q) R.yold[tt][q] = *(const float4*)(yrow + 32 * tt + 8 * q);
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int k = 0; k < 2; ++k) R.w[tt][u][k] = T.w1pk[(((size_t)tt * T.units + u0 + u) * 2 + k) * 64 + lane];
+            for (int k = 0; k < 2; ++k) R.w[tt][u][k] = ldg(T.w1pk + (((size_t)tt * T.units + u0 + u) * 2 + k) * 64 + lane);
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int ch = A.coff + 16 * u + 8 * h + 4 * i;
-            R.s[2 * u + i] = *(const float4*)(T.s1 + ch);
-            R.t[2 * u + i] = *(const float4*)(T.t1 + ch);
+            R.s[2 * u + i] = ldg(T.s1 + ch);
+            R.t[2 * u + i] = ldg(T.t1 + ch);
         }
 }
 
@@ -171,12 +180,13 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs A) {
     float4 st[NLD];
     bool ok[NLD];
 #pragma unroll
-    for (int e = 0; e < NLD; ++e) {
+    for (int e = 0; e < NLD; ++e) {                                          // (unconditional loads from clamped addresses)
         const int pos = (tid >> 5) + 8 * e;
         const int pr = pos / PC, pc = pos - pr * PC;
         const int yy = y0 - 1 + pr, xx = x0 - 1 + pc;
         ok[e] = pos < NPOS && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        st[e] = ok[e] ? *(const float4*)(yl + ((size_t)(b * H + yy) * W + xx) * MID + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+        st[e] = *(const float4*)(yl + ((size_t)(b * H + yc) * W + xc) * MID + 4 * j);
     }
     const float4 s2 = *(const float4*)(A.s2 + 4 * j), t2 = *(const float4*)(A.t2 + 4 * j);
     // ---- (1b) this wave's 3x3 weights: channel units 2 wave, 2 wave + 1, all nine taps ----------------------------------
@@ -191,10 +201,11 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs A) {
     const int py = y0 + (n >> 3), px = x0 + (n & 7);
     const bool valid = py < H && px < W;
     const long long pix = (long long)(b * H + py) * W + px;
+    const long long pixc = (long long)(b * H + min(py, H - 1)) * W + min(px, W - 1);
     const int nlater = A.nlayers - 1 - A.layer;
     const int slot = g * 4 + wave, stride = 4 * A.G;
     TargetRegs R;
-    if (slot < nlater) target_load(A, A.layer + 1 + slot, lane, pix, valid, R);
+    if (slot < nlater) target_load(A, A.layer + 1 + slot, lane, pixc, R);
 
     // ---- (1c) patch -> LDS as (hi, lo) bf16 -----------------------------------------------------------------------------
     {
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs A) {
     target_apply(A, A.layer + 1 + slot, lane, pix, valid, R, v);
 #pragma unroll 1
     for (int s = slot + stride; s < nlater; s += stride) {
-        target_load(A, A.layer + 1 + s, lane, pix, valid, R);
+        target_load(A, A.layer + 1 + s, lane, pixc, R);
         target_apply(A, A.layer + 1 + s, lane, pix, valid, R, v);
     }
 }
@@ -302,16 +313,16 @@ __global__ __launch_bounds__(256) void dense_entry_kernel(const EntryArgs A) {
 #pragma unroll
     for (int e = 0; e < NLD; ++e) {
         const long long p = p0 + (tid + 256 * e) / F4;
-        st[e] = p < A.P ? *(const float4*)(A.buf + (size_t)p * A.ctot + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        st[e] = *(const float4*)(A.buf + (size_t)(p < A.P ? p : A.P - 1) * A.ctot + 4 * j);      // (rows past the end are never stored)
     }
-    const float4 s1 = *(const float4*)(T.s1 + 4 * j), t1 = *(const float4*)(T.t1 + 4 * j);
+    const float4 s1 = ldg(T.s1 + 4 * j), t1 = ldg(T.t1 + 4 * j);
     constexpr int GU = 4;                                                      // units per weight prefetch group
     float4 wq[2][GU][2];
     const float4* W4 = T.w1pk + (size_t)wave * T.units * 2 * 64 + lane;
 #pragma unroll
     for (int i = 0; i < GU; ++i)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) wq[0][i][k] = W4[((size_t)i * 2 + k) * 64];
+        for (int k = 0; k < 2; ++k) wq[0][i][k] = ldg(W4 + ((size_t)i * 2 + k) * 64);
     {
         uint2* p2 = (uint2*)xs;
         const int u = j >> 2, jj = j & 3;
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(256) void dense_entry_kernel(const EntryArgs A) {
 #pragma unroll
             for (int i = 0; i < GU; ++i)
 #pragma unroll
-                for (int k = 0; k < 2; ++k) wq[(gq + 1) & 1][i][k] = W4[((size_t)((gq + 1) * GU + i) * 2 + k) * 64];
+                for (int k = 0; k < 2; ++k) wq[(gq + 1) & 1][i][k] = ldg(W4 + ((size_t)((gq + 1) * GU + i) * 2 + k) * 64);
         }
 #pragma unroll
         for (int i = 0; i < GU; ++i) {
