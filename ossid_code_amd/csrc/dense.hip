@@ -28,6 +28,8 @@
 // Traffic: y1 of all layers lives in one [L][P][128] buffer (14.7 MB for block 3 at 1 200 pixels); a tile is always handled
 // by workgroups with the same id modulo 8, i.e. on the same XCD, so its read-modify-write mostly stays in that L2. For many
 // pixels (a batch of images) the O(L^2) read-modify-write outweighs the launches it saves: the caller picks per block.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -41,6 +43,16 @@ __device__ __forceinline__ v16f mfma3(const float4& whi, const float4& wlo, cons
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+}
+
+// compile-time loop: the body sees its index as a constant BEFORE the optimiser's first scalar-replacement pass (a `#pragma
+// unroll` loop is unrolled after it: register arrays indexed by the loop variable then live in scratch memory)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
 }
 
 // Pointers read from the device table are generic to the compiler (flat_load: slower, and counted on lgkmcnt as well); they
@@ -92,22 +104,26 @@ constexpr int SSTR = GROWTH + 4;                    // floats per pixel of the s
 
 // registers of one later layer's share: requested early, used after the slab exists
 struct TargetRegs {
-    float4 yold[4][4];    // [channel tile][register quad]: the 16 accumulator values of this lane
+    float yold[4][16];    // [channel tile][accumulator register]
     float4 w[4][2][2];    // [channel tile][unit][hi / lo]
     float4 s[4], t[4];    // affine of this lane's 16 slab channels: [unit][half-quad]
 };
 
-// pixc: an in-image pixel for every lane (a lane outside the image reads a neighbour's row and stores nothing): the loads are
-// unconditional, so nothing waits between them
-__device__ __forceinline__ void target_load(const DenseArgs& A, int m, int lane, long long pixc, TargetRegs& R) {
+// The shares are computed TRANSPOSED -- pixels on the MFMA's M axis, output channels on N (the operand layouts of
+// v_mfma_f32_32x32x16_bf16 are symmetric, so the packed weights serve as the B operand as they are) -- which puts one
+// CHANNEL in a lane and the tile's pixels in its 16 accumulator registers: register 4q + i of lane (n, h) is pixel
+// (row q, column 4h + i) of the tile, channel 32 tt + n. A load / store of one register then covers two whole 128-byte rows
+// of y (coalesced) instead of 16 bytes in each of 32 rows. rowoff[r]: that pixel's row in y (clamped into the image: lanes
+// outside it read a neighbour and store nothing), all loads unconditional so nothing waits between them.
+__device__ __forceinline__ void target_load(const DenseArgs& A, int m, int lane, const int (&rowoff)[16], TargetRegs& R) {
     const DenseTarget T = A.tab[m];
-    const int h = lane >> 5;
+    const int h = lane >> 5, n = lane & 31;
     const int u0 = A.coff / 16;
-    const float* yrow = A.y + ((size_t)m * A.P + pixc) * MID + 4 * h;
+    const float* yb = A.y + (size_t)m * A.P * MID + n;
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) R.yold[tt][q] = *(const float4*)(yrow + 32 * tt + 8 * q);
+        for (int r = 0; r < 16; ++r) R.yold[tt][r] = yb[(size_t)rowoff[r] * MID + 32 * tt];
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -124,10 +140,38 @@ __device__ __forceinline__ void target_load(const DenseArgs& A, int m, int lane,
         }
 }
 
-// y1_m[tile] += W1_m[:, slab] . relu(bn1_m(slab)); v = this lane's 16 slab channels (unit u: v[8u .. 8u+7])
-__device__ __forceinline__ void target_apply(const DenseArgs& A, int m, int lane, long long pix, bool valid, const TargetRegs& R,
-                                             const float (&v)[16]) {
+// The same loads in slices. A wave issues in order and a CU's load path serves one 1 KB wave-instruction per ~16 cycles for
+// all four waves: a block of loads in front of the 3x3's MFMA loop holds the loop back until the path has taken them all.
+// So the 24 weight / affine loads are woven into the loop's last 12 (unit, tap) steps, two each -- by then the 3x3's own
+// weight registers are being released, which keeps the kernel under 256 registers (beyond that the allocator parks loaded
+// values in accumulator registers through a copy that waits for the load: measured 6.5 us for the loop) -- and the old sums
+// are requested right after the loop, to land while the partial tiles meet in LDS.
+template <int IDX>
+__device__ __forceinline__ void target_load_step(const DenseArgs& A, const DenseTarget& T, int lane, TargetRegs& R) {
     const int h = lane >> 5;
+    const int u0 = A.coff / 16;
+    if constexpr (IDX < 16) {
+        constexpr int tt = IDX >> 2, u = (IDX >> 1) & 1, k = IDX & 1;
+        R.w[tt][u][k] = ldg(T.w1pk + (((size_t)tt * T.units + u0 + u) * 2 + k) * 64 + lane);
+    } else {
+        constexpr int q = (IDX - 16) & 3;                                     // [unit][half-quad]
+        const int ch = A.coff + 16 * (q >> 1) + 8 * h + 4 * (q & 1);
+        if constexpr (IDX < 20) R.s[q] = ldg(T.s1 + ch);
+        else R.t[q] = ldg(T.t1 + ch);
+    }
+}
+__device__ __forceinline__ void target_load_yold(const DenseArgs& A, int m, int lane, const int (&rowoff)[16], TargetRegs& R) {
+    const float* yb = A.y + (size_t)m * A.P * MID + (lane & 31);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) R.yold[tt][r] = yb[(size_t)rowoff[r] * MID + 32 * tt];
+}
+
+// y1_m[tile] += W1_m[:, slab] . relu(bn1_m(slab)); v = the 16 slab channels 16u + 8h + 0..7 (u = 0, 1) of pixel n
+__device__ __forceinline__ void target_apply(const DenseArgs& A, int m, int lane, const int (&rowoff)[16], unsigned rowvalid,
+                                             const TargetRegs& R, const float (&v)[16]) {
+    const int n = lane & 31;
     float4 xh[2], xl[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -142,32 +186,63 @@ __device__ __forceinline__ void target_apply(const DenseArgs& A, int m, int lane
         }
         split8(a, xh[u], xl[u]);
     }
-    float* yrow = A.y + ((size_t)m * A.P + (valid ? pix : 0)) * MID + 4 * h;
+    float* yb = A.y + (size_t)m * A.P * MID + n;
+    // four independent accumulator chains, interleaved product by product (one tile after the other would leave the matrix
+    // pipe waiting for each chain's dependent results)
+    v16f acc[4];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        v16f acc;
+    for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc[4 * q + 0] = R.yold[tt][q].x, acc[4 * q + 1] = R.yold[tt][q].y;
-            acc[4 * q + 2] = R.yold[tt][q].z, acc[4 * q + 3] = R.yold[tt][q].w;
-        }
-        acc = mfma3(R.w[tt][0][0], R.w[tt][0][1], xh[0], xl[0], acc);
-        acc = mfma3(R.w[tt][1][0], R.w[tt][1][1], xh[1], xl[1], acc);
-        if (valid) {
+        for (int r = 0; r < 16; ++r) acc[tt][r] = R.yold[tt][r];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *(float4*)(yrow + 32 * tt + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-        }
+    for (int u = 0; u < 2; ++u) {
+        const v8bf ah = __builtin_bit_cast(v8bf, xh[u]), al = __builtin_bit_cast(v8bf, xl[u]);      // (activations as A: the transposed product)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(v8bf, R.w[tt][u][0]), acc[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(v8bf, R.w[tt][u][1]), acc[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(v8bf, R.w[tt][u][0]), acc[tt], 0, 0, 0);
+    }
+    if (__builtin_amdgcn_ballot_w64(rowvalid != 0xffffu) == 0) {             // the whole tile inside the image: plain stores
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yb[(size_t)rowoff[r] * MID + 32 * tt] = acc[tt][r];
+    } else {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (rowvalid >> r & 1) yb[(size_t)rowoff[r] * MID + 32 * tt] = acc[tt][r];
     }
 }
 
+#ifdef OSSID_DENSE_TIMING   // diagnostic build only (tools/dense_timeline.py): s_memrealtime stamps (100 MHz) of every wave of the LAST launch
+__device__ unsigned long long dense_stamps[8192 * 8];
+#define DSTAMP(i)                                                                                        \
+    do {                                                                                                 \
+        unsigned long long t_;                                                                           \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");               \
+        if (lane == 0 && blockIdx.x * 4 + wave < 8192) dense_stamps[(blockIdx.x * 4 + wave) * 8 + (i)] = t_; \
+    } while (0)
+#else
+#define DSTAMP(i)
+#endif
+
 __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs A) {
-    __shared__ __attribute__((aligned(16))) float4 patch[NPOS * PSTR];          // 31 680 B; the partial tiles reuse it
+    // 60 positions + 4 that only take the writes of the last staging round's spare threads (every load and every LDS write
+    // unconditional: a load whose value is used under a condition gets sunk into it, with a wait for ALL loads behind it)
+    __shared__ __attribute__((aligned(16))) float4 patch[64 * PSTR];            // 33 792 B; the partial tiles reuse it
     __shared__ __attribute__((aligned(16))) float slab[32 * SSTR];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, n = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x / A.ntiles_pad, t = blockIdx.x - g * A.ntiles_pad;
     if (t >= A.ntiles) return;
+    DSTAMP(0);
     const int per_img = A.tiles_x * A.tiles_y;
     const int b = t / per_img, r = t - b * per_img;
     const int y0 = (r / A.tiles_x) * TR, x0 = (r % A.tiles_x) * TC;
@@ -189,23 +264,34 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs A) {
         st[e] = *(const float4*)(yl + ((size_t)(b * H + yc) * W + xc) * MID + 4 * j);
     }
     const float4 s2 = *(const float4*)(A.s2 + 4 * j), t2 = *(const float4*)(A.t2 + 4 * j);
-    // ---- (1b) this wave's 3x3 weights: channel units 2 wave, 2 wave + 1, all nine taps ----------------------------------
-    float4 w2[2][9][2];
+    // ---- (1b) this wave's 3x3 weights: channel units 2 wave, 2 wave + 1, all nine taps, as a ring WRING (unit, tap) steps
+    // deep: only the first steps' weights are requested in front of the staging (a wave issues in order and the CU's load
+    // path takes ~16 cycles per wave-instruction: with all 36 in front, the staging started 2.1 us into the launch), the
+    // rest inside the MFMA loop, WRING steps ahead of their use
+    constexpr int WRING = 6;
+    float4 w2r[WRING][2];
+    auto w2_load = [&](auto S) {
+        constexpr int step = decltype(S)::value, tap = step / 2, uu = step % 2;
 #pragma unroll
-    for (int uu = 0; uu < 2; ++uu)
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) w2[uu][tap][k] = A.w2pk[((size_t)((2 * wave + uu) * 9 + tap) * 2 + k) * 64 + lane];
-    // ---- (3a) this wave's first later layer: everything it needs that does not depend on the slab -------------------------
+        for (int k = 0; k < 2; ++k) w2r[step % WRING][k] = A.w2pk[((size_t)((2 * wave + uu) * 9 + tap) * 2 + k) * 64 + lane];
+    };
+    static_for<0, WRING>(w2_load);
     const int py = y0 + (n >> 3), px = x0 + (n & 7);
     const bool valid = py < H && px < W;
     const long long pix = (long long)(b * H + py) * W + px;
-    const long long pixc = (long long)(b * H + min(py, H - 1)) * W + min(px, W - 1);
     const int nlater = A.nlayers - 1 - A.layer;
-    const int slot = g * 4 + wave, stride = 4 * A.G;
-    TargetRegs R;
-    if (slot < nlater) target_load(A, A.layer + 1 + slot, lane, pixc, R);
+    const int slot = wave * A.G + g, stride = 4 * A.G;        // later layer s -> group s % G, wave s / G: few per workgroup
+    int rowoff[16];                                                            // accumulator register 4q + i <-> pixel (q, 4h + i)
+    unsigned rowvalid = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = y0 + q, xx = x0 + 4 * h + i;
+            rowoff[4 * q + i] = (b * H + min(yy, H - 1)) * W + min(xx, W - 1);
+            rowvalid |= (yy < H && xx < W) ? 1u << (4 * q + i) : 0u;
+        }
+    DSTAMP(1);
 
     // ---- (1c) patch -> LDS as (hi, lo) bf16 -----------------------------------------------------------------------------
     {
@@ -214,12 +300,12 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs A) {
 #pragma unroll
         for (int e = 0; e < NLD; ++e) {
             const int pos = (tid >> 5) + 8 * e;
-            if (pos >= NPOS) continue;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (ok[e]) {
-                v[0] = fmaxf(st[e].x * s2.x + t2.x, 0.f), v[1] = fmaxf(st[e].y * s2.y + t2.y, 0.f);
-                v[2] = fmaxf(st[e].z * s2.z + t2.z, 0.f), v[3] = fmaxf(st[e].w * s2.w + t2.w, 0.f);
-            }
+            // (a 0 / 1 factor, not a condition: a load whose value is used under one is sunk into it, and a wait for ALL loads
+            // with it; the clamped address holds a finite value)
+            const float okf = ok[e] ? 1.0f : 0.0f;
+            float v[4];
+            v[0] = okf * fmaxf(st[e].x * s2.x + t2.x, 0.f), v[1] = okf * fmaxf(st[e].y * s2.y + t2.y, 0.f);
+            v[2] = okf * fmaxf(st[e].z * s2.z + t2.z, 0.f), v[3] = okf * fmaxf(st[e].w * s2.w + t2.w, 0.f);
             union {
                 __bf16 b4[4];
                 uint2 u2;
@@ -234,21 +320,51 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs A) {
         }
     }
     __syncthreads();
-
-    // ---- (1d) 3x3, this wave's 32 of the 128 reduction channels ---------------------------------------------------------
+    DSTAMP(2);
+    // ---- (1d) 3x3, this wave's 32 of the 128 reduction channels (one accumulator chain per unit), with (3a) woven in: the
+    // loads of this wave's first later layer -- old sums, weights, affine: nothing that depends on the slab. Not in front of
+    // the staging: a CU's load path takes one 1 KB wave-instruction per ~16 cycles, the 3x3 weights alone keep it busy for
+    // ~1.4 us, and a wave cannot go on before all its loads are issued (tools/dense_timeline.py: the staging started 3.6 us
+    // into the launch with these loads in front of it); and not as one block in front of the MFMAs, which would wait likewise.
+    TargetRegs R;
+    const bool has = slot < nlater;
+    const int m0 = A.layer + 1 + (has ? slot : 0);
+    const DenseTarget T0 = A.tab[has ? m0 : A.layer];
+    v16f acc2[2];
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc2[uu][i] = 0.f;
+    // (two copies of the loop, with and without the woven loads: a branch INSIDE it makes every step wait for all
+    // outstanding loads -- the wait-count pass gives up at the joins; measured 6.5 us for this phase)
+    const int p0 = (n >> 3) * PC + (n & 7);
+    const float4* pbase = patch + (size_t)p0 * PSTR + 2 * wave * 4 + h;
+    if (has) {
+        static_for<0, 18>([&](auto S) {
+            constexpr int step = decltype(S)::value, tap = step / 2, uu = step % 2;
+            const float4* px4 = pbase + ((tap / 3) * PC + tap % 3) * PSTR + uu * 4;
+            acc2[uu] = mfma3(w2r[step % WRING][0], w2r[step % WRING][1], px4[0], px4[2], acc2[uu]);
+            if constexpr (step + WRING < 18) w2_load(std::integral_constant<int, step + WRING>{});
+            if constexpr (step >= 6) {
+                target_load_step<2 * (step - 6)>(A, T0, lane, R);
+                target_load_step<2 * (step - 6) + 1>(A, T0, lane, R);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        target_load_yold(A, m0, lane, rowoff, R);
+    } else {
+        static_for<0, 18>([&](auto S) {
+            constexpr int step = decltype(S)::value, tap = step / 2, uu = step % 2;
+            const float4* px4 = pbase + ((tap / 3) * PC + tap % 3) * PSTR + uu * 4;
+            acc2[uu] = mfma3(w2r[step % WRING][0], w2r[step % WRING][1], px4[0], px4[2], acc2[uu]);
+            if constexpr (step + WRING < 18) w2_load(std::integral_constant<int, step + WRING>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
     v16f acc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    {
-        const int p0 = (n >> 3) * PC + (n & 7);
-#pragma unroll
-        for (int uu = 0; uu < 2; ++uu)
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const float4* px4 = patch + (size_t)(p0 + (tap / 3) * PC + tap % 3) * PSTR + (2 * wave + uu) * 4 + h;
-                acc = mfma3(w2[uu][tap][0], w2[uu][tap][1], px4[0], px4[2], acc);
-            }
-    }
+    for (int i = 0; i < 16; ++i) acc[i] = acc2[0][i] + acc2[1][i];
+    DSTAMP(3);
     __syncthreads();                                                           // the patch is dead: partial tiles go there
     float* red = (float*)patch;                                                // [4 waves][16][64]
 #pragma unroll
@@ -269,6 +385,7 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs A) {
         *(float4*)(slab + n * SSTR + 8 * wave + 4 * h) = o;
     }
     __syncthreads();
+    DSTAMP(4);
     if (slot >= nlater) return;                                                // (after the last barrier)
     // ---- (3b) shares of the later layers -----------------------------------------------------------------------------------
     float v[16];
@@ -279,11 +396,16 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs A) {
             const float4 q = *(const float4*)(slab + n * SSTR + 16 * u + 8 * h + 4 * i);
             v[8 * u + 4 * i + 0] = q.x, v[8 * u + 4 * i + 1] = q.y, v[8 * u + 4 * i + 2] = q.z, v[8 * u + 4 * i + 3] = q.w;
         }
-    target_apply(A, A.layer + 1 + slot, lane, pix, valid, R, v);
+    target_apply(A, A.layer + 1 + slot, lane, rowoff, rowvalid, R, v);
+    DSTAMP(5);
+#ifdef OSSID_DENSE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DSTAMP(6);
+#endif
 #pragma unroll 1
     for (int s = slot + stride; s < nlater; s += stride) {
-        target_load(A, A.layer + 1 + s, lane, pixc, R);
-        target_apply(A, A.layer + 1 + s, lane, pix, valid, R, v);
+        target_load(A, A.layer + 1 + s, lane, rowoff, R);
+        target_apply(A, A.layer + 1 + s, lane, rowoff, rowvalid, R, v);
     }
 }
 
@@ -387,6 +509,13 @@ extern "C" {
 
 int ossid_dense_fused_available(void) { return OSSID_CONV_SB; }
 
+#ifdef OSSID_DENSE_TIMING
+int ossid_dense_debug_stamps(void* host_out, size_t bytes) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dense_stamps), bytes < sizeof(dense_stamps) ? bytes : sizeof(dense_stamps)) == hipSuccess
+               ? OSSID_OK : OSSID_ELAUNCH;
+}
+#endif
+
 size_t ossid_dense_table_bytes(int nlayers) { return (size_t)(nlayers > 0 ? nlayers : 0) * sizeof(DenseTarget); }
 
 int ossid_dense_entry(const float* buf, int ctot, int c0, long long pixels, int nlayers, const void* table, float* y, void* stream) {
@@ -420,9 +549,11 @@ int ossid_dense_layer(float* y, float* buf, int B, int H, int W, int ctot, int c
     a.tiles_x = (W + TC - 1) / TC, a.tiles_y = (H + TR - 1) / TR;
     const long long nt = (long long)B * a.tiles_x * a.tiles_y;
     const int nlater = nlayers - 1 - layer;
-    int G = (nlater + 3) / 4;
-    if (G < 1) G = 1;
-    // enough groups for one later layer per wave while the launch stays within ~2 workgroups per CU
+    // The later layers' shares are vector-memory work (old sums in, weights in, new sums out: ~70 wave-instructions each), and a
+    // CU's waves queue at its one texture-address unit: as many groups as later layers (one share per workgroup) while the
+    // launch stays within one workgroup per CU; beyond that, one share per wave, at most ~2 workgroups per CU.
+    int G = nlater < 1 ? 1 : nlater;
+    while (G > 1 && nt * G > 256 && G > (nlater + 3) / 4) --G;
     while (G > 1 && nt * G > 512) --G;
     if (nt * G > 0x3fffffffLL) return OSSID_EINVAL;
     a.G = G, a.ntiles = (int)nt, a.ntiles_pad = (int)((nt + 7) / 8 * 8);
