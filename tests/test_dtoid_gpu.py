@@ -1000,7 +1000,10 @@ def test_template_encoder_training_node_matches_module_path(hiplib, which, repla
             # (rounds 0 and 1 sit at 2e-5; in round 2 one max-pool / ReLU decision of the global encoder falls differently in
             # torch's path and puts 2.0e-3 on the layers in front of it -- in the exact-f32 build (1.99e-3) as in the default
             # one (2.01e-3); the float64 anchor below tells a flip from a fault)
-            assert l2(p.grad, q.grad) < 3e-3, (rnd, n, l2(p.grad, q.grad))
+            # (... and the module path is not run-to-run deterministic -- MIOpen's atomics -- so the flip can be on ITS side:
+            # where the two float32 paths are further apart than that, this repo's must be the one closer to float64)
+            d = l2(p.grad, q.grad)
+            assert d < 3e-3 or mine < max(1e-4, theirs), (rnd, n, d, mine, theirs)
         if bad64:
             missed64.append((rnd, bad64))
         for (n, b), q, q64 in zip(mod.named_buffers(), ref.buffers(), ref64.buffers()):
