@@ -559,6 +559,24 @@ size_t ossid_nms_workspace_bytes(int n);
 int ossid_nms(const float* boxes, int n, float iou_threshold, void* workspace, size_t workspace_bytes,
               int32_t* keep, int32_t* num_keep, void* stream);
 
+/* D12  the post-processing of a frame as launches only (network.py:543-566: decode + clip, top-k of the object scores over all
+ * templates, NMS), so that it can live in the frame's captured graph: scores = the object column of the class probabilities
+ * (element i at scores[i * score_stride], n = templates * A of them, i = template * A + anchor), anchors [A][4], deltas [n][4].
+ * Out: the k best scores in decreasing order (ties by increasing index, as ossid_topk), their indices, their decoded and
+ * clipped boxes (the arithmetic of ossid_decode_clip_boxes, applied to the k survivors only), and ossid_nms's keep list over
+ * them with its count. k <= 2048, n % A == 0. Nothing is read back by the host.
+ * ossid_detect_emit then writes the detection list for the first `count` kept candidates (network.py:566-581; the host knows
+ * count = min(*num_keep, topk) by then): row j = candidate keep[j]: score, box, index of the template that fired (as float,
+ * network.py:561), that template's row of seg [templates][seg_row_floats] -- through a sigmoid when seg_sigmoid != 0
+ * (models/dtoid/__init__.py:147) -- and of heat [templates][heat_row_floats]. */
+size_t ossid_detect_post_workspace_bytes(int n, int k);
+int ossid_detect_post(const float* scores, int n, int score_stride, int k, const float* anchors, const float* deltas, int A,
+                      float img_w, float img_h, float iou_threshold, void* workspace, size_t workspace_bytes, float* out_scores,
+                      long long* out_indices, float* out_boxes, int32_t* keep, int32_t* num_keep, void* stream);
+int ossid_detect_emit(const float* scores, const long long* indices, const float* boxes, const int32_t* keep, int count, int A,
+                      const float* seg, long long seg_row_floats, const float* heat, long long heat_row_floats, int seg_sigmoid,
+                      float* out_scores, float* out_boxes, float* out_obj, float* out_seg, float* out_heat, void* stream);
+
 /* D6  `norm(F.elu(conv(image_feat - avg_t)))` (network.py:346) for ONE image against all templates without a convolution
  * per template: conv is linear, so conv(x - a_t) = conv(x) - conv(a_t). S [H][W][channels] = conv(x) + bias, computed
  * once per frame; csub [templates][9][channels] = the response to the per-channel constant image a_t for each of the 9

@@ -128,6 +128,9 @@ _PROTOS = {
     "ossid_conv1x1_c1_bwd": (_i, [_vp, _vp, C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp]),
     "ossid_spatial_mean": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ossid_small_matmul": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ossid_detect_post_workspace_bytes": (_sz, [_i, _i]),
+    "ossid_detect_post": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _f, _f, _f, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ossid_detect_emit": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, C.c_longlong, _vp, C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_dense_fused_available": (_i, []),
     "ossid_dense_table_bytes": (_sz, [_i]),
     "ossid_dense_entry": (_i, [_vp, _i, _i, C.c_longlong, _i, _vp, _vp, _vp]),

@@ -95,6 +95,18 @@ __device__ __forceinline__ float iou(const float4 a, const float4 b) {
     return inter / ua;
 }
 
+// zero n 16-byte units (instead of hipMemsetAsync: these entry points also run inside captured graphs, beside ~190 kernel
+// nodes, where a memset node aborted at replay)
+__global__ __launch_bounds__(256) void zero16_kernel(float4* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+static inline void zero_async(void* p, size_t bytes, hipStream_t s) {      // p 16-byte aligned, bytes a multiple of 16
+    const size_t n = bytes / 16;
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(zero16_kernel, dim3(blocks), dim3(256), 0, s, (float4*)p, n);
+}
+
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ boxes, int n, float thr,
                                                       unsigned long long* __restrict__ mask, int words) {
     const int rb = blockIdx.y, cb = blockIdx.x;
@@ -348,12 +360,15 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float4* __restri
 
 // ---- anchor decode + clip ------------------------------------------------------------------------------------------
 // anchors [A][4] shared by every batch row, deltas [R][A][4] -> boxes [R][A][4]; std (.1,.1,.2,.2), mean 0.
+__device__ __forceinline__ float4 decode_clip_one(const float4 a, const float4 d, float img_w, float img_h);
 __global__ __launch_bounds__(256) void decode_clip_kernel(const float4* __restrict__ anchors,
                                                           const float4* __restrict__ deltas, int A, size_t total,
                                                           float img_w, float img_h, float4* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const float4 a = anchors[i % A], d = deltas[i];
+    out[i] = decode_clip_one(anchors[i % A], deltas[i], img_w, img_h);
+}
+__device__ __forceinline__ float4 decode_clip_one(const float4 a, const float4 d, float img_w, float img_h) {
     const float w = a.z - a.x, h = a.w - a.y;
     const float cx = a.x + 0.5f * w, cy = a.y + 0.5f * h;
     const float dx = d.x * 0.1f, dy = d.y * 0.1f, dw = d.z * 0.2f, dh = d.w * 0.2f;
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(256) void decode_clip_kernel(const float4* __restri
     o.y = fmaxf(pcy - 0.5f * ph, 0.0f);
     o.z = fminf(pcx + 0.5f * pw, img_w);
     o.w = fminf(pcy + 0.5f * ph, img_h);
-    out[i] = o;
+    return o;
 }
 
 // ---- AMSGrad Adam over a flat buffer (torch.optim.Adam(amsgrad=True, weight_decay) semantics) --------------------
@@ -465,7 +480,7 @@ int ossid_nms(const float* boxes, int n, float iou_threshold, void* workspace, s
     if (!boxes || !keep || !workspace || workspace_bytes < ossid_nms_workspace_bytes(n)) return OSSID_EINVAL;
     const int words = (n + 63) / 64;
     unsigned long long* mask = (unsigned long long*)workspace;
-    if (hipMemsetAsync(mask, 0, (size_t)n * words * 8, s) != hipSuccess) return OSSID_ELAUNCH;
+    zero_async(mask, (((size_t)n * words * 8) + 15) / 16 * 16, s);      // (the workspace has 256 spare bytes)
     hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words), dim3(64), 0, s, (const float4*)boxes, n, iou_threshold,
                        mask, words);
     if (words <= 16) {
@@ -581,17 +596,21 @@ __device__ int topk_find_bin(const int* __restrict__ hist, int nbins, int& rem, 
     const int t = threadIdx.x, per = nbins / 256;               // blockDim.x == 256, nbins a multiple of 256
     int seg = 0;
     for (int j = 0; j < per; ++j) seg += hist[nbins - 1 - (t * per + j)];      // thread t owns the t-th segment FROM THE TOP
-    lds[t] = seg;
-    __syncthreads();
-    if (t == 0) {
-        int run = 0, found = 0;
-        for (int i = 0; i < 256; ++i) {
-            if (run + lds[i] >= rem) { found = i; break; }
-            run += lds[i];
-        }
-        lds[256] = found;
-        lds[0] = run;                                            // keys above the segment
+    // inclusive scan of the 256 segment sums (round 3 walked them with one thread: 256 dependent LDS reads, ~8 us per call
+    // and six calls per top-k); the one segment whose range (excl, incl] holds `rem` reports itself
+    const int lane = t & 63, wave = t >> 6;
+    int incl = seg;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
     }
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) incl += lds[w];
+    const int excl = incl - seg;
+    __syncthreads();
+    if (excl < rem && rem <= incl) lds[256] = t, lds[0] = excl;   // (keys above the segment)
     __syncthreads();
     const int segi = lds[256];
     int run = lds[0];
@@ -629,7 +648,7 @@ __device__ TopkState topk_state(const int* __restrict__ hist, int level, int k, 
     return s;
 }
 
-__global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict__ x, int n, int level, int k, int* __restrict__ hist) {
+__global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict__ x, int xs, int n, int level, int k, int* __restrict__ hist) {
     __shared__ int lh[2048];
     __shared__ int scratch[257];
     const TopkState s = topk_state(hist, level, k, scratch);
@@ -637,7 +656,7 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict_
     __syncthreads();
     const int shift = level == 1 ? 21 : (level == 2 ? 10 : 0), bmask = level == 3 ? 1023 : 2047;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const unsigned key = topk_key(x[i]);
+        const unsigned key = topk_key(x[(size_t)i * xs]);
         if ((key & s.mask) == s.prefix) atomicAdd(&lh[(key >> shift) & bmask], 1);
     }
     __syncthreads();
@@ -648,7 +667,7 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict_
 
 // pass 1 (write == 0): per-block counts of (key > T, key == T) over the block's CONTIGUOUS chunk -> counts[block][2].
 // pass 2 (write == 1): positions from the counts of the blocks before; greater elements first (k_gt of them), then ties.
-__global__ __launch_bounds__(256) void topk_gather_kernel(const float* __restrict__ x, int n, int k, const int* __restrict__ hist,
+__global__ __launch_bounds__(256) void topk_gather_kernel(const float* __restrict__ x, int xs, int n, int k, const int* __restrict__ hist,
                                                           int* __restrict__ counts, int write, float* __restrict__ sel_val,
                                                           int* __restrict__ sel_idx) {
     __shared__ int scratch[257];
@@ -673,7 +692,7 @@ __global__ __launch_bounds__(256) void topk_gather_kernel(const float* __restric
     for (int i0 = lo; i0 < hi; i0 += 256) {
         const int i = i0 + threadIdx.x;
         const bool in = i < hi;
-        const float v = in ? x[i] : 0.0f;
+        const float v = in ? x[(size_t)i * xs] : 0.0f;
         const unsigned key = topk_key(v);
         const bool gt = in && key > T, eq = in && key == T;
         const unsigned long long mg = __ballot(gt), me = __ballot(eq);
@@ -702,8 +721,12 @@ __global__ __launch_bounds__(256) void topk_gather_kernel(const float* __restric
 }
 
 // one workgroup: bitonic sort of the k (<= 2048) selected (value, index) pairs, value descending, index ascending
+// boxes != NULL: also decode + clip the box of every survivor (anchors [A][4], deltas [rows][A][4], element i = row i / A):
+// the arithmetic of decode_clip_kernel on k boxes instead of all of them.
 __global__ __launch_bounds__(1024) void topk_sort_kernel(const float* __restrict__ sel_val, const int* __restrict__ sel_idx, int k,
-                                                         float* __restrict__ out_val, long long* __restrict__ out_idx) {
+                                                         float* __restrict__ out_val, long long* __restrict__ out_idx,
+                                                         const float4* __restrict__ anchors, const float4* __restrict__ deltas, int A,
+                                                         float img_w, float img_h, float4* __restrict__ boxes) {
     __shared__ unsigned long long keys[2048];
     for (int i = threadIdx.x; i < 2048; i += 1024)
         keys[i] = i < k ? (((unsigned long long)topk_key(sel_val[i]) << 32) | (unsigned)(~sel_idx[i])) : 0ull;
@@ -722,7 +745,43 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(const float* __restrict
         const unsigned hi = (unsigned)(kk >> 32);
         const unsigned u = (hi & 0x80000000u) ? (hi & 0x7FFFFFFFu) : ~hi;
         out_val[i] = __uint_as_float(u);
-        out_idx[i] = (long long)(~(unsigned)(kk & 0xFFFFFFFFu));
+        const unsigned id = ~(unsigned)(kk & 0xFFFFFFFFu);
+        out_idx[i] = (long long)id;
+        if (boxes) boxes[i] = decode_clip_one(anchors[id % A], deltas[id], img_w, img_h);
+    }
+}
+
+// The detection list of a frame (network.py:566-581) from the sorted candidates and the NMS keep list, ONE launch: row j of
+// every output belongs to candidate keep[j] -- its score, its box, the index of the template that fired (candidate index / A),
+// that template's segmentation map (optionally through the sigmoid of models/dtoid/__init__.py:147) and heat map.
+__global__ __launch_bounds__(256) void detect_emit_kernel(const float* __restrict__ scores, const long long* __restrict__ indices,
+                                                          const float4* __restrict__ boxes, const int* __restrict__ keep, int A,
+                                                          const float* __restrict__ seg, long long seg_row, const float* __restrict__ heat,
+                                                          long long heat_row, int seg_sigmoid, float* __restrict__ o_scores,
+                                                          float4* __restrict__ o_boxes, float* __restrict__ o_obj, float* __restrict__ o_seg,
+                                                          float* __restrict__ o_heat) {
+    const int j = blockIdx.y, c = keep[j];
+    const long long tmpl = indices[c] / A;
+    if (blockIdx.x == 0 && threadIdx.x == 0) o_scores[j] = scores[c], o_boxes[j] = boxes[c], o_obj[j] = (float)tmpl;
+    const size_t t0 = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    if (seg_row) {
+        const float* s = seg + (size_t)tmpl * seg_row;
+        float* o = o_seg + (size_t)j * seg_row;
+        auto sg = [&](float v) { return seg_sigmoid ? 1.0f / (1.0f + expf(-v)) : v; };
+        if ((seg_row & 3) == 0) {
+            for (size_t i = t0; i < (size_t)seg_row / 4; i += step) {
+                float4 v = ((const float4*)s)[i];
+                v.x = sg(v.x), v.y = sg(v.y), v.z = sg(v.z), v.w = sg(v.w);
+                ((float4*)o)[i] = v;
+            }
+        } else {
+            for (size_t i = t0; i < (size_t)seg_row; i += step) o[i] = sg(s[i]);
+        }
+    }
+    if (heat_row) {
+        const float* s = heat + (size_t)tmpl * heat_row;
+        float* o = o_heat + (size_t)j * heat_row;
+        for (size_t i = t0; i < (size_t)heat_row; i += step) o[i] = s[i];
     }
 }
 
@@ -736,23 +795,62 @@ size_t ossid_topk_workspace_bytes(int n, int k) {
     return (size_t)(3 * 2048 + 2 * 512) * sizeof(int) + (size_t)k * (sizeof(float) + sizeof(int)) + 64;
 }
 
-int ossid_topk(const float* scores, int n, int k, void* workspace, size_t workspace_bytes, float* values, long long* indices,
-               void* stream) {
-    if (!scores || !workspace || !values || !indices || n <= 0 || k <= 0 || k > n || k > 2048) return OSSID_EINVAL;
-    if (workspace_bytes < ossid_topk_workspace_bytes(n, k)) return OSSID_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
+static int topk_launch(const float* scores, int stride, int n, int k, void* workspace, float* values, long long* indices,
+                       const float* anchors, const float* deltas, int A, float img_w, float img_h, float* boxes, hipStream_t s) {
     int* hist = (int*)workspace;
     int* counts = hist + 3 * 2048;
     float* sel_val = (float*)(counts + 2 * 512);
     int* sel_idx = (int*)(sel_val + k);
-    if (hipMemsetAsync(hist, 0, 3 * 2048 * sizeof(int), s) != hipSuccess) return OSSID_ELAUNCH;
+    zero_async(hist, 3 * 2048 * sizeof(int), s);
     int blocks = (n + 2047) / 2048;
     if (blocks > 512) blocks = 512;
     for (int level = 1; level <= 3; ++level)
-        hipLaunchKernelGGL(topk_hist_kernel, dim3(blocks), dim3(256), 0, s, scores, n, level, k, hist);
-    hipLaunchKernelGGL(topk_gather_kernel, dim3(blocks), dim3(256), 0, s, scores, n, k, (const int*)hist, counts, 0, sel_val, sel_idx);
-    hipLaunchKernelGGL(topk_gather_kernel, dim3(blocks), dim3(256), 0, s, scores, n, k, (const int*)hist, counts, 1, sel_val, sel_idx);
-    hipLaunchKernelGGL(topk_sort_kernel, dim3(1), dim3(1024), 0, s, (const float*)sel_val, (const int*)sel_idx, k, values, indices);
+        hipLaunchKernelGGL(topk_hist_kernel, dim3(blocks), dim3(256), 0, s, scores, stride, n, level, k, hist);
+    hipLaunchKernelGGL(topk_gather_kernel, dim3(blocks), dim3(256), 0, s, scores, stride, n, k, (const int*)hist, counts, 0, sel_val, sel_idx);
+    hipLaunchKernelGGL(topk_gather_kernel, dim3(blocks), dim3(256), 0, s, scores, stride, n, k, (const int*)hist, counts, 1, sel_val, sel_idx);
+    hipLaunchKernelGGL(topk_sort_kernel, dim3(1), dim3(1024), 0, s, (const float*)sel_val, (const int*)sel_idx, k, values, indices,
+                       (const float4*)anchors, (const float4*)deltas, A, img_w, img_h, (float4*)boxes);
+    return ossid_launch_status();
+}
+
+int ossid_topk(const float* scores, int n, int k, void* workspace, size_t workspace_bytes, float* values, long long* indices,
+               void* stream) {
+    if (!scores || !workspace || !values || !indices || n <= 0 || k <= 0 || k > n || k > 2048) return OSSID_EINVAL;
+    if (workspace_bytes < ossid_topk_workspace_bytes(n, k)) return OSSID_EINVAL;
+    return topk_launch(scores, 1, n, k, workspace, values, indices, nullptr, nullptr, 1, 0.f, 0.f, nullptr, (hipStream_t)stream);
+}
+
+size_t ossid_detect_post_workspace_bytes(int n, int k) {
+    return ((ossid_topk_workspace_bytes(n, k) + 255) / 256) * 256 + ossid_nms_workspace_bytes(k);
+}
+
+int ossid_detect_post(const float* scores, int n, int score_stride, int k, const float* anchors, const float* deltas, int A,
+                      float img_w, float img_h, float iou_threshold, void* workspace, size_t workspace_bytes, float* out_scores,
+                      long long* out_indices, float* out_boxes, int32_t* keep, int32_t* num_keep, void* stream) {
+    if (!scores || !anchors || !deltas || !workspace || !out_scores || !out_indices || !out_boxes || !keep || !num_keep) return OSSID_EINVAL;
+    if (n <= 0 || k <= 0 || k > n || k > 2048 || A <= 0 || score_stride <= 0 || (n % A)) return OSSID_EINVAL;
+    if (workspace_bytes < ossid_detect_post_workspace_bytes(n, k)) return OSSID_EINVAL;
+    const int rc = topk_launch(scores, score_stride, n, k, workspace, out_scores, out_indices, anchors, deltas, A, img_w, img_h,
+                               out_boxes, (hipStream_t)stream);
+    if (rc != OSSID_OK) return rc;
+    char* nms_ws = (char*)workspace + ((ossid_topk_workspace_bytes(n, k) + 255) / 256) * 256;
+    return ossid_nms(out_boxes, k, iou_threshold, nms_ws, ossid_nms_workspace_bytes(k), keep, num_keep, stream);
+}
+
+int ossid_detect_emit(const float* scores, const long long* indices, const float* boxes, const int32_t* keep, int count, int A,
+                      const float* seg, long long seg_row_floats, const float* heat, long long heat_row_floats, int seg_sigmoid,
+                      float* out_scores, float* out_boxes, float* out_obj, float* out_seg, float* out_heat, void* stream) {
+    if (count < 0 || count > 65535 || A <= 0 || seg_row_floats < 0 || heat_row_floats < 0) return OSSID_EINVAL;
+    if (count == 0) return OSSID_OK;
+    if (!scores || !indices || !boxes || !keep || !out_scores || !out_boxes || !out_obj) return OSSID_EINVAL;
+    if ((seg_row_floats && (!seg || !out_seg)) || (heat_row_floats && (!heat || !out_heat))) return OSSID_EINVAL;
+    const long long most = seg_row_floats / 4 > heat_row_floats ? seg_row_floats / 4 : heat_row_floats;
+    unsigned gx = (unsigned)((most + 255) / 256);
+    if (gx < 1) gx = 1;
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(detect_emit_kernel, dim3(gx, count), dim3(256), 0, (hipStream_t)stream, scores, indices, (const float4*)boxes, keep,
+                       A, seg, seg_row_floats, heat, heat_row_floats, seg_sigmoid, out_scores, (float4*)out_boxes, out_obj, out_seg,
+                       out_heat);
     return ossid_launch_status();
 }
 

@@ -1087,15 +1087,19 @@ class Network(nn.Module):
         with torch.no_grad():
             return self._graphed_dense_impl(*args, **kwargs)
 
-    def _graphed_dense_impl(self, image, template_features, template_global, head_only=False, raw_image=False):
+    def _graphed_dense_impl(self, image, template_features, template_global, head_only=False, raw_image=False, post_hw=None):
         """The dense part replayed from a captured hipGraph (the B=1 backbone alone is ~500 launches and otherwise
         host-bound). One graph per (input shape, chunk sizes, packed-head identity); inputs are copied into the
         graph's static buffers, outputs are read from them. head_only: `image` is already the feature map [1,640,h,w]
         (the batched test-time path runs the backbone once for the whole batch and replays this graph per image)."""
         fused = self._fused_head() if self.use_fused_head else None
         fused_bb = self._fused_backbone() if (self.use_fused_backbone and not head_only) else None
+        # post_hw = (H, W) of the frame: the device-only part of the post-processing (candidates, NMS: post_dense) is captured
+        # behind the dense part; the ops.DetectPost it fills is left in self._graph_post for post_emit
+        if post_hw is not None and not (self.use_fused_post and self.use_fused_head):
+            post_hw = None
         key = (tuple(image.shape), tuple(int(c.shape[0]) for c in template_features), id(fused), id(fused_bb),
-               str(image.device), bool(head_only), bool(raw_image))
+               str(image.device), bool(head_only), bool(raw_image), None if post_hw is None else tuple(post_hw))
         cache = self.__dict__.setdefault("_graph_cache", {})
         entry = cache.get(key)
         if entry is None:
@@ -1108,8 +1112,15 @@ class Network(nn.Module):
             # the template-only part of the correlation lives OUTSIDE the graph, in static buffers refreshed only when the
             # templates or the weights change (below)
             s_sides = [fused.template_side(c) for c in s_tf] if fused is not None else None
-            run = (lambda: self._dense_head(s_img, s_tf, s_sides)) if head_only else \
+            dense = (lambda: self._dense_head(s_img, s_tf, s_sides)) if head_only else \
                 (lambda: self._dense_all_templates(s_img, s_tf, s_g, s_sides, raw_image))
+            post_box = [None]
+
+            def run():
+                outs = dense()
+                if post_hw is not None and outs[1].shape[0] * outs[1].shape[1] >= 1:
+                    post_box[0] = self.post_dense(outs[0], outs[1], outs[4], post_hw, post_box[0])
+                return outs
             with torch.cuda.stream(side):           # warm-up off the capture: MIOpen picks its kernels here
                 for _ in range(2):
                     run()
@@ -1117,9 +1128,10 @@ class Network(nn.Module):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 outs = run()
-            entry = [graph, s_img, s_tf, s_g, outs, (fused, fused_bb), s_sides, None]
+            entry = [graph, s_img, s_tf, s_g, outs, (fused, fused_bb), s_sides, None, post_box[0]]
             cache[key] = entry
-        graph, s_img, s_tf, s_g, outs, _, s_sides, last = entry
+        graph, s_img, s_tf, s_g, outs, _, s_sides, last, post = entry
+        self.__dict__["_graph_post"] = post
         s_img.copy_(image)
         if s_g is not None:
             s_g.copy_(template_global)
@@ -1160,7 +1172,11 @@ class Network(nn.Module):
             for i in range(images.shape[0]):
                 f = feats[i:i + 1]
                 if self.use_graph and f.is_cuda and not self.training:
-                    dense = self._graphed_dense(f, template_features, None, head_only=True)
+                    dense = self._graphed_dense(f, template_features, None, head_only=True, post_hw=hw)
+                    post = self.__dict__.get("_graph_post")
+                    if post is not None:
+                        out.append(self.post_emit(post, dense[2], dense[3], topk, seg_sigmoid))
+                        continue
                 else:
                     dense = self._dense_head(f, template_features)
                 out.append(self.postprocess(*dense, hw, topk, seg_sigmoid))
@@ -1175,7 +1191,11 @@ class Network(nn.Module):
             if self.use_graph and image.is_cuda and not self.training:
                 cls_all, reg_all, seg_all, heat_all, fmap = self._graphed_dense(image, template_features,
                                                                                 template_features_global[0],
-                                                                                raw_image=raw_image)
+                                                                                raw_image=raw_image,
+                                                                                post_hw=(image.shape[2], image.shape[3]))
+                post = self.__dict__.get("_graph_post")
+                if post is not None:       # candidates + NMS ran inside the graph: only the count and one gather launch are left
+                    return self.post_emit(post, seg_all, heat_all, topk, seg_sigmoid)
             else:
                 cls_all, reg_all, seg_all, heat_all, fmap = self._dense_all_templates(image, template_features,
                                                                                       template_features_global[0],
@@ -1183,12 +1203,33 @@ class Network(nn.Module):
             return self.postprocess(cls_all, reg_all, seg_all, heat_all, fmap, (image.shape[2], image.shape[3]), topk,
                                     seg_sigmoid)
 
+    use_fused_post = os.environ.get("OSSID_FUSED_POST", "1") != "0"
+
+    def post_dense(self, cls_all, reg_all, fmap, img_hw, state=None):
+        """The part of postprocess that needs no host decision (decode + clip of the candidates, top-1000 object scores over
+        all templates, NMS 0.5: network.py:543-566) as launches only (ops.detect_post): it can be captured with the dense
+        part of the frame. Returns the ops.DetectPost holding the candidates, the keep list and its count."""
+        anchors = self.anchors([list(fmap)], device=reg_all.device)
+        n_t, A = int(reg_all.shape[0]), int(reg_all.shape[1])
+        return ops.detect_post(cls_all, reg_all, anchors, img_hw[1], img_hw[0], min(1000, n_t * A), 0.5, state)
+
+    def post_emit(self, post, seg_all, heat_all, topk, seg_sigmoid):
+        """The host's one decision -- how many candidates survived -- and the detection list for the first `topk` of them
+        (network.py:566-581) in one launch."""
+        post.count_host.copy_(post.count, non_blocking=True)
+        torch.cuda.current_stream(post.scores.device).synchronize()
+        count = min(int(post.count_host[0]), int(topk))
+        return ops.detect_emit(post, count, seg_all[:, 0], heat_all[:, 0], seg_sigmoid)
+
     def postprocess(self, cls_all, reg_all, seg_all, heat_all, fmap, img_hw, topk=1, seg_sigmoid=False):
         """Dense head outputs of ONE image (cls [n_t,A,2], reg [n_t,A,4], seg [n_t,1,H,W], heat [n_t,1,hh,hw]) -> the
         reference's detection list (network.py:543-581: decode + clip, top-1000 object scores over all templates, NMS 0.5,
         first `topk`, per-detection segmentation / heat map of the template that fired). Everything stays on the device."""
         with torch.no_grad():
             n_t, A = reg_all.shape[0], reg_all.shape[1]
+            if reg_all.is_cuda and self.use_fused_post and min(1000, n_t * A) <= 2048:
+                post = self.post_dense(cls_all, reg_all, fmap, img_hw)
+                return self.post_emit(post, seg_all, heat_all, topk, seg_sigmoid)
             anchors = self.anchors([list(fmap)], device=reg_all.device)
             boxes = ops.decode_clip_boxes(anchors, reg_all, img_hw[1], img_hw[0]).view(-1, 4)
             k = min(1000, n_t * A)

@@ -116,6 +116,71 @@ def topk_scores(scores, k):
     return vals, idx
 
 
+class DetectPost:
+    """Device-side state of one frame's post-processing (ossid_detect_post): the k best object scores in decreasing order, their
+    flat indices (template * A + anchor), their decoded + clipped boxes, the NMS keep list over them and its count. Everything is
+    written by launches only -- no read-back -- so the call can sit inside the frame's captured graph; `count_host` (pinned) is
+    where the caller copies the count to afterwards (outside any capture: a device-to-host copy node aborted at replay)."""
+
+    def __init__(self, n, k, A, device):
+        self.n, self.k, self.A = n, k, A
+        self.scores = torch.empty(k, dtype=torch.float32, device=device)
+        self.indices = torch.empty(k, dtype=torch.int64, device=device)
+        self.boxes = torch.empty((k, 4), dtype=torch.float32, device=device)
+        self.keep = torch.empty(k, dtype=torch.int32, device=device)
+        self.count = torch.zeros(1, dtype=torch.int32, device=device)
+        self.count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.ws = torch.empty(_lib.fn("ossid_detect_post_workspace_bytes")(n, k), dtype=torch.uint8, device=device)
+
+
+def detect_post(cls_all, reg_all, anchors, img_w, img_h, k, iou_threshold=0.5, state=None):
+    """network.py:543-566 on the device: cls_all [n_t, A, 2] (class 1 = object), reg_all [n_t, A, 4], anchors [1, A, 4] ->
+    DetectPost. Launches only (capturable)."""
+    _lib.require_cuda(cls_all, reg_all, anchors)
+    n_t, A = int(reg_all.shape[0]), int(reg_all.shape[1])
+    n = n_t * A
+    cls_all, reg_all = cls_all.detach(), reg_all.detach()
+    if cls_all.dtype != torch.float32 or not cls_all.is_contiguous() or cls_all.shape[-1] != 2:
+        cls_all = cls_all.float().contiguous()
+    if reg_all.dtype != torch.float32 or not reg_all.is_contiguous():
+        reg_all = reg_all.float().contiguous()
+    a = anchors.reshape(-1, 4)
+    if a.dtype != torch.float32 or not a.is_contiguous():
+        a = a.float().contiguous()
+    if state is None or state.n != n or state.k != k or state.A != A or state.scores.device != reg_all.device:
+        state = DetectPost(n, k, A, reg_all.device)
+    with _lib.on_device(reg_all.device):
+        _lib.check(_lib.fn("ossid_detect_post")(cls_all.data_ptr() + 4, n, 2, k, a.data_ptr(), reg_all.data_ptr(), A, float(img_w),
+                                                float(img_h), float(iou_threshold), state.ws.data_ptr(), state.ws.numel(),
+                                                state.scores.data_ptr(), state.indices.data_ptr(), state.boxes.data_ptr(),
+                                                state.keep.data_ptr(), state.count.data_ptr(), _lib.stream()), "ossid_detect_post")
+    state._inputs = (cls_all, reg_all, a)          # (alive until the launches have run)
+    return state
+
+
+def detect_emit(state, count, seg_all, heat_all, seg_sigmoid=False):
+    """The detection list of network.py:566-581 for the first `count` kept candidates of a DetectPost, ONE launch:
+    [scores [c], boxes [c,4], template index [c,1] (float), seg [c,H,W], heat [c,hh,hw]]. seg_all [n_t,H,W], heat_all [n_t,hh,hw]."""
+    dev = state.scores.device
+    seg_all = seg_all if (seg_all.dtype == torch.float32 and seg_all.is_contiguous()) else seg_all.float().contiguous()
+    heat_all = heat_all if (heat_all.dtype == torch.float32 and heat_all.is_contiguous()) else heat_all.float().contiguous()
+    o_s = torch.empty(count, dtype=torch.float32, device=dev)
+    o_b = torch.empty((count, 4), dtype=torch.float32, device=dev)
+    o_o = torch.empty((count, 1), dtype=torch.float32, device=dev)
+    o_seg = torch.empty((count,) + tuple(seg_all.shape[1:]), dtype=torch.float32, device=dev)
+    o_heat = torch.empty((count,) + tuple(heat_all.shape[1:]), dtype=torch.float32, device=dev)
+    if count:
+        seg_row = int(seg_all[0].numel())
+        heat_row = int(heat_all[0].numel())
+        with _lib.on_device(dev):
+            _lib.check(_lib.fn("ossid_detect_emit")(state.scores.data_ptr(), state.indices.data_ptr(), state.boxes.data_ptr(),
+                                                    state.keep.data_ptr(), count, state.A, seg_all.data_ptr(), seg_row,
+                                                    heat_all.data_ptr(), heat_row, 1 if seg_sigmoid else 0, o_s.data_ptr(),
+                                                    o_b.data_ptr(), o_o.data_ptr(), o_seg.data_ptr(), o_heat.data_ptr(),
+                                                    _lib.stream()), "ossid_detect_emit")
+    return [o_s, o_b, o_o, o_seg, o_heat]
+
+
 _IMNORM = {}
 
 

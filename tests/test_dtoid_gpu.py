@@ -1124,3 +1124,29 @@ def test_head_remainder_kernels_match_torch(hiplib):
         assert got.shape == want.shape and rel(got, want) < 1e-6 and rel(xg.grad, x64.grad) < 1e-6
     a, b = torch.randn(21, 640, generator=g), torch.randn(640, 2304, generator=g)
     assert rel(ops.small_matmul(a.cuda(), b.cuda()), a.double() @ b.double()) < 1e-5
+
+
+@pytest.mark.parametrize("n_t,topk,spread", [(21, 500, 1.0), (3, 5, 1.0), (21, 500, 0.02), (1, 1, 1.0)])
+def test_fused_post_processing_equals_the_step_by_step_one(hiplib, n_t, topk, spread, monkeypatch):
+    """ossid_detect_post + ossid_detect_emit (decode of the candidates only, top-k on the strided object column, NMS, one
+    gather launch) against the step-by-step path (decode of every box, ossid_topk, index, ossid_nms, gathers): the same
+    detection list, bit for bit -- also with heavily tied scores (spread 0.02: quantised probabilities) and with boxes that
+    overlap enough for NMS to drop most candidates."""
+    torch.manual_seed(n_t * 7 + topk)
+    net = dtoid.Network(img_size=(480, 640), heatmap_size=(29, 39)).cuda().eval()
+    H, W, hh, hw = 480, 640, 29, 39
+    A = hh * hw * 24
+    cls = torch.rand(n_t, A, 2, device="cuda")
+    if spread < 1:
+        cls = (cls / spread).round() * spread
+    reg = torch.randn(n_t, A, 4, device="cuda") * 0.5
+    seg = torch.randn(n_t, 1, H, W, device="cuda")
+    heat = torch.rand(n_t, 1, hh, hw, device="cuda")
+    outs = {}
+    for fused in (False, True):
+        monkeypatch.setattr(dtoid.Network, "use_fused_post", fused)
+        outs[fused] = net.postprocess(cls, reg, seg, heat, (hh, hw), (H, W), topk, True)
+    for a, b in zip(outs[False], outs[True]):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        assert torch.equal(a, b)
+    assert 1 <= outs[True][0].shape[0] <= topk
