@@ -132,6 +132,8 @@ class FusedAMSGrad:
         # the kernel wrote the parameters behind autograd's back: bump their version counters so that anything keyed on
         # them (the packed test-time plans of dtoid.Network) notices the update
         torch.autograd.graph.increment_version(self._params)
+        from . import network
+        network.PARAM_EPOCH[0] += 1             # (the next test-time frame checks its plans BEFORE it launches)
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
