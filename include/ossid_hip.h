@@ -494,6 +494,16 @@ int ossid_stem_conv_wgrad(const float* img_nchw, const float* dy, int B, int Cin
  * 0 (one kernel set for the whole batch). */
 int ossid_stem_tail_nhwc(const float* x0, const float* kernels, int kernels_batch_stride, const float* scale, const float* shift,
                          int B, int H, int W, int C, float* out, void* stream);
+/* D4 at test time, fused further: ossid_stem_tail_pool_nhwc = ossid_stem_tail_nhwc followed by pool0 = nn.MaxPool2d(3, 2, 1)
+ * (network.py:170-179) in one pass, written into the first C channels of a buffer with out_channel_stride floats per pixel (the
+ * dense block's resident buffer): out [B][Ho][Wo][out_channel_stride], Ho = (H - 1) / 2 + 1.
+ * ossid_bn_relu_avgpool2_nhwc: relu(scale * x + shift) averaged over 2 x 2 windows (stride 1 or 2) -- the front of a DenseNet
+ * transition (norm -> relu -> conv 1x1 -> AvgPool2d) with the pool moved in front of the bias-free 1x1 convolution, with which
+ * it commutes: x [B][H][W][in_channel_stride] (first C channels) -> out [B][Ho][Wo][C]. */
+int ossid_stem_tail_pool_nhwc(const float* x0, const float* kernels, int kernels_batch_stride, const float* scale, const float* shift,
+                              int B, int H, int W, int C, float* out, int out_channel_stride, void* stream);
+int ossid_bn_relu_avgpool2_nhwc(const float* x, int B, int H, int W, int C, int in_channel_stride, const float* scale,
+                                const float* shift, int stride, float* out, void* stream);
 /* D2-D4  nn.MaxPool2d(k, stride, padding, ceil_mode) channels-last (DenseNet pool0: 3, 2, 1; SqueezeNet: 3, 2, 0, ceil). */
 int ossid_maxpool_nhwc(const float* x, int B, int H, int W, int C, int k, int stride, int pad, int ceil_mode, float* out,
                        void* stream);

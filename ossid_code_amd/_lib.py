@@ -139,6 +139,8 @@ _PROTOS = {
     "ossid_stem_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "ossid_stem_conv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _i, _vp]),
     "ossid_stem_tail_nhwc": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ossid_stem_tail_pool_nhwc": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "ossid_bn_relu_avgpool2_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "ossid_maxpool_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ossid_dw_add_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ossid_dw_add_stats_partials": (_i, [_i, _i, _i, _i]),

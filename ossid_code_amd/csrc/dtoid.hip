@@ -931,6 +931,103 @@ __global__ __launch_bounds__(256) void stem_tail_kernel(const float4* __restrict
                          fmaxf(acc.w * sc.w + sh.w, 0.f));
 }
 
+// Test time, one pass: relu(norm0(x0 + dw(x0, k))) and pool0 = MaxPool2d(3, 2, 1) behind it (network.py:170-179), without the
+// full-resolution tensor in between (19.7 MB written and re-read at 480 x 640: stem_tail 48 us + max-pool 8 us + a copy into the
+// dense block's buffer 6 us). A thread owns 4 channels of TWO neighbouring pooled pixels of a row: the 5 x 7 window of x0 under
+// them is loaded in one go (35 independent 16-byte reads), the 3 x 5 modulated values are formed once and shared by the two
+// pooling windows; the result goes straight into the first channels of the block buffer (out_cs floats per pixel).
+__global__ __launch_bounds__(256) void stem_tail_pool_kernel(const float4* __restrict__ x0, const float* __restrict__ kern, int kern_bs,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             int H, int W, int C4, int Ho, int Wo, int strips, size_t total,
+                                                             float* __restrict__ out, int out_cs) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int xo0 = (int)(r % strips) * 2;
+    r /= strips;
+    const int yo = (int)(r % Ho), b = (int)(r / Ho);
+    const float* kk = kern + (size_t)b * kern_bs + (size_t)c4 * 36;          // 4 channels x 9 taps
+    float w[36];
+#pragma unroll
+    for (int t = 0; t < 36; ++t) w[t] = kk[t];
+    const float4 sc = *(const float4*)(scale + 4 * c4), sh = *(const float4*)(shift + 4 * c4);
+    const int ya = 2 * yo - 2, xa = 2 * xo0 - 2;                             // window origin in x0
+    float4 v[5][7];
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy) {
+        const int y = ya + dy;
+        const bool rv = y >= 0 && y < H;
+        const int yc = min(max(y, 0), H - 1);
+#pragma unroll
+        for (int dx = 0; dx < 7; ++dx) {
+            const int x = xa + dx;
+            const float4 q = x0[(((size_t)b * H + yc) * W + min(max(x, 0), W - 1)) * C4 + c4];
+            const float f = (rv && x >= 0 && x < W) ? 1.0f : 0.0f;         // zero padding of the depthwise convolution
+            v[dy][dx] = make_float4(f * q.x, f * q.y, f * q.z, f * q.w);
+        }
+    }
+    float4 best[2];
+    best[0] = best[1] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int my = 0; my < 3; ++my) {                                         // modulated pixel (ya + 1 + my, xa + 1 + mx)
+        const int y = ya + 1 + my;
+        if (y < 0 || y >= H) continue;                                       // max-pool padding: not a candidate
+#pragma unroll
+        for (int mx = 0; mx < 5; ++mx) {
+            const int x = xa + 1 + mx;
+            if (x < 0 || x >= W) continue;
+            float4 acc = v[my + 1][mx + 1];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float4 q = v[my + dy][mx + dx];
+                    const int t = dy * 3 + dx;
+                    acc.x = fmaf(q.x, w[t], acc.x), acc.y = fmaf(q.y, w[9 + t], acc.y);
+                    acc.z = fmaf(q.z, w[18 + t], acc.z), acc.w = fmaf(q.w, w[27 + t], acc.w);
+                }
+            const float4 a = make_float4(fmaxf(acc.x * sc.x + sh.x, 0.f), fmaxf(acc.y * sc.y + sh.y, 0.f),
+                                         fmaxf(acc.z * sc.z + sh.z, 0.f), fmaxf(acc.w * sc.w + sh.w, 0.f));
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+                if (mx >= 2 * o && mx <= 2 * o + 2)
+                    best[o] = make_float4(fmaxf(best[o].x, a.x), fmaxf(best[o].y, a.y), fmaxf(best[o].z, a.z), fmaxf(best[o].w, a.w));
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+        if (xo0 + o < Wo) *(float4*)(out + (((size_t)b * Ho + yo) * Wo + xo0 + o) * out_cs + 4 * c4) = best[o];
+}
+
+// relu(scale * x + shift) averaged over 2 x 2 windows (stride 1 or 2): the front of a DenseNet transition at test time with the
+// pool moved IN FRONT of the 1x1 convolution (norm -> relu -> conv -> pool of network.py:164-184's densenet121; a bias-free 1x1
+// convolution and an average commute), so that the convolution runs on a quarter of the pixels. x [B][H][W][in_cs] (first C
+// channels), out [B][Ho][Wo][C].
+__global__ __launch_bounds__(256) void bn_relu_avgpool2_kernel(const float* __restrict__ x, int in_cs, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int H, int W, int C4, int stride,
+                                                               int Ho, int Wo, size_t total, float4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int xo = (int)(r % Wo);
+    r /= Wo;
+    const int yo = (int)(r % Ho), b = (int)(r / Ho);
+    const float4 sc = *(const float4*)(scale + 4 * c4), sh = *(const float4*)(shift + 4 * c4);
+    float4 q[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        q[e] = *(const float4*)(x + (((size_t)b * H + yo * stride + (e >> 1)) * W + xo * stride + (e & 1)) * in_cs + 4 * c4);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s.x += fmaxf(q[e].x * sc.x + sh.x, 0.f), s.y += fmaxf(q[e].y * sc.y + sh.y, 0.f);
+        s.z += fmaxf(q[e].z * sc.z + sh.z, 0.f), s.w += fmaxf(q[e].w * sc.w + sh.w, 0.f);
+    }
+    out[i] = make_float4(0.25f * s.x, 0.25f * s.y, 0.25f * s.z, 0.25f * s.w);
+}
+
 __global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const float4* __restrict__ x, int H, int W, int C4, int k, int stride,
                                                            int pad, int Ho, int Wo, size_t total, float4* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -978,6 +1075,31 @@ int ossid_stem_tail_nhwc(const float* x0, const float* kernels, int kernels_batc
     const size_t total = (size_t)B * H * W * (C / 4);
     hipLaunchKernelGGL(stem_tail_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)x0, kernels, kernels_batch_stride, scale, shift, H, W, C / 4, total, (float4*)out);
+    return ossid_launch_status();
+}
+
+int ossid_stem_tail_pool_nhwc(const float* x0, const float* kernels, int kernels_batch_stride, const float* scale, const float* shift,
+                              int B, int H, int W, int C, float* out, int out_channel_stride, void* stream) {
+    if (!x0 || !kernels || !scale || !shift || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || kernels_batch_stride < 0 ||
+        out_channel_stride < C || out_channel_stride % 4)
+        return OSSID_EINVAL;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, strips = (Wo + 1) / 2;
+    const size_t total = (size_t)B * Ho * strips * (C / 4);
+    hipLaunchKernelGGL(stem_tail_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x0, kernels, kernels_batch_stride, scale, shift, H, W, C / 4, Ho, Wo, strips, total, out,
+                       out_channel_stride);
+    return ossid_launch_status();
+}
+
+int ossid_bn_relu_avgpool2_nhwc(const float* x, int B, int H, int W, int C, int in_channel_stride, const float* scale,
+                                const float* shift, int stride, float* out, void* stream) {
+    if (!x || !scale || !shift || !out || B <= 0 || H < 2 || W < 2 || C <= 0 || C % 4 || in_channel_stride < C ||
+        in_channel_stride % 4 || (stride != 1 && stride != 2))
+        return OSSID_EINVAL;
+    const int Ho = (H - 2) / stride + 1, Wo = (W - 2) / stride + 1;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(bn_relu_avgpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       in_channel_stride, scale, shift, H, W, C / 4, stride, Ho, Wo, total, (float4*)out);
     return ossid_launch_status();
 }
 

@@ -626,15 +626,32 @@ class FusedBackbone:
             dst.copy_(src)
 
     use_fused_stem = os.environ.get("OSSID_FUSED_STEM", "1") != "0"
+    # stem_tail + pool0 in one pass, transitions with the pool in front of the 1x1 convolution, both written straight into the
+    # next dense block's buffer
+    use_pooled_transitions = os.environ.get("OSSID_POOLED_TRANSITIONS", "1") != "0"
     # a dense block of at most this many pixels (batch x height x width) takes the one-launch-per-layer form
     DENSE_FUSED_MAX_PIXELS = int(os.environ.get("OSSID_DENSE_FUSED_MAX_PIXELS", "6000"))
 
     def __call__(self, image, template_feat, raw_image=False):
         """raw_image: `image` is in [0, 1] and normalizeImageRange is applied inside the stem's gather (D1)."""
         ife = self.ife
+        def block_buffer(si, B, C, H, W):
+            """The resident buffer of the dense block at stage si (None if that stage is no block): its producer -- the stem's
+            pooling pass, a transition's convolution -- writes the block's input straight into the first C channels."""
+            if si >= len(self.stages) or self.stages[si][0] != "block":
+                return None
+            mod = self.stages[si][1]
+            return torch.empty((B, C + mod.nlayers * mod.growth, H, W), dtype=torch.float32, device=image.device,
+                               memory_format=torch.channels_last)
+        pending = None                      # the next block's buffer, already holding its input
         if self.use_fused_stem:
             x0 = ops.stem_conv(image, ife.backdense_0[0], normalize=raw_image)
-            x = ops.maxpool_nhwc(ops.stem_tail(x0, template_feat, *self.norm0_affine), 3, 2, 1)
+            B, C, H0, W0 = x0.shape
+            pending = block_buffer(0, B, C, (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1) if self.use_pooled_transitions else None
+            x = ops.stem_tail_pool(x0, template_feat, *self.norm0_affine, out=pending) if self.use_pooled_transitions else \
+                ops.maxpool_nhwc(ops.stem_tail(x0, template_feat, *self.norm0_affine), 3, 2, 1)
+            if pending is not None:
+                x = pending[:, :C]
         else:
             if raw_image:
                 from .model import normalizeImageRange
@@ -646,13 +663,16 @@ class FusedBackbone:
             for m in self.stem:
                 x = m(x)
             x = x.contiguous(memory_format=torch.channels_last)
-        for kind, mod, packed in self.stages:
+        for si, (kind, mod, packed) in enumerate(self.stages):
             B, C, H, W = x.shape
             if kind == "block":
                 ctot = C + mod.nlayers * mod.growth
-                buf = torch.empty((B, ctot, H, W), dtype=torch.float32, device=x.device,
-                                  memory_format=torch.channels_last)
-                buf[:, :C] = x
+                if pending is not None:
+                    buf, pending = pending, None
+                else:
+                    buf = torch.empty((B, ctot, H, W), dtype=torch.float32, device=x.device,
+                                      memory_format=torch.channels_last)
+                    buf[:, :C] = x
                 table = mod.__dict__.get("_ossid_dense_table")
                 if table is not None and B * H * W <= self.DENSE_FUSED_MAX_PIXELS and C in (64, 128, 256, 512):
                     # few pixels (a single frame): one launch per layer, the later layers' bottleneck sums kept up to date
@@ -669,7 +689,19 @@ class FusedBackbone:
                 x = buf
             else:
                 st = mod.pool.stride if isinstance(mod.pool.stride, int) else mod.pool.stride[0]
-                x = ops.avgpool2_nhwc(packed(x), st)
+                if self.use_pooled_transitions and mod.conv.bias is None and st in (1, 2) and H >= 2 and W >= 2:
+                    # norm -> relu -> conv 1x1 -> avg-pool with the pool moved in front of the (bias-free, linear, pixelwise)
+                    # convolution: one pass that normalises, rectifies and averages, then the convolution on the pooled
+                    # pixels (a quarter of them at stride 2), written straight into the next block's buffer
+                    pooled = ops.bn_relu_avgpool2(x, C, packed.pre_scale, packed.pre_shift, st)
+                    Ho, Wo = int(pooled.shape[2]), int(pooled.shape[3])
+                    pending = block_buffer(si + 1, B, packed.cout, Ho, Wo)
+                    out = pending if pending is not None else torch.empty((B, packed.cout, Ho, Wo), dtype=torch.float32,
+                                                                          device=x.device, memory_format=torch.channels_last)
+                    packed.run(pooled, B, Ho, Wo, out, out_cs=int(out.shape[1]), skip_pre=True)
+                    x = out[:, :packed.cout]
+                else:
+                    x = ops.avgpool2_nhwc(packed(x), st)
         return self.final(x)
 
 

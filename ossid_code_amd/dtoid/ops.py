@@ -324,6 +324,36 @@ def stem_tail(x0, kernels, scale, shift):
     return out
 
 
+def stem_tail_pool(x0, kernels, scale, shift, out=None):
+    """maxpool(3, 2, 1) of relu(scale * (x0 + dw_xcorr(x0, kernels)) + shift) in one pass (test time: stem_tail + pool0 of
+    DenseNet). out: a channels-last [B, >= C, Ho, Wo] tensor whose first C channels receive the result (a dense block's
+    resident buffer); None = a fresh [B, C, Ho, Wo]."""
+    B, C, H, W = x0.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    k = kernels.detach().float().contiguous()
+    if out is None:
+        out = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x0.device, memory_format=torch.channels_last)
+    elif tuple(out.shape[2:]) != (Ho, Wo) or out.shape[0] != B or out.shape[1] < C or not out.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError("stem_tail_pool: out must be a channels-last [B, >= C, Ho, Wo] tensor")
+    with _lib.on_device(x0.device):
+        rc = _lib.fn("ossid_stem_tail_pool_nhwc")(x0.data_ptr(), k.data_ptr(), 0 if k.shape[0] == 1 else C * 9, scale.data_ptr(),
+                                                  shift.data_ptr(), B, H, W, C, out.data_ptr(), int(out.shape[1]), _lib.stream())
+    _lib.check(rc, "ossid_stem_tail_pool_nhwc")
+    return out
+
+
+def bn_relu_avgpool2(x, C, scale, shift, stride):
+    """avgpool2x2(relu(scale * x[:, :C] + shift), stride) on a channels-last x [B, >= C, H, W] -> [B, C, Ho, Wo] (the front of
+    a DenseNet transition with the pool moved in front of its bias-free 1x1 convolution)."""
+    B, ctot, H, W = x.shape
+    Ho, Wo = (H - 2) // stride + 1, (W - 2) // stride + 1
+    out = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with _lib.on_device(x.device):
+        _lib.check(_lib.fn("ossid_bn_relu_avgpool2_nhwc")(x.data_ptr(), B, H, W, C, int(ctot), scale.data_ptr(), shift.data_ptr(),
+                                                          stride, out.data_ptr(), _lib.stream()), "ossid_bn_relu_avgpool2_nhwc")
+    return out
+
+
 def maxpool_nhwc(x, k, stride, pad=0, ceil_mode=False):
     """nn.MaxPool2d(k, stride, pad, ceil_mode=ceil_mode) on a channels-last tensor."""
     B, C, H, W = x.shape
@@ -499,17 +529,19 @@ class PackedConv:
                 sc.copy_(a)
                 sh.copy_(b)
 
-    def _desc(self, x_nhwc, B, H, W, out_nhwc, in_cs=0, out_cs=0, out_coff=0, src_hw=(0, 0), in_bs=-1, pre=None):
+    def _desc(self, x_nhwc, B, H, W, out_nhwc, in_cs=0, out_cs=0, out_coff=0, src_hw=(0, 0), in_bs=-1, pre=None, skip_pre=False):
         """(ossid_conv_desc, entry name) of one launch; the Winograd form when the layer has it and the launch fills the chip."""
         d = _lib.ConvDesc()
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         d.x, d.wpk, d.bias, d.out = x_nhwc.data_ptr(), self.wpk.data_ptr(), p(self.bias), out_nhwc.data_ptr()
         d.pre_scale, d.pre_shift, d.post_scale, d.post_shift = p(self.pre_scale), p(self.pre_shift), p(self.scale), p(self.shift)
         d.in_batch_stride, d.pre_batch_stride = in_bs, 0
+        if skip_pre:                 # the caller has applied the input affine (+ReLU) itself (pooled transitions)
+            d.pre_scale = d.pre_shift = None
         if pre is not None:
             d.pre_scale, d.pre_shift, d.pre_batch_stride = pre[0].data_ptr(), pre[1].data_ptr(), self.cin
         d.batch, d.height, d.width, d.cin, d.cout, d.taps = B, H, W, self.cin, self.cout, self.taps
-        d.act, d.pre_relu = self.act, self.pre_relu
+        d.act, d.pre_relu = self.act, (0 if skip_pre else self.pre_relu)
         d.src_height, d.src_width = int(src_hw[0]), int(src_hw[1])
         d.in_channel_stride, d.out_channel_stride, d.out_channel_offset = in_cs, out_cs, out_coff
         name = "ossid_conv_nhwc_fwd"
@@ -525,10 +557,10 @@ class PackedConv:
             return False
         return ((B * ((H + 1) // 2) * ((W + 1) // 2) + 31) // 32) * ((self.cout + 63) // 64) >= WINO_MIN_WGS
 
-    def run(self, x_nhwc, B, H, W, out_nhwc, in_cs=0, out_cs=0, out_coff=0, src_hw=(0, 0), in_bs=-1, pre=None):
+    def run(self, x_nhwc, B, H, W, out_nhwc, in_cs=0, out_cs=0, out_coff=0, src_hw=(0, 0), in_bs=-1, pre=None, skip_pre=False):
         """Raw call on physical [B][H][W][C] buffers (tensors only provide pointers). in_bs = 0: x is ONE image shared by
         the whole batch; pre = (scale [B,Cin], shift [B,Cin]): a per-image input affine instead of the stored one."""
-        d, name = self._desc(x_nhwc, B, H, W, out_nhwc, in_cs, out_cs, out_coff, src_hw, in_bs, pre)
+        d, name = self._desc(x_nhwc, B, H, W, out_nhwc, in_cs, out_cs, out_coff, src_hw, in_bs, pre, skip_pre)
         with _lib.on_device(out_nhwc.device):
             if name == "ossid_conv3x3_wino_fwd":
                 wino_workspace((d,), out_nhwc.device)

@@ -1150,3 +1150,27 @@ def test_fused_post_processing_equals_the_step_by_step_one(hiplib, n_t, topk, sp
         assert a.shape == b.shape and a.dtype == b.dtype
         assert torch.equal(a, b)
     assert 1 <= outs[True][0].shape[0] <= topk
+
+
+@pytest.mark.parametrize("B,H,W,kb", [(1, 240, 320, 1), (2, 37, 51, 2), (1, 6, 5, 1), (3, 1, 1, 1)])
+def test_stem_tail_with_pool0_in_one_pass_and_pooled_transition_front(hiplib, B, H, W, kb):
+    """ossid_stem_tail_pool_nhwc = max-pool(3, 2, 1) of ossid_stem_tail_nhwc, bit for bit (same fmaf chain per modulated pixel,
+    a maximum is exact), written into the channel prefix of a wider buffer whose other channels stay untouched;
+    ossid_bn_relu_avgpool2_nhwc against avg_pool2d(relu(affine)) in torch (four-term sums: 1e-6)."""
+    torch.manual_seed(H * 3 + W)
+    C = 64
+    x0 = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    k = torch.randn(kb, C, 3, 3, device="cuda") * 0.2
+    sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.3
+    want = ops.maxpool_nhwc(ops.stem_tail(x0, k, sc, sh), 3, 2, 1)
+    got = ops.stem_tail_pool(x0, k, sc, sh)
+    assert got.shape == want.shape and torch.equal(got, want)
+    wide = torch.full((B, C + 32, want.shape[2], want.shape[3]), 7.0, device="cuda").contiguous(memory_format=torch.channels_last)
+    ops.stem_tail_pool(x0, k, sc, sh, out=wide)
+    assert torch.equal(wide[:, :C], want) and bool((wide[:, C:] == 7.0).all())
+    if H >= 2 and W >= 2:
+        for stride in (1, 2):
+            xw = torch.randn(B, C + 16, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+            ref = torch.nn.functional.avg_pool2d(torch.relu(xw[:, :C] * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 2, stride)
+            got = ops.bn_relu_avgpool2(xw, C, sc, sh, stride)
+            assert got.shape == ref.shape and torch.allclose(got, ref, rtol=1e-6, atol=1e-6)
