@@ -78,25 +78,35 @@ class FlatParams:
         for _, p in self.entries:
             p.grad = None
 
-    def gather_grads(self):
+    def gather_grads(self, reattach=True):
         """After backward with p.grad = None: every gradient into its slice of the flat buffer (multi-tensor copies; nothing
         to do for a gradient a kernel already wrote in place, train_ops.grad_home), zeros for a USED parameter that got
         none this step (rare: an unused branch), then p.grad = the flat views again. The never-used parameters in the
-        buffer's tail are left alone: the optimizer does not read them."""
+        buffer's tail are left alone: the optimizer does not read them.
+        reattach=False: leave `p.grad = view` to a later reattach_grads() -- 700 attribute writes that nothing on the device
+        waits for; finetune_step does them AFTER it has launched the optimizer (the device is idle at the end of a step:
+        every host microsecond in front of that launch is step time)."""
         dst, src, zero = [], [], []
-        n_used_entries = sum(1 for name, _ in self.entries if self.offsets[name][0] < self.n_used)
-        for i, ((_, p), v) in enumerate(zip(self.entries, self._views)):
+        n_used_entries = self.__dict__.get("_n_used_entries")
+        if n_used_entries is None:
+            n_used_entries = self._n_used_entries = sum(1 for name, _ in self.entries if self.offsets[name][0] < self.n_used)
+            self._view_ptrs = [v.data_ptr() for v in self._views]
+        for i, ((_, p), v, vp) in enumerate(zip(self.entries, self._views, self._view_ptrs)):
             g = p.grad
             if g is None:
                 if i < n_used_entries:
                     zero.append(v)
-            elif g.data_ptr() != v.data_ptr():
+            elif g.data_ptr() != vp:
                 dst.append(v)
                 src.append(g)
         if zero:
             torch._foreach_zero_(zero)
         if dst:
             torch._foreach_copy_(dst, src)
+        if reattach:
+            self.reattach_grads()
+
+    def reattach_grads(self):
         for (_, p), v in zip(self.entries, self._views):
             p.grad = v
 
@@ -463,6 +473,11 @@ def _finetune_step_eager(model, batch, optimizer, sync=None):
             sync.finish()
         else:
             loss.backward()
+            if sync is None and hasattr(optimizer, "flat"):
+                flat.gather_grads(reattach=False)     # the fused step reads the flat buffer, not p.grad: launch it first
+                optimizer.step()
+                flat.reattach_grads()
+                return loss.detach()
             flat.gather_grads()
             if sync is not None:
                 sync.sync()

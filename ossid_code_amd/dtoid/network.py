@@ -852,20 +852,22 @@ class Network(nn.Module):
         # at the start of a step: the previous step's weight gradients were joined before its optimizer ran) beside the stem
         # In two launches: the backbone's and the encoders' weights (7 of the 34 M) first, with an event of their own -- the stem
         # on this repo's kernels takes 0.5 ms, not the 1.5 ms that used to cover the whole packing -- then the head's.
-        pack_event = pack_event_all = None
+        # (round 4: three launches -- the GLOBAL template encoder's weights first, in a launch of a few microseconds: that encoder
+        # is the head of the step's critical path (stem modulation needs its output) and used to wait ~1 ms for the whole
+        # first part; tools/step_gaps.py)
+        pack_event = pack_event_all = pack_event_g = None
         if self._branches_on(image.device):
             main = torch.cuda.current_stream(image.device)
             ps = T.side_streams(image.device)["wgrad"]
             ps.wait_stream(main)                                 # behind the optimizer step that wrote the weights
             with torch.cuda.stream(ps):
-                pack_event = self._train_pack_plan().run(want_first_event=True)
-            pack_event_all = torch.cuda.Event()
-            pack_event_all.record(ps)
-            if pack_event is None:
-                pack_event = pack_event_all
+                evs = self._train_pack_plan().run(want_events=True)
+            pack_event_all = evs[-1]
+            pack_event = evs[-2] if len(evs) >= 2 else pack_event_all
+            pack_event_g = evs[0] if len(evs) >= 3 else pack_event
         else:
             self._train_pack_plan().run()
-        self.__dict__["_pack_event"] = pack_event                # what a fork waits for (the encoders: the first part)
+        self.__dict__["_pack_event"] = pack_event_g              # what a fork waits for: the global encoder only its own part
         seq = list(ife.backdense_1) + list(ife.backdense_2)      # norm0 relu0 pool0 block1 | trans1 block2 ... norm5
         if self.use_hip_stem_training:
             # stem on this repo's kernels, channels-last from the first one
@@ -873,12 +875,14 @@ class Network(nn.Module):
             if lazy_g is not None:
                 g, s_g = lazy_g()
                 self._join(s_g, [g])
+            self.__dict__["_pack_event"] = pack_event            # (later forks -- the local encoder -- wait for the first big part)
             x = T.stem_tail(x0, g, seq[0])                        # modulation + norm0 + ReLU + pool0: three passes
         else:
             x0 = ife.backdense_0(image)
             if lazy_g is not None:
                 g, s_g = lazy_g()
                 self._join(s_g, [g])
+            self.__dict__["_pack_event"] = pack_event
             x0 = x0 + ops.dw_xcorr(x0, g)
             x = x0
             for m in seq[:3]:                                    # stem: 64 channels at 240x320, on torch
@@ -926,6 +930,10 @@ class Network(nn.Module):
         from .backbones import DenseBlock, Transition
         ife, corr = self.image_feature_extractor, self.correlation_model
         convs = []
+        if self.use_hip_template_training:
+            from .train_encoders import encoder_convs
+            convs += encoder_convs(self.template_feature_extractor_global)
+        n_global = len(convs)                                    # first launch: the global template encoder alone (tiny)
         for m in list(ife.backdense_1) + list(ife.backdense_2):
             if isinstance(m, DenseBlock):
                 for layer in m.values():
@@ -934,9 +942,8 @@ class Network(nn.Module):
                 convs.append(m.conv)
         convs.append(ife.c1)
         if self.use_hip_template_training:
-            from .train_encoders import encoder_convs
-            convs += encoder_convs(self.template_feature_extractor_global) + encoder_convs(self.template_feature_extractor)
-        n_first = len(convs)                                     # packed by the first launch: everything in front of the head
+            convs += encoder_convs(self.template_feature_extractor)
+        n_first = len(convs)                                     # second launch: everything else in front of the head
         convs += [corr.c1, corr.c2, corr.corr_conv_dot, corr.corr_conv_sub, corr.corr_conv_dot3x3, corr.cf] + \
             [getattr(corr, "s%d" % i) for i in (1, 2, 3, 4, 5)]
         for mod in (self.classification, self.regression):
@@ -964,7 +971,7 @@ class Network(nn.Module):
                     for cv in encoder_convs(enc):
                         final = any(cv is getattr(enc, n, None) for n in ("final_conv_1", "final_conv_2"))
                         kinds[cv] = ("fwd_exact", "dgrad_exact") if final else (T.FWD_ENCODER, "dgrad")
-            plan = self.__dict__["_pack_plan"] = T.PackPlan(convs, kinds, split_at=n_first)
+            plan = self.__dict__["_pack_plan"] = T.PackPlan(convs, kinds, split_at=([n_global] if n_global else []) + [n_first])
         return plan
 
     def _head_train_hip(self, feat, local):

@@ -239,10 +239,12 @@ class PackPlan:
         after a fifth of the packing time)."""
         rows, keys = [], []
         self.bufs, self.buf_ptr = [], {}       # strong references: the tables below hold raw addresses of these buffers
-        parts = [[], []]
-        firsts = [0, 0]
+        # split_at: one index, or an increasing sequence of them (one launch per segment of the list)
+        cuts = [] if split_at is None else ([int(split_at)] if isinstance(split_at, int) else [int(c) for c in split_at])
+        parts = [[] for _ in range(len(cuts) + 1)]
+        firsts = [0] * (len(cuts) + 1)
         for ci, conv in enumerate(convs):
-            part = 0 if (split_at is None or ci < split_at) else 1
+            part = sum(1 for c in cuts if ci >= c)
             w = conv.weight.detach()
             cout, cin, taps = int(w.shape[0]), int(w.shape[1]), int(w.shape[2] * w.shape[3])
             for kind in (("fwd", "dgrad") if kinds is None else kinds.get(conv, ("fwd", "dgrad"))):
@@ -281,15 +283,18 @@ class PackPlan:
             return False
         return all(_Packed._cache.get(k) is b for k, b in zip(self.keys, self.bufs))
 
-    def run(self, want_first_event=False):
+    def run(self, want_first_event=False, want_events=False):
         """Enqueue the packing launches on the current stream. want_first_event: return a torch.cuda.Event recorded behind
-        the first launch (the `split_at` part), else None."""
-        ev = None
+        the first launch (the `split_at` part), else None. want_events: return the list of events, one behind every launch."""
+        ev, evs = None, []
         with _lib.on_device(self.device):
             for i, (table, n_rows, blocks) in enumerate(self.tables):
                 rc = _lib.fn("ossid_conv_pack_weights_table")(table.data_ptr(), n_rows, blocks, _lib.stream())
                 _lib.check(rc, "ossid_conv_pack_weights_table")
-                if i == 0 and want_first_event and len(self.tables) > 1:
+                if want_events:
+                    evs.append(torch.cuda.Event())
+                    evs[-1].record(torch.cuda.current_stream(self.device))
+                elif i == 0 and want_first_event and len(self.tables) > 1:
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream(self.device))
         global _ACTIVE_PLAN
@@ -297,7 +302,7 @@ class PackPlan:
         vers = {w.data_ptr(): w._version for w in self.weights}
         self.fresh = {k: vers[k[0]] for k in self.keys}
         _ACTIVE_PLAN = weakref.ref(self)
-        return ev
+        return evs if want_events else ev
 
 
 def end_step():
