@@ -327,6 +327,13 @@ struct PackRow {
     int Cout, Cin, taps, kind;  // kind 0: forward layout, 1: data-gradient layout, 2 / 3: their Winograd forms, 4 / 5: 0 / 1 for exact-f32 launches, 6 / 7: for three-way-split launches
 };
 
+// A thread packs EVERYTHING that derives from one lane's group of reduction channels of one output row: all taps and all
+// bf16 pieces (direct layouts), all 16 transform positions and both pieces (Winograd layouts). Round 3 had one thread per
+// 16-byte output unit, each gathering its 8 (direct) or 72 (Winograd) source weights again: 2 reads per weight for the direct
+// layouts, 32 for the Winograd ones, 4 bytes at a time -- 1.5 ms per step for 0.5 GB of traffic. Here a weight is read once per
+// layout (a thread's 8 x taps source values are contiguous in the forward layouts, 8 runs of `taps` in the data-gradient ones),
+// and a wave's stores are whole 1 KB units. The grid and the table are unchanged (first_block counts 256 output units per
+// block): a row simply needs fewer of its blocks, the rest return at once.
 __global__ __launch_bounds__(256) void pack_all_kernel(const PackRow* __restrict__ table, int n_rows) {
     int lo = 0, hi = n_rows - 1;
     const long long b = blockIdx.x;
@@ -336,18 +343,108 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackRow* __restrict
     }
     const PackRow R = table[lo];
     const size_t i = (size_t)(b - R.first_block) * 256 + threadIdx.x;
-    if (R.kind == 2 || R.kind == 3) {      // Winograd layouts (csrc/wino.hip): 16 transform positions per (channel tile, 8-channel block)
+    const float* __restrict__ w = R.w;
+    const int Cout = R.Cout, Cin = R.Cin;
+    if (R.kind == 2 || R.kind == 3) {      // Winograd layouts (csrc/wino.hip)
+#ifndef OSSID_WINO_F32
+        const int dgrad = R.kind == 3;
+        const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout, KC = K / 16, M32 = (M + 31) / 32;
+        if (i >= (size_t)M32 * KC * 64) return;
+        const int lane = (int)(i & 63);
+        const size_t r = i >> 6;
+        const int ch = (int)(r % KC), mt = (int)(r / KC);
+        const int m = mt * 32 + (lane & 31), k0 = ch * 16 + 8 * (lane >> 5);
+        union Oct {
+            __bf16 hv[8];
+            float4 f;
+        } hi_o[16], lo_o[16];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float g[9];
+            if (m < M) {
+                const float* src = dgrad ? w + ((size_t)(k0 + e) * Cin + m) * 9 : w + ((size_t)m * Cin + k0 + e) * 9;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) g[t] = src[t];
+            }
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) {
+                float u = 0.0f;
+                if (m < M) {                                   // (the arithmetic of ossid_wino_u, on the values loaded above)
+                    const int ti = xi >> 2, tj = xi & 3;
+                    float t3[3];
+#pragma unroll
+                    for (int bb = 0; bb < 3; ++bb) {
+                        const float g0 = dgrad ? g[8 - bb] : g[bb], g1 = dgrad ? g[5 - bb] : g[3 + bb], g2 = dgrad ? g[2 - bb] : g[6 + bb];
+                        t3[bb] = ti == 0 ? g0 : (ti == 1 ? 0.5f * (g0 + g1 + g2) : (ti == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+                    }
+                    u = tj == 0 ? t3[0] : (tj == 1 ? 0.5f * (t3[0] + t3[1] + t3[2]) : (tj == 2 ? 0.5f * (t3[0] - t3[1] + t3[2]) : t3[2]));
+                }
+                const __bf16 h = (__bf16)u;
+                hi_o[xi].hv[e] = h;
+                lo_o[xi].hv[e] = (__bf16)(u - (float)h);
+            }
+        }
+        float4* out = R.wpk + (((size_t)mt * KC + ch) * 16) * 2 * 64 + lane;
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            out[(size_t)(xi * 2 + 0) * 64] = hi_o[xi].f;
+            out[(size_t)(xi * 2 + 1) * 64] = lo_o[xi].f;
+        }
+#else
         const int K8 = (R.kind == 2 ? R.Cin : R.Cout) / 8, M32 = ((R.kind == 2 ? R.Cout : R.Cin) + 31) / 32;
         if (i < (size_t)M32 * K8 * 16 * 64) R.wpk[i] = ossid_wino_pack_quad(R.w, R.Cout, R.Cin, R.kind == 3, i);
+#endif
         return;
     }
     if (R.kind < 0 || R.kind > 7) return;
     const int dgrad = R.kind & 1, exact = R.kind >= 6 ? 2 : (R.kind >= 4 ? 1 : 0);
-    const int KB = (dgrad ? R.Cout : R.Cin) / 8;
-    const int MT = ((dgrad ? R.Cin : R.Cout) + 31) / 32;
-    const size_t total = (size_t)MT * KB * R.taps * 64 / 2 * ((exact == 2 && OSSID_CONV_SB) ? 3 : 2);
-    if (i >= total) return;
-    R.wpk[i] = ossid_conv_pack_quad(R.w, R.Cout, R.Cin, R.taps, dgrad, exact, i);
+    const int taps = R.taps;
+    const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout, MT = (M + 31) / 32;
+    auto at = [&](int m, int k, int tap) {
+        return dgrad ? w[((size_t)k * Cin + m) * taps + (taps - 1 - tap)] : w[((size_t)m * Cin + k) * taps + tap];
+    };
+    if (OSSID_CONV_SB && exact != 1) {     // split forms: [mt][K/16][taps][parts][64 lanes] x 8 bf16
+        const int parts = exact == 2 ? 3 : 2, KU = K / 16;
+        if (i >= (size_t)MT * KU * 64) return;
+        const int lane = (int)(i & 63);
+        const size_t r = i >> 6;
+        const int u = (int)(r % KU), mt = (int)(r / KU);
+        const int m = mt * 32 + (lane & 31), k0 = u * 16 + 8 * (lane >> 5);
+        float4* out = R.wpk + (((size_t)mt * KU + u) * taps) * parts * 64 + lane;
+        for (int tap = 0; tap < taps; ++tap) {
+            union {
+                __bf16 hv[8];
+                float4 f;
+            } o[3];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = m < M ? at(m, k0 + e, tap) : 0.0f;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const __bf16 pc = (__bf16)v;
+                    o[p].hv[e] = pc;
+                    v -= (float)pc;
+                }
+            }
+            for (int p = 0; p < parts; ++p) out[((size_t)tap * parts + p) * 64] = o[p].f;
+        }
+        return;
+    }
+    {                                      // exact-f32 form: [mt][K/8][taps][64 lanes] x 4 floats
+        const int KB = K / 8;
+        if (i >= (size_t)MT * KB * 64) return;
+        const int lane = (int)(i & 63);
+        const size_t r = i >> 6;
+        const int kb = (int)(r % KB), mt = (int)(r / KB);
+        const int m = mt * 32 + (lane & 31), k0 = kb * 8 + 4 * (lane >> 5);
+        float4* out = R.wpk + (((size_t)mt * KB + kb) * taps) * 64 + lane;
+        for (int tap = 0; tap < taps; ++tap) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = m < M ? at(m, k0 + e, tap) : 0.0f;
+            out[(size_t)tap * 64] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
 }
 
 // =====================================================================================================================

@@ -1119,7 +1119,9 @@ class Conv3x3C1(torch.autograd.Function):
                     _lib.check(_lib.fn("ossid_conv3x3_c1_wgrad")(x.data_ptr(), g.data_ptr(), B, H, W, C, ws.data_ptr(), nbytes,
                                                                  dwb.data_ptr(), dbb.data_ptr(), _lib.stream()), "ossid_conv3x3_c1_wgrad")
                 _wgrad_async([x, g, dwb, dbb], run, dev, weights=(w,))
-                dw, db = _alias(dwb), (dbb if ctx.has_bias else None)
+                # (fresh tensor objects on the same memory: AccumulateGrad takes a gradient over unread only when nothing else
+                # refers to the tensor OBJECT, and clones it -- i.e. reads it -- otherwise)
+                dw, db = _alias(dwb), (_alias(dbb) if ctx.has_bias else None)
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 _lib.check(_lib.fn("ossid_conv3x3_c1_dgrad")(g.data_ptr(), B, H, W, C, w.detach().contiguous().data_ptr(), dx.data_ptr(),
