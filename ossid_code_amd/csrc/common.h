@@ -17,6 +17,12 @@ bool ossid_wgrad_fewch_takes(int Cin, int Cout, int taps, int in_cs, int dy_cs);
 size_t ossid_wgrad_fewch_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int ossid_wgrad_fewch(const ossid_wgrad_desc* d, void* stream);
 
+// csrc/wgrad_t9.hip: the dense blocks' 3x3 weight gradients (128 -> 32) from 2-D pixel tiles, all taps from one staged patch
+// (internal: reached through ossid_conv_wgrad_group / ossid_conv_wgrad_group_workspace_bytes of csrc/train.hip)
+bool ossid_wgrad_t9_takes(const ossid_wgrad_desc* d);
+size_t ossid_wgrad_t9_workspace_bytes(const ossid_wgrad_desc* descs, int n);
+int ossid_wgrad_t9_group(const ossid_wgrad_desc* descs, int n, void* workspace, size_t workspace_bytes, void* stream);
+
 // Kernels that declare more dynamic LDS than the default limit need hipFuncAttributeMaxDynamicSharedMemorySize. It is a
 // property of the FUNCTION, not of a launch: raise it to the hardware maximum ONCE per (function, device), the first
 // time the function is launched (always a warm-up pass, never inside a stream capture), instead of before every launch.

@@ -1531,6 +1531,9 @@ int ossid_conv_pack_weights_dgrad(const float* w, int Cout, int Cin, int taps, f
 #ifndef OSSID_WGRAD_FEWCH
 #define OSSID_WGRAD_FEWCH 1      // the decoder's few-channel 3x3 layers on csrc/wgrad_fc.hip (0: the general kernel, for A/B runs)
 #endif
+#ifndef OSSID_WGRAD_T9
+#define OSSID_WGRAD_T9 1         // the dense blocks' 3x3 layers (128 -> 32) on csrc/wgrad_t9.hip (0: this file's grouped kernel)
+#endif
 
 size_t ossid_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps) {
     WgradPlan p;
@@ -1627,8 +1630,34 @@ static void group_splits(WgradPlan* plans, int n) {
     }
 }
 
+// The problems of a group that csrc/wgrad_t9.hip takes (3x3, 128 -> 32: the dense layers' second convolution), provided they
+// share one geometry and fit one launch; the rest stay on the kernels of this file. Returns how many went to `t9`.
+static int split_t9(const ossid_wgrad_desc* descs, int n, ossid_wgrad_desc* t9, ossid_wgrad_desc* rest, int* n_rest) {
+    int m = 0, r = 0;
+    for (int i = 0; i < n; ++i) {
+        const ossid_wgrad_desc& d = descs[i];
+        const bool take = OSSID_WGRAD_T9 && ossid_wgrad_t9_takes(&d) && m < 24 &&
+                          (m == 0 || (d.batch == t9[0].batch && d.height == t9[0].height && d.width == t9[0].width));
+        if (take) t9[m++] = d;
+        else rest[r++] = d;
+    }
+    *n_rest = r;
+    return m;
+}
+
 size_t ossid_conv_wgrad_group_workspace_bytes(const ossid_wgrad_desc* descs, int n) {
     if (!descs || n <= 0 || n > 2 * OSSID_WGRAD_GROUP_MAX) return 0;
+    {
+        ossid_wgrad_desc t9[2 * OSSID_WGRAD_GROUP_MAX], rest[2 * OSSID_WGRAD_GROUP_MAX];
+        int n_rest = 0;
+        const int m = split_t9(descs, n, t9, rest, &n_rest);
+        if (m > 0) {
+            const size_t a = (ossid_wgrad_t9_workspace_bytes(t9, m) + 255) & ~(size_t)255;
+            if (n_rest == 0) return a;
+            const size_t b = ossid_conv_wgrad_group_workspace_bytes(rest, n_rest);     // (no eligible problem left: no recursion beyond this)
+            return b ? a + b : 0;
+        }
+    }
     WgradPlan plans[4 * OSSID_WGRAD_GROUP_MAX];
     for (int i = 0; i < n; ++i)
         if (!wgrad_plan(descs[i].batch, descs[i].height, descs[i].width, descs[i].cin, descs[i].cout, descs[i].taps, plans[i]))
@@ -1655,6 +1684,17 @@ size_t ossid_conv_wgrad_group_workspace_bytes(const ossid_wgrad_desc* descs, int
 int ossid_conv_wgrad_group(const ossid_wgrad_desc* descs, int n, void* workspace, size_t workspace_bytes, void* stream) {
     if (!descs || n <= 0 || n > 2 * OSSID_WGRAD_GROUP_MAX || !workspace) return OSSID_EINVAL;
     if (workspace_bytes < ossid_conv_wgrad_group_workspace_bytes(descs, n)) return OSSID_EINVAL;
+    {
+        ossid_wgrad_desc t9[2 * OSSID_WGRAD_GROUP_MAX], rest[2 * OSSID_WGRAD_GROUP_MAX];
+        int n_rest = 0;
+        const int m = split_t9(descs, n, t9, rest, &n_rest);
+        if (m > 0) {
+            const size_t a = (ossid_wgrad_t9_workspace_bytes(t9, m) + 255) & ~(size_t)255;
+            const int rc = ossid_wgrad_t9_group(t9, m, workspace, a, stream);
+            if (rc != OSSID_OK || n_rest == 0) return rc;
+            return ossid_conv_wgrad_group(rest, n_rest, (char*)workspace + a, workspace_bytes - a, stream);
+        }
+    }
     WgradPlan plans[4 * OSSID_WGRAD_GROUP_MAX];
     for (int i = 0; i < n; ++i) {
         const ossid_wgrad_desc& d = descs[i];
