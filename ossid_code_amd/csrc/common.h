@@ -22,6 +22,13 @@ int ossid_wgrad_fewch(const ossid_wgrad_desc* d, void* stream);
 bool ossid_wgrad_t9_takes(const ossid_wgrad_desc* d);
 size_t ossid_wgrad_t9_workspace_bytes(const ossid_wgrad_desc* descs, int n);
 int ossid_wgrad_t9_group(const ossid_wgrad_desc* descs, int n, void* workspace, size_t workspace_bytes, void* stream);
+// ... and the dense layers' 1x1 convolution (c -> 128) in blocks of 256 input channels ("jobs": at most
+// ossid_wgrad_t1_max_jobs() per call, ossid_wgrad_t1_job_count says how many a list makes)
+bool ossid_wgrad_t1_takes(const ossid_wgrad_desc* d);
+int ossid_wgrad_t1_max_jobs(void);
+int ossid_wgrad_t1_job_count(const ossid_wgrad_desc* descs, int n);
+size_t ossid_wgrad_t1_workspace_bytes(const ossid_wgrad_desc* descs, int n);
+int ossid_wgrad_t1_group(const ossid_wgrad_desc* descs, int n, void* workspace, size_t workspace_bytes, void* stream);
 
 // Kernels that declare more dynamic LDS than the default limit need hipFuncAttributeMaxDynamicSharedMemorySize. It is a
 // property of the FUNCTION, not of a launch: raise it to the hardware maximum ONCE per (function, device), the first

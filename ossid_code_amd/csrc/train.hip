@@ -1630,32 +1630,45 @@ static void group_splits(WgradPlan* plans, int n) {
     }
 }
 
-// The problems of a group that csrc/wgrad_t9.hip takes (3x3, 128 -> 32: the dense layers' second convolution), provided they
-// share one geometry and fit one launch; the rest stay on the kernels of this file. Returns how many went to `t9`.
-static int split_t9(const ossid_wgrad_desc* descs, int n, ossid_wgrad_desc* t9, ossid_wgrad_desc* rest, int* n_rest) {
-    int m = 0, r = 0;
+// The problems of a group that csrc/wgrad_t9.hip takes -- `t9`: 3x3, 128 -> 32 (the dense layers' second convolution), `t1`:
+// 1x1, c -> 128 (their first) -- provided they share one geometry; the rest stay on the kernels of this file.
+struct WgradSplit {
+    ossid_wgrad_desc t9[2 * OSSID_WGRAD_GROUP_MAX], t1[2 * OSSID_WGRAD_GROUP_MAX], rest[2 * OSSID_WGRAD_GROUP_MAX];
+    int n9, n1, nr;
+};
+static void split_tiled(const ossid_wgrad_desc* descs, int n, WgradSplit& S) {
+    S.n9 = S.n1 = S.nr = 0;
     for (int i = 0; i < n; ++i) {
         const ossid_wgrad_desc& d = descs[i];
-        const bool take = OSSID_WGRAD_T9 && ossid_wgrad_t9_takes(&d) && m < 24 &&
-                          (m == 0 || (d.batch == t9[0].batch && d.height == t9[0].height && d.width == t9[0].width));
-        if (take) t9[m++] = d;
-        else rest[r++] = d;
+        auto same = [&](const ossid_wgrad_desc& o) { return d.batch == o.batch && d.height == o.height && d.width == o.width; };
+        if (OSSID_WGRAD_T9 && ossid_wgrad_t9_takes(&d) && S.n9 < 24 && (S.n9 == 0 || same(S.t9[0]))) S.t9[S.n9++] = d;
+        else if (OSSID_WGRAD_T9 && ossid_wgrad_t1_takes(&d) && (S.n1 == 0 || same(S.t1[0]))) S.t1[S.n1++] = d;
+        else S.rest[S.nr++] = d;
     }
-    *n_rest = r;
-    return m;
+}
+// the t1 list in calls of at most ossid_wgrad_t1_max_jobs() jobs: [first, first + count)
+static int t1_chunk(const ossid_wgrad_desc* t1, int n1, int first) {
+    int count = 0;
+    while (first + count < n1 && ossid_wgrad_t1_job_count(t1 + first, count + 1) <= ossid_wgrad_t1_max_jobs()) ++count;
+    return count;
 }
 
 size_t ossid_conv_wgrad_group_workspace_bytes(const ossid_wgrad_desc* descs, int n) {
     if (!descs || n <= 0 || n > 2 * OSSID_WGRAD_GROUP_MAX) return 0;
     {
-        ossid_wgrad_desc t9[2 * OSSID_WGRAD_GROUP_MAX], rest[2 * OSSID_WGRAD_GROUP_MAX];
-        int n_rest = 0;
-        const int m = split_t9(descs, n, t9, rest, &n_rest);
-        if (m > 0) {
-            const size_t a = (ossid_wgrad_t9_workspace_bytes(t9, m) + 255) & ~(size_t)255;
-            if (n_rest == 0) return a;
-            const size_t b = ossid_conv_wgrad_group_workspace_bytes(rest, n_rest);     // (no eligible problem left: no recursion beyond this)
-            return b ? a + b : 0;
+        WgradSplit S;
+        split_tiled(descs, n, S);
+        if (S.n9 + S.n1 > 0) {
+            size_t total = S.n9 ? (ossid_wgrad_t9_workspace_bytes(S.t9, S.n9) + 255) & ~(size_t)255 : 0;
+            for (int f = 0; f < S.n1;) {
+                const int cnt = t1_chunk(S.t1, S.n1, f);
+                if (cnt <= 0) return 0;
+                total += (ossid_wgrad_t1_workspace_bytes(S.t1 + f, cnt) + 255) & ~(size_t)255;
+                f += cnt;
+            }
+            if (S.nr == 0) return total;
+            const size_t b = ossid_conv_wgrad_group_workspace_bytes(S.rest, S.nr);     // (nothing eligible left: one level of recursion)
+            return b ? total + b : 0;
         }
     }
     WgradPlan plans[4 * OSSID_WGRAD_GROUP_MAX];
@@ -1685,14 +1698,26 @@ int ossid_conv_wgrad_group(const ossid_wgrad_desc* descs, int n, void* workspace
     if (!descs || n <= 0 || n > 2 * OSSID_WGRAD_GROUP_MAX || !workspace) return OSSID_EINVAL;
     if (workspace_bytes < ossid_conv_wgrad_group_workspace_bytes(descs, n)) return OSSID_EINVAL;
     {
-        ossid_wgrad_desc t9[2 * OSSID_WGRAD_GROUP_MAX], rest[2 * OSSID_WGRAD_GROUP_MAX];
-        int n_rest = 0;
-        const int m = split_t9(descs, n, t9, rest, &n_rest);
-        if (m > 0) {
-            const size_t a = (ossid_wgrad_t9_workspace_bytes(t9, m) + 255) & ~(size_t)255;
-            const int rc = ossid_wgrad_t9_group(t9, m, workspace, a, stream);
-            if (rc != OSSID_OK || n_rest == 0) return rc;
-            return ossid_conv_wgrad_group(rest, n_rest, (char*)workspace + a, workspace_bytes - a, stream);
+        WgradSplit S;
+        split_tiled(descs, n, S);
+        if (S.n9 + S.n1 > 0) {
+            char* ws = (char*)workspace;
+            if (S.n9) {
+                const size_t a = (ossid_wgrad_t9_workspace_bytes(S.t9, S.n9) + 255) & ~(size_t)255;
+                const int rc = ossid_wgrad_t9_group(S.t9, S.n9, ws, a, stream);
+                if (rc != OSSID_OK) return rc;
+                ws += a;
+            }
+            for (int f = 0; f < S.n1;) {
+                const int cnt = t1_chunk(S.t1, S.n1, f);
+                if (cnt <= 0) return OSSID_EINVAL;
+                const size_t a = (ossid_wgrad_t1_workspace_bytes(S.t1 + f, cnt) + 255) & ~(size_t)255;
+                const int rc = ossid_wgrad_t1_group(S.t1 + f, cnt, ws, a, stream);
+                if (rc != OSSID_OK) return rc;
+                ws += a, f += cnt;
+            }
+            if (S.nr == 0) return OSSID_OK;
+            return ossid_conv_wgrad_group(S.rest, S.nr, ws, workspace_bytes - (size_t)(ws - (char*)workspace), stream);
         }
     }
     WgradPlan plans[4 * OSSID_WGRAD_GROUP_MAX];

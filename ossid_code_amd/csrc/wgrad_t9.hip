@@ -212,6 +212,201 @@ __global__ __launch_bounds__(256) void wgrad_t9_reduce_kernel(const T9Args A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The dense layers' FIRST convolution (1x1, c -> 128, torchvision _DenseLayer.conv1): dW[co][ci] = sum_px dZ[px][co] *
+// relu(s[ci] X[px][ci] + t[ci]) with X the first c channels of the block's resident buffer. Same operand scheme; a job =
+// (layer, block of up to 256 input channels): 64-pixel stages (dZ 64 x 128 and X 64 x 256 split into bf16 images), wave w owns
+// output channels 32w .. 32w+31 against up to eight 32-channel column tiles: 96 MFMAs per stage and wave between two barriers
+// (train.hip's tiling for this shape: 36 per 48-pixel chunk, and the f32 -> 2 x bf16 split of a staged element feeds four tile
+// products there, eight here). Persistent workgroups, one slab [128][256] each, fixed-order reduction.
+constexpr int T1_COUT = 128, T1_CIB = 256, T1_PXS = 64;
+constexpr int T1_PD = 320, T1_PXB = 576;               // bytes per pixel of the dZ / X images (pitch mod 256 = 64)
+constexpr int T1_DIMG = T1_PXS * T1_PD, T1_XIMG = T1_PXS * T1_PXB;
+constexpr int T1_LDS = 2 * (T1_DIMG + T1_XIMG);        // 114 688 B
+constexpr int T1_MAX = 48;                             // jobs per launch
+constexpr int T1_SLAB = T1_COUT * T1_CIB;
+
+struct T1Job {
+    const float *x, *dy, *pre_scale, *pre_shift;       // x / pre_* already offset to the job's first input channel
+    float* dw;                                         // dw + first input channel; rows of cin_total floats
+    int cw, cin_total, in_cs, dy_cs, pre_relu, accumulate;    // cw = input channels of this block (<= 256, a multiple of 32)
+};
+struct T1Args {
+    T1Job j[T1_MAX];
+    float* slabs;                                      // [n][nwg][128][256]
+    long long npx;
+    int n, nwg, nstages;
+};
+
+__global__ __launch_bounds__(256, 1) void wgrad_t1_kernel(const T1Args A) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* dyl = lds;                                   // [2 parts][64][PD]
+    char* xl = lds + 2 * T1_DIMG;                      // [2 parts][64][PXB]
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ji = blockIdx.x / A.nwg, wg = blockIdx.x - ji * A.nwg;
+    if (ji >= A.n) return;
+    const T1Job J = A.j[ji];
+    const int ntn = J.cw / 32;                         // column tiles in use (uniform)
+
+    v16f acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    const int xq = tid & 63, dq = tid & 31;
+    const bool xq_ok = 4 * xq < J.cw;
+    float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (J.pre_scale && xq_ok) {
+        ps = *(const float4*)(J.pre_scale + 4 * xq);
+        pt = *(const float4*)(J.pre_shift + 4 * xq);
+    }
+    const bool has_pre = J.pre_scale != nullptr, relu = J.pre_relu != 0;
+    float4 sx[16], sd[8];
+    auto fetch = [&](int stage) {                       // loads only (see wgrad_t9_kernel)
+        const long long p0 = (long long)stage * T1_PXS;
+        if (xq_ok) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long long p = min(p0 + (tid >> 6) + 4 * e, A.npx - 1);
+                sx[e] = *(const float4*)(J.x + (size_t)p * J.in_cs + 4 * xq);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const long long p = min(p0 + (tid >> 5) + 8 * e, A.npx - 1);
+            sd[e] = *(const float4*)(J.dy + (size_t)p * J.dy_cs + 4 * dq);
+        }
+    };
+    auto split_store = [&](const float4& fv, char* hi_at, int part_stride) {
+        const float v[4] = {fv.x, fv.y, fv.z, fv.w};
+        union {
+            __bf16 b[4];
+            uint2 u;
+        } hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hi.b[i] = (__bf16)v[i];
+            lo.b[i] = (__bf16)(v[i] - (float)hi.b[i]);
+        }
+        *(uint2*)hi_at = hi.u;
+        *(uint2*)(hi_at + part_stride) = lo.u;
+    };
+    auto commit = [&](int stage) {
+        const long long p0 = (long long)stage * T1_PXS;
+        if (xq_ok) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int px = (tid >> 6) + 4 * e;
+                float4 v = sx[e];
+                if (has_pre) {
+                    v.x = v.x * ps.x + pt.x, v.y = v.y * ps.y + pt.y, v.z = v.z * ps.z + pt.z, v.w = v.w * ps.w + pt.w;
+                    if (relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                }
+                split_store(v, xl + (size_t)px * T1_PXB + 8 * xq, T1_XIMG);      // (pixels past the end pair with zero dZ rows)
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int px = (tid >> 5) + 8 * e;
+            const float f = (p0 + px < A.npx) ? 1.0f : 0.0f;
+            const float4 v = sd[e];
+            split_store(make_float4(f * v.x, f * v.y, f * v.z, f * v.w), dyl + (size_t)px * T1_PD + 8 * dq, T1_DIMG);
+        }
+    };
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
+    const char* a_base = dyl + (size_t)(8 * h + tq) * T1_PD + (wave * 32 + 16 * tg + 4 * tp) * 2;
+    const char* b_base = xl + (size_t)(8 * h + tq) * T1_PXB + (16 * tg + 4 * tp) * 2;
+    auto tr8 = [&](const char* at, int pitch) {
+        const v4i16 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)at);
+        const v4i16 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(at + 4 * pitch));
+        typedef short v8i16 __attribute__((ext_vector_type(8)));
+        const v8i16 v = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(v8bf16, v);
+    };
+
+    if (wg < A.nstages) fetch(wg);
+    for (int stage = wg; stage < A.nstages; stage += A.nwg) {
+        __syncthreads();
+        commit(stage);
+        __syncthreads();
+        if (stage + A.nwg < A.nstages) fetch(stage + A.nwg);
+#pragma unroll 1
+        for (int k = 0; k < T1_PXS / 16; ++k) {
+            const v8bf16 a_hi = tr8(a_base + (size_t)(16 * k) * T1_PD, T1_PD);
+            const v8bf16 a_lo = tr8(a_base + T1_DIMG + (size_t)(16 * k) * T1_PD, T1_PD);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                if (n < ntn) {
+                    const char* at = b_base + (size_t)(16 * k) * T1_PXB + n * 64;
+                    const v8bf16 b_hi = tr8(at, T1_PXB), b_lo = tr8(at + T1_XIMG, T1_PXB);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[n], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* slab = A.slabs + ((size_t)ji * A.nwg + wg) * T1_SLAB;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        if (n >= ntn) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            slab[(size_t)co * T1_CIB + n * 32 + c] = acc[n][r];
+        }
+    }
+}
+
+// dw[co][ci] (+)= sum over a job's slabs [co][256], fixed order
+__global__ __launch_bounds__(256) void wgrad_t1_reduce_kernel(const T1Args A) {
+    __shared__ float red[8][32];
+    constexpr int per_job = T1_SLAB / 32;
+    const int ji = blockIdx.x / per_job, blk = blockIdx.x - ji * per_job;
+    const T1Job J = A.j[ji];
+    const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int i = blk * 32 + col;                          // slab element (co, ci)
+    const int co = i / T1_CIB, ci = i - co * T1_CIB;
+    if (blk * 32 % T1_CIB >= J.cw) return;                 // (whole block outside the job's channels: uniform)
+    const float* base = A.slabs + (size_t)ji * A.nwg * T1_SLAB + i;
+    const int per = (A.nwg + 7) / 8, g0 = part * per, g1 = min(A.nwg, g0 + per);
+    float s = 0.0f;
+    int g = g0;
+    for (; g + 8 <= g1; g += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(g + u) * T1_SLAB];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; g < g1; ++g) s += base[(size_t)g * T1_SLAB];
+    red[part][col] = s;
+    __syncthreads();
+    if (part == 0 && ci < J.cw) {
+        float t = red[0][col];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) t += red[u][col];
+        float* o = J.dw + (size_t)co * J.cin_total + ci;
+        *o = J.accumulate ? *o + t : t;
+    }
+}
+
+int g_t1_grid = 0;
+int t1_grid() {
+    if (!g_t1_grid) {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wgrad_t1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T1_LDS) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_t1_kernel, 256, T1_LDS) != hipSuccess || per_cu <= 0)
+            return 256;
+        g_t1_grid = per_cu * p.multiProcessorCount;
+    }
+    return g_t1_grid;
+}
+
 int g_t9_grid = 0;
 int t9_grid() {
     if (!g_t9_grid) {
@@ -282,5 +477,73 @@ int ossid_wgrad_t9_group(const ossid_wgrad_desc* descs, int n, void* workspace, 
     t9_grid();                                             // (sets the dynamic-LDS attribute once)
     hipLaunchKernelGGL(wgrad_t9_kernel, dim3((unsigned)(n * a.nwg)), dim3(256), T9_LDS, s, a);
     hipLaunchKernelGGL(wgrad_t9_reduce_kernel, dim3((unsigned)(n * ((T9_SLAB + 31) / 32))), dim3(256), 0, s, a);
+    return ossid_launch_status();
+}
+
+// ---- 1x1, c -> 128 (the dense layers' first convolution) -------------------------------------------------------------------
+bool ossid_wgrad_t1_takes(const ossid_wgrad_desc* d) {
+#ifdef OSSID_WGRAD_F32
+    (void)d;
+    return false;
+#else
+    const int in_cs = d->in_channel_stride > 0 ? d->in_channel_stride : d->cin;
+    const int dy_cs = d->dy_channel_stride > 0 ? d->dy_channel_stride : d->cout;
+    return d->taps == 1 && d->cout == T1_COUT && d->cin >= 32 && d->cin % 32 == 0 && in_cs % 4 == 0 && dy_cs % 4 == 0 &&
+           !((uintptr_t)d->x & 15) && !((uintptr_t)d->dy & 15) && (!d->pre_scale || !((uintptr_t)d->pre_scale & 15)) &&
+           (!d->pre_shift || !((uintptr_t)d->pre_shift & 15)) && d->batch > 0 && d->height > 0 && d->width > 0;
+#endif
+}
+
+static int t1_jobs(const ossid_wgrad_desc* descs, int n) {
+    int jobs = 0;
+    for (int i = 0; i < n; ++i) jobs += (descs[i].cin + T1_CIB - 1) / T1_CIB;
+    return jobs;
+}
+static int t1_nwg(int jobs, long long nstages) {
+    int nwg = t1_grid() / jobs;
+    if (nwg < 1) nwg = 1;
+    if (nwg > nstages) nwg = (int)nstages;
+    return nwg;
+}
+
+// n problems of ONE pixel count (batch * height * width), all accepted by ossid_wgrad_t1_takes, at most T1_MAX jobs
+int ossid_wgrad_t1_max_jobs(void) { return T1_MAX; }
+int ossid_wgrad_t1_job_count(const ossid_wgrad_desc* descs, int n) { return t1_jobs(descs, n); }
+
+size_t ossid_wgrad_t1_workspace_bytes(const ossid_wgrad_desc* descs, int n) {
+    const int jobs = t1_jobs(descs, n);
+    if (n <= 0 || jobs > T1_MAX) return 0;
+    const long long npx = (long long)descs[0].batch * descs[0].height * descs[0].width;
+    return (size_t)jobs * t1_nwg(jobs, (npx + T1_PXS - 1) / T1_PXS) * T1_SLAB * sizeof(float);
+}
+
+int ossid_wgrad_t1_group(const ossid_wgrad_desc* descs, int n, void* workspace, size_t workspace_bytes, void* stream) {
+    const int jobs = t1_jobs(descs, n);
+    if (n <= 0 || jobs > T1_MAX || !workspace || ((uintptr_t)workspace & 15)) return OSSID_EINVAL;
+    T1Args a;
+    a.npx = (long long)descs[0].batch * descs[0].height * descs[0].width;
+    const long long ns = (a.npx + T1_PXS - 1) / T1_PXS;
+    if (ns > 0x7fffffff) return OSSID_EINVAL;
+    a.nstages = (int)ns, a.n = jobs, a.nwg = t1_nwg(jobs, ns), a.slabs = (float*)workspace;
+    if (workspace_bytes < (size_t)jobs * a.nwg * T1_SLAB * sizeof(float)) return OSSID_EINVAL;
+    int ji = 0;
+    for (int i = 0; i < n; ++i) {
+        const ossid_wgrad_desc& d = descs[i];
+        if (!ossid_wgrad_t1_takes(&d) || (long long)d.batch * d.height * d.width != a.npx || !d.dw || (d.pre_scale && !d.pre_shift))
+            return OSSID_EINVAL;
+        for (int c0 = 0; c0 < d.cin; c0 += T1_CIB) {
+            T1Job& j = a.j[ji++];
+            j.x = d.x + c0, j.dy = d.dy, j.dw = d.dw + c0;
+            j.pre_scale = d.pre_scale ? d.pre_scale + c0 : nullptr, j.pre_shift = d.pre_shift ? d.pre_shift + c0 : nullptr;
+            j.cw = d.cin - c0 < T1_CIB ? d.cin - c0 : T1_CIB, j.cin_total = d.cin;
+            j.in_cs = d.in_channel_stride > 0 ? d.in_channel_stride : d.cin;
+            j.dy_cs = d.dy_channel_stride > 0 ? d.dy_channel_stride : d.cout;
+            j.pre_relu = d.pre_relu, j.accumulate = d.accumulate;
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    t1_grid();
+    hipLaunchKernelGGL(wgrad_t1_kernel, dim3((unsigned)(jobs * a.nwg)), dim3(256), T1_LDS, s, a);
+    hipLaunchKernelGGL(wgrad_t1_reduce_kernel, dim3((unsigned)(jobs * (T1_SLAB / 32))), dim3(256), 0, s, a);
     return ossid_launch_status();
 }

@@ -32,6 +32,26 @@ def main():
         ms = e0.elapsed_time(e1) / 10
         fl = L * 2.0 * B * H * W * 32 * 128 * 9
         print("%s  %2d layers  %7.3f ms  %6.1f TFLOP/s" % (name, L, ms, fl / ms / 1e9), flush=True)
+        # the same block's 1x1 layers (c -> 128 on the channel prefix of the resident buffer)
+        buf = torch.randn(B, Ct, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+        items, fl = [], 0.0
+        for li in range(L):
+            c = C0 + 32 * li
+            dz = torch.randn(B, 128, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+            f = torch.rand(2, c, device="cuda") + 0.5
+            items.append(dict(x=buf, dy=dz, B=B, H=H, W=W, cin=c, cout=128, taps=1, dw=torch.empty(128, c, 1, 1, device="cuda"),
+                              pre=(f[0], f[1] - 1.0), pre_relu=True, in_cs=Ct))
+            fl += 2.0 * B * H * W * 128 * c
+        for _ in range(3):
+            T.wgrad_group(items)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            T.wgrad_group(items)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print("%s  %2d layers 1x1  %7.3f ms  %6.1f TFLOP/s" % (name, L, ms, fl / ms / 1e9), flush=True)
 
 
 if __name__ == "__main__":
