@@ -17,9 +17,10 @@ bool ossid_wgrad_fewch_takes(int Cin, int Cout, int taps, int in_cs, int dy_cs);
 size_t ossid_wgrad_fewch_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int ossid_wgrad_fewch(const ossid_wgrad_desc* d, void* stream);
 
-// csrc/wgrad_t9.hip: the dense blocks' 3x3 weight gradients (128 -> 32) from 2-D pixel tiles, all taps from one staged patch
-// (internal: reached through ossid_conv_wgrad_group / ossid_conv_wgrad_group_workspace_bytes of csrc/train.hip)
+// csrc/wgrad_t9.hip: plain 3x3 weight gradients with input channels in 128s (the dense blocks' 128 -> 32, the head's layers) from
+// 2-D pixel tiles, all taps from one staged patch (internal: reached through ossid_conv_wgrad(_group) and their workspace queries)
 bool ossid_wgrad_t9_takes(const ossid_wgrad_desc* d);
+int ossid_wgrad_t9_class(const ossid_wgrad_desc* d);      // problems of one ossid_wgrad_t9_group call share it (and the geometry)
 size_t ossid_wgrad_t9_workspace_bytes(const ossid_wgrad_desc* descs, int n);
 int ossid_wgrad_t9_group(const ossid_wgrad_desc* descs, int n, void* workspace, size_t workspace_bytes, void* stream);
 // ... and the dense layers' 1x1 convolution (c -> 128) in blocks of 256 input channels ("jobs": at most

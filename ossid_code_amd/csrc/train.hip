@@ -1534,6 +1534,9 @@ int ossid_conv_pack_weights_dgrad(const float* w, int Cout, int Cin, int taps, f
 #ifndef OSSID_WGRAD_T9
 #define OSSID_WGRAD_T9 1         // the dense blocks' 3x3 layers (128 -> 32) on csrc/wgrad_t9.hip (0: this file's grouped kernel)
 #endif
+#ifndef OSSID_WGRAD_T9_SINGLE
+#define OSSID_WGRAD_T9_SINGLE 1  // ... and every other plain 3x3 layer with input channels in 128s (the head) through ossid_conv_wgrad
+#endif
 
 size_t ossid_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps) {
     WgradPlan p;
@@ -1542,6 +1545,14 @@ size_t ossid_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, 
     if (OSSID_WGRAD_FEWCH && ossid_wgrad_fewch_takes(Cin, Cout, taps, Cin, Cout)) {
         const size_t m = ossid_wgrad_fewch_workspace_bytes(B, H, W, Cin, Cout);
         if (m > n) n = m;
+    }
+    if (OSSID_WGRAD_T9 && OSSID_WGRAD_T9_SINGLE) {          // (a shape-only probe: pointers and strides are checked at the call)
+        ossid_wgrad_desc d = {};
+        d.batch = B, d.height = H, d.width = W, d.cin = Cin, d.cout = Cout, d.taps = taps;
+        if (Cin <= 256 && ossid_wgrad_t9_takes(&d)) {
+            const size_t m = ossid_wgrad_t9_workspace_bytes(&d, 1);
+            if (m > n) n = m;
+        }
     }
     return n;
 }
@@ -1558,6 +1569,12 @@ int ossid_conv_wgrad(const ossid_wgrad_desc* d, void* stream) {
         d->workspace_bytes >= ossid_wgrad_fewch_workspace_bytes(B, H, W, Cin, Cout) && !((uintptr_t)d->x & 15) &&
         !((uintptr_t)d->dy & 15) && !((uintptr_t)d->workspace & 15))
         return ossid_wgrad_fewch(d, stream);                 // 2-D pixel tiles, every tap from one staged patch (csrc/wgrad_fc.hip)
+    // (measured per layer at batch 8, 29 x 39, tools/train_layers_bench.py: 256 -> 256 / 96 / 48 take 0.091 / 0.054 / 0.034 ms there
+    // against 0.104 / 0.081 / 0.054 here; 512 -> 256, 640 -> 256, 768 -> 512 are no faster there -- 0.152 / 0.196 / 0.409 against
+    // 0.143 / 0.162 / 0.421: this file's 128 x 128 tiles re-use a staged element four times -- so only up to 256 input channels)
+    if (OSSID_WGRAD_T9 && OSSID_WGRAD_T9_SINGLE && Cin <= 256 && ossid_wgrad_t9_takes(d) && !((uintptr_t)d->workspace & 15) &&
+        d->workspace_bytes >= ossid_wgrad_t9_workspace_bytes(d, 1))
+        return ossid_wgrad_t9_group(d, 1, d->workspace, d->workspace_bytes, stream);      // the same, split-bf16 (csrc/wgrad_t9.hip)
     WgradPlan p;
     if (!wgrad_plan(B, H, W, Cin, Cout, taps, p)) return OSSID_EINVAL;
     if (d->workspace_bytes < (size_t)p.nsplit * p.wk * taps * Cout * Cin * sizeof(float)) return OSSID_EINVAL;
@@ -1641,7 +1658,9 @@ static void split_tiled(const ossid_wgrad_desc* descs, int n, WgradSplit& S) {
     for (int i = 0; i < n; ++i) {
         const ossid_wgrad_desc& d = descs[i];
         auto same = [&](const ossid_wgrad_desc& o) { return d.batch == o.batch && d.height == o.height && d.width == o.width; };
-        if (OSSID_WGRAD_T9 && ossid_wgrad_t9_takes(&d) && S.n9 < 24 && (S.n9 == 0 || same(S.t9[0]))) S.t9[S.n9++] = d;
+        if (OSSID_WGRAD_T9 && ossid_wgrad_t9_takes(&d) &&
+            (S.n9 == 0 || (same(S.t9[0]) && ossid_wgrad_t9_class(&d) == ossid_wgrad_t9_class(&S.t9[0]))))
+            S.t9[S.n9++] = d;
         else if (OSSID_WGRAD_T9 && ossid_wgrad_t1_takes(&d) && (S.n1 == 0 || same(S.t1[0]))) S.t1[S.n1++] = d;
         else S.rest[S.nr++] = d;
     }

@@ -12,8 +12,8 @@
 // bf16 images [pixel][channel], the layout of train.hip's kernel: operands by ds_read_b64_tr_b16 with the pixels on the MFMA's
 // K axis), wave w owns input channels 32w .. 32w+31 and walks the nine taps of the tile's four 16-pixel rows: 108 MFMAs per
 // tile and wave between two barriers (four times the old ratio), nine accumulator tiles (144 registers) live across all the
-// tiles of the workgroup. Workgroups are persistent (two per CU), each belongs to ONE problem of the group (the L layers of a
-// block are one launch), prefetches its next tile's loads under the current tile's MFMAs, and writes one partial slab
+// tiles of the workgroup. Workgroups are persistent (one per CU: 330 registers), each belongs to ONE job of the launch (the L
+// layers of a block are one launch), prefetches its next tile's loads under the current tile's MFMAs, and writes one partial slab
 // [tap][co][ci]; a second kernel adds a problem's slabs in a fixed order: bit-reproducible, no float atomics.
 // Arithmetic: dy_lo * x_hi + dy_hi * x_lo + dy_hi * x_hi per product, f32 accumulation, as train.hip's split form. A
 // -DOSSID_WGRAD_F32 build does not use this file (ossid_wgrad_t9_takes returns false).
@@ -25,48 +25,58 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
 typedef short v4i16 __attribute__((ext_vector_type(4)));
 
-constexpr int T9_CIN = 128, T9_COUT = 32;
+constexpr int T9_CIN = 128;                            // input channels of a job (a block of the layer's)
 constexpr int T9_TH = 4, T9_TW = 16, T9_PH = T9_TH + 2, T9_PW = T9_TW + 2;
-constexpr int T9_PX = 320, T9_PD = 64;                 // bytes per pixel of the x / dy images (pitch mod 256 = 64: see train.hip)
-constexpr int T9_XIMG = T9_PH * T9_PW * T9_PX, T9_DIMG = T9_TH * T9_TW * T9_PD;      // bytes per part
-constexpr int T9_LDS = 2 * (T9_XIMG + T9_DIMG);        // 77 312 B: two workgroups per CU
-constexpr int T9_MAX = 24;                             // problems per launch (a DenseNet-121 block has at most 24 layers)
-constexpr int T9_SLAB = 9 * T9_COUT * T9_CIN;          // floats
+constexpr int T9_PX = 320;                             // bytes per pixel of the x images (pitch mod 256 = 64: see train.hip)
+constexpr int T9_XIMG = T9_PH * T9_PW * T9_PX;         // bytes per part
+constexpr int t9_pd(int tm) { return tm == 1 ? 64 : 192; }                 // bytes per pixel of the dY images (32 / 64 channels)
+constexpr int t9_lds(int tm) { return 2 * (T9_XIMG + T9_TH * T9_TW * t9_pd(tm)); }   // 77 312 / 93 696 B
+constexpr int T9_MAX = 48;                             // jobs per launch
+constexpr int t9_slab(int tm) { return 9 * tm * 32 * T9_CIN; }             // floats
 
-struct T9Problem {
+// A job = (layer, tile of 32 TM output channels, block of 128 input channels): pointers already offset to the job's first
+// channels. The dense blocks' layers (128 -> 32) are one job each (TM = 1); the head's 3x3 layers are cut into jobs of 64 output
+// channels (TM = 2: every staged input pixel then feeds two tile products per tap).
+struct T9Job {
     const float *x, *dy, *pre_scale, *pre_shift;
-    float* slabs;                                      // [nwg][9][32][128]
-    float* dw;
-    int in_cs, dy_cs, pre_relu, accumulate;
+    float* dw;                                         // dw + (co0 * cin_total + ci0) * 9
+    int cin_total, cout_w, in_cs, dy_cs, pre_relu, accumulate;      // cout_w: output channels of this job that exist (<= 32 TM)
 };
 struct T9Args {
-    T9Problem p[T9_MAX];
-    int n, nwg;                                        // problems, workgroups per problem
+    T9Job j[T9_MAX];
+    float* slabs;                                      // [n][nwg][9][32 TM][128]
+    int n, nwg;                                        // jobs, workgroups per job
     int B, H, W, tiles_y, tiles_x, ntiles;
 };
 
+template <int TM>
 __global__ __launch_bounds__(256, 1) void wgrad_t9_kernel(const T9Args A) {
+    constexpr int PD = t9_pd(TM), DIMG = T9_TH * T9_TW * PD, D4 = TM * 8;      // float4 of dY per pixel
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* xl = lds;                                    // [2 parts][PH][PW][PX]
     char* dyl = lds + 2 * T9_XIMG;                     // [2 parts][TH * TW][PD]
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pi = blockIdx.x / A.nwg, wg = blockIdx.x - pi * A.nwg;
-    if (pi >= A.n) return;
-    const T9Problem P = A.p[pi];
+    const int ji = blockIdx.x / A.nwg, wg = blockIdx.x - ji * A.nwg;
+    if (ji >= A.n) return;
+    const T9Job P = A.j[ji];
     const int H = A.H, W = A.W;
 
-    v16f acc[9];
+    v16f acc[TM][9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
 
-    // staging maps: x patch = 108 pixels x 32 float4 (13.5 per thread), dy tile = 64 pixels x 8 float4 (2 per thread)
-    constexpr int NX = (T9_PH * T9_PW * (T9_CIN / 4) + 255) / 256, ND = (T9_TH * T9_TW * (T9_COUT / 4)) / 256;
-    const int xq = tid & 31, dq = tid & 7;
+    // staging maps: x patch = 108 pixels x 32 float4 (13.5 per thread), dY tile = 64 pixels x D4 float4 (2 TM per thread)
+    constexpr int NX = (T9_PH * T9_PW * (T9_CIN / 4) + 255) / 256, ND = (T9_TH * T9_TW * D4) / 256;
+    const int xq = tid & 31, dq = tid % D4;
+    const bool dq_ok = 4 * dq < P.cout_w;
     float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (P.pre_scale) {
+    const bool has_pre = P.pre_scale != nullptr, relu = P.pre_relu != 0;
+    if (has_pre) {
         ps = *(const float4*)(P.pre_scale + 4 * xq);
         pt = *(const float4*)(P.pre_shift + 4 * xq);
     }
@@ -85,9 +95,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_t9_kernel(const T9Args A) {
         }
 #pragma unroll
         for (int e = 0; e < ND; ++e) {
-            const int idx = (tid >> 3) + 32 * e;                               // tile pixel
+            const int idx = tid / D4 + (256 / D4) * e;                         // tile pixel
             const int py = idx / T9_TW, px = idx - py * T9_TW;
-            sd[e] = *(const float4*)(P.dy + ((size_t)(b * H + min(oy0 + py, H - 1)) * W + min(ox0 + px, W - 1)) * P.dy_cs + 4 * dq);
+            sd[e] = *(const float4*)(P.dy + ((size_t)(b * H + min(oy0 + py, H - 1)) * W + min(ox0 + px, W - 1)) * P.dy_cs +
+                                     (dq_ok ? 4 * dq : 0));
         }
     };
     auto split_store = [&](const float4& fv, char* hi_at, int part_stride) {
@@ -114,27 +125,27 @@ __global__ __launch_bounds__(256, 1) void wgrad_t9_kernel(const T9Args A) {
             const int py = idx / T9_PW, px = idx - py * T9_PW;
             const int yy = oy0 - 1 + py, xx = ox0 - 1 + px;
             float4 v = sx[e];
-            if (P.pre_scale) {
+            if (has_pre) {
                 v.x = v.x * ps.x + pt.x, v.y = v.y * ps.y + pt.y, v.z = v.z * ps.z + pt.z, v.w = v.w * ps.w + pt.w;
-                if (P.pre_relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                if (relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
             }
             const float f = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 1.0f : 0.0f;      // zero padding (finite clamped values)
             split_store(make_float4(f * v.x, f * v.y, f * v.z, f * v.w), xl + (size_t)idx * T9_PX + 8 * xq, T9_XIMG);
         }
 #pragma unroll
         for (int e = 0; e < ND; ++e) {
-            const int idx = (tid >> 3) + 32 * e;
+            const int idx = tid / D4 + (256 / D4) * e;
             const int py = idx / T9_TW, px = idx - py * T9_TW;
-            const float f = (oy0 + py < H && ox0 + px < W) ? 1.0f : 0.0f;
+            const float f = (dq_ok && oy0 + py < H && ox0 + px < W) ? 1.0f : 0.0f;
             const float4 v = sd[e];
-            split_store(make_float4(f * v.x, f * v.y, f * v.z, f * v.w), dyl + (size_t)idx * T9_PD + 8 * dq, T9_DIMG);
+            split_store(make_float4(f * v.x, f * v.y, f * v.z, f * v.w), dyl + (size_t)idx * PD + 8 * dq, DIMG);
         }
     };
     // transposed-read addresses (as csrc/train.hip): within its group of 16 lanes, lane 4q+p supplies the address of block row q
     // (a pixel), channels 4p..4p+3 of the block's 16; groups 0 / 1 take channels 0-15 / 16-31 of a 32-channel tile, the wave's
     // halves the pixels 8h..8h+7 of a 16-pixel row (two blocks of 4 pixels each)
     const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
-    const char* a_base = dyl + (size_t)(8 * h + tq) * T9_PD + (16 * tg + 4 * tp) * 2;
+    const char* a_base = dyl + (size_t)(8 * h + tq) * PD + (16 * tg + 4 * tp) * 2;
     const char* b_base = xl + (size_t)(8 * h + tq) * T9_PX + (wave * 32 + 16 * tg + 4 * tp) * 2;
     auto tr8 = [&](const char* at, int pitch) {
         const v4i16 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)at);
@@ -152,8 +163,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_t9_kernel(const T9Args A) {
         if (tile + A.nwg < A.ntiles) fetch(tile + A.nwg);  // in flight under this tile's MFMAs
 #pragma unroll 1
         for (int r = 0; r < T9_TH; ++r) {
-            const v8bf16 a_hi = tr8(a_base + (size_t)(r * T9_TW) * T9_PD, T9_PD);
-            const v8bf16 a_lo = tr8(a_base + T9_DIMG + (size_t)(r * T9_TW) * T9_PD, T9_PD);
+            v8bf16 a_hi[TM], a_lo[TM];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) {
+                a_hi[m] = tr8(a_base + (size_t)(r * T9_TW) * PD + m * 64, PD);
+                a_lo[m] = tr8(a_base + DIMG + (size_t)(r * T9_TW) * PD + m * 64, PD);
+            }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -161,53 +176,59 @@ __global__ __launch_bounds__(256, 1) void wgrad_t9_kernel(const T9Args A) {
                     const char* at = b_base + (size_t)((r + ky) * T9_PW + kx) * T9_PX;
                     const v8bf16 b_hi = tr8(at, T9_PX), b_lo = tr8(at + T9_XIMG, T9_PX);
                     const int t = ky * 3 + kx;
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) {
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[m], b_hi, acc[m][t], 0, 0, 0);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[m], b_lo, acc[m][t], 0, 0, 0);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[m], b_hi, acc[m][t], 0, 0, 0);
+                    }
                 }
         }
     }
-    float* slab = P.slabs + (size_t)wg * T9_SLAB;
+    float* slab = A.slabs + ((size_t)ji * A.nwg + wg) * t9_slab(TM);
     const int ci = wave * 32 + c;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
-            slab[((size_t)t * T9_COUT + co) * T9_CIN + ci] = acc[t][r];
-        }
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                slab[((size_t)t * (TM * 32) + co) * T9_CIN + ci] = acc[m][t][r];
+            }
 }
 
-// dw[co][ci][tap] (+)= sum over a problem's slabs [tap][co][ci], fixed order; 8 slab ranges x 32 outputs per workgroup
+// dw[co][ci][tap] (+)= sum over a job's slabs [tap][co][ci], fixed order; 8 slab ranges x 32 outputs per workgroup
+template <int TM>
 __global__ __launch_bounds__(256) void wgrad_t9_reduce_kernel(const T9Args A) {
     __shared__ float red[8][32];
-    constexpr int per_problem = (T9_SLAB + 31) / 32;
-    const int pi = blockIdx.x / per_problem, blk = blockIdx.x - pi * per_problem;
-    const T9Problem P = A.p[pi];
+    constexpr int SLAB = t9_slab(TM), per_job = SLAB / 32;
+    const int ji = blockIdx.x / per_job, blk = blockIdx.x - ji * per_job;
+    const T9Job P = A.j[ji];
     const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int i = blk * 32 + col;                          // slab element: (tap, co, ci)
+    const int i = blk * 32 + col;                          // slab element: (tap, co, ci); a block's 32 share (tap, co)
+    const int tap = i / (TM * 32 * T9_CIN), rem = i - tap * (TM * 32 * T9_CIN);
+    const int co = rem / T9_CIN, ci = rem - co * T9_CIN;
+    if (co >= P.cout_w) return;                            // (uniform per block)
+    const float* base = A.slabs + (size_t)ji * A.nwg * SLAB + i;
     const int per = (A.nwg + 7) / 8, g0 = part * per, g1 = min(A.nwg, g0 + per);
     float s = 0.0f;
-    if (i < T9_SLAB) {
-        int g = g0;
-        for (; g + 8 <= g1; g += 8) {
-            float v[8];
+    int g = g0;
+    for (; g + 8 <= g1; g += 8) {
+        float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = P.slabs[(size_t)(g + u) * T9_SLAB + i];
+        for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(g + u) * SLAB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        for (; g < g1; ++g) s += P.slabs[(size_t)g * T9_SLAB + i];
+        for (int u = 0; u < 8; ++u) s += v[u];
     }
+    for (; g < g1; ++g) s += base[(size_t)g * SLAB];
     red[part][col] = s;
     __syncthreads();
-    if (part == 0 && i < T9_SLAB) {
+    if (part == 0) {
         float t = red[0][col];
 #pragma unroll
         for (int u = 1; u < 8; ++u) t += red[u][col];
-        const int tap = i / (T9_COUT * T9_CIN), rem = i - tap * (T9_COUT * T9_CIN);
-        const int co = rem / T9_CIN, ci = rem - co * T9_CIN;
-        float* o = P.dw + ((size_t)co * T9_CIN + ci) * 9 + tap;
+        float* o = P.dw + ((size_t)co * P.cin_total + ci) * 9 + tap;
         *o = P.accumulate ? *o + t : t;
     }
 }
@@ -407,23 +428,25 @@ int t1_grid() {
     return g_t1_grid;
 }
 
-int g_t9_grid = 0;
+int g_t9_grid[3] = {0, 0, 0};
+template <int TM>
 int t9_grid() {
-    if (!g_t9_grid) {
+    if (!g_t9_grid[TM]) {
         int dev = 0, per_cu = 0;
         hipDeviceProp_t p;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess ||
-            hipFuncSetAttribute((const void*)wgrad_t9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T9_LDS) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_t9_kernel, 256, T9_LDS) != hipSuccess || per_cu <= 0)
-            return 512;
-        g_t9_grid = per_cu * p.multiProcessorCount;
+            hipFuncSetAttribute((const void*)wgrad_t9_kernel<TM>, hipFuncAttributeMaxDynamicSharedMemorySize, t9_lds(TM)) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_t9_kernel<TM>, 256, t9_lds(TM)) != hipSuccess || per_cu <= 0)
+            return 256;
+        g_t9_grid[TM] = per_cu * p.multiProcessorCount;
     }
-    return g_t9_grid;
+    return g_t9_grid[TM];
 }
 
 }  // namespace
 
-// (not part of the public ABI: csrc/train.hip's ossid_conv_wgrad_group / ..._workspace_bytes route eligible problems here)
+// (not part of the public ABI: csrc/train.hip's ossid_conv_wgrad / ossid_conv_wgrad_group and their workspace queries route
+// eligible problems here)
 bool ossid_wgrad_t9_takes(const ossid_wgrad_desc* d) {
 #ifdef OSSID_WGRAD_F32
     (void)d;
@@ -431,52 +454,92 @@ bool ossid_wgrad_t9_takes(const ossid_wgrad_desc* d) {
 #else
     const int in_cs = d->in_channel_stride > 0 ? d->in_channel_stride : d->cin;
     const int dy_cs = d->dy_channel_stride > 0 ? d->dy_channel_stride : d->cout;
-    return d->taps == 9 && d->cin == T9_CIN && d->cout == T9_COUT && (d->src_height <= 0 || d->src_height == d->height) &&
-           (d->src_width <= 0 || d->src_width == d->width) && in_cs % 4 == 0 && dy_cs % 4 == 0 && !((uintptr_t)d->x & 15) &&
-           !((uintptr_t)d->dy & 15) && d->batch > 0 && d->height > 0 && d->width > 0;
+    return d->taps == 9 && d->cin >= T9_CIN && d->cin % T9_CIN == 0 && d->cout >= 32 && d->cout % 4 == 0 &&
+           (d->src_height <= 0 || d->src_height == d->height) && (d->src_width <= 0 || d->src_width == d->width) &&
+           in_cs % 4 == 0 && dy_cs % 4 == 0 && !((uintptr_t)d->x & 15) && !((uintptr_t)d->dy & 15) &&
+           (!d->pre_scale || !((uintptr_t)d->pre_scale & 15)) && (!d->pre_shift || !((uintptr_t)d->pre_shift & 15)) &&
+           d->batch > 0 && d->height > 0 && d->width > 0;
 #endif
 }
 
-// workgroups per problem for a group of n same-shaped problems
-static int t9_nwg(int n, long long ntiles) {
-    int nwg = t9_grid() / n;
+// output channels per job: 64 once the layer has that many
+static int t9_tm(const ossid_wgrad_desc& d) { return d.cout >= 64 ? 2 : 1; }
+static int t9_jobs_of(const ossid_wgrad_desc& d) { return ((d.cout + 32 * t9_tm(d) - 1) / (32 * t9_tm(d))) * (d.cin / T9_CIN); }
+static long long t9_tiles(const ossid_wgrad_desc& d) {
+    return (long long)d.batch * ((d.height + T9_TH - 1) / T9_TH) * ((d.width + T9_TW - 1) / T9_TW);
+}
+static int t9_nwg(int tm, int jobs, long long ntiles) {
+    int nwg = (tm == 2 ? t9_grid<2>() : t9_grid<1>()) / jobs;
     if (nwg < 1) nwg = 1;
     if (nwg > ntiles) nwg = (int)ntiles;
     return nwg;
 }
-
-size_t ossid_wgrad_t9_workspace_bytes(const ossid_wgrad_desc* descs, int n) {
-    if (n <= 0 || n > T9_MAX) return 0;
-    const long long nt = (long long)descs[0].batch * ((descs[0].height + T9_TH - 1) / T9_TH) * ((descs[0].width + T9_TW - 1) / T9_TW);
-    return (size_t)n * t9_nwg(n, nt) * T9_SLAB * sizeof(float);
+int ossid_wgrad_t9_max_jobs(void) { return T9_MAX; }
+int ossid_wgrad_t9_class(const ossid_wgrad_desc* d) { return t9_tm(*d); }          // problems of one call share it
+int ossid_wgrad_t9_job_count(const ossid_wgrad_desc* descs, int n) {
+    int jobs = 0;
+    for (int i = 0; i < n; ++i) jobs += t9_jobs_of(descs[i]);
+    return jobs;
 }
 
-// n <= 24 problems of ONE geometry (batch, height, width), all accepted by ossid_wgrad_t9_takes
+// n problems of ONE geometry (batch, height, width) and one class, all accepted by ossid_wgrad_t9_takes. A problem with more
+// jobs than a launch takes is cut over several launches here; the list as a whole may be of any length.
+size_t ossid_wgrad_t9_workspace_bytes(const ossid_wgrad_desc* descs, int n) {
+    if (n <= 0) return 0;
+    const int tm = t9_tm(descs[0]);
+    const int jobs = ossid_wgrad_t9_job_count(descs, n);
+    const int per_launch = jobs < T9_MAX ? jobs : T9_MAX;
+    // (every launch of the call has at most per_launch jobs, hence at least this many workgroups per job)
+    return (size_t)jobs * t9_nwg(tm, per_launch, t9_tiles(descs[0])) * t9_slab(tm) * sizeof(float);
+}
+
 int ossid_wgrad_t9_group(const ossid_wgrad_desc* descs, int n, void* workspace, size_t workspace_bytes, void* stream) {
-    if (n <= 0 || n > T9_MAX || !workspace || ((uintptr_t)workspace & 15)) return OSSID_EINVAL;
+    if (n <= 0 || !workspace || ((uintptr_t)workspace & 15)) return OSSID_EINVAL;
+    const int tm = t9_tm(descs[0]);
+    const int jobs_all = ossid_wgrad_t9_job_count(descs, n);
+    const int per_launch = jobs_all < T9_MAX ? jobs_all : T9_MAX;
     T9Args a;
-    a.n = n, a.B = descs[0].batch, a.H = descs[0].height, a.W = descs[0].width;
+    a.B = descs[0].batch, a.H = descs[0].height, a.W = descs[0].width;
     a.tiles_y = (a.H + T9_TH - 1) / T9_TH, a.tiles_x = (a.W + T9_TW - 1) / T9_TW;
-    const long long nt = (long long)a.B * a.tiles_y * a.tiles_x;
+    const long long nt = t9_tiles(descs[0]);
     if (nt > 0x7fffffff) return OSSID_EINVAL;
     a.ntiles = (int)nt;
-    a.nwg = t9_nwg(n, nt);
-    if (workspace_bytes < (size_t)n * a.nwg * T9_SLAB * sizeof(float)) return OSSID_EINVAL;
+    a.nwg = t9_nwg(tm, per_launch, nt);
+    if (workspace_bytes < (size_t)jobs_all * a.nwg * t9_slab(tm) * sizeof(float)) return OSSID_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    auto flush = [&]() {
+        if (a.n == 0) return;
+        a.slabs = ws;
+        if (tm == 2) {
+            hipLaunchKernelGGL(wgrad_t9_kernel<2>, dim3((unsigned)(a.n * a.nwg)), dim3(256), t9_lds(2), s, a);
+            hipLaunchKernelGGL(wgrad_t9_reduce_kernel<2>, dim3((unsigned)(a.n * (t9_slab(2) / 32))), dim3(256), 0, s, a);
+        } else {
+            hipLaunchKernelGGL(wgrad_t9_kernel<1>, dim3((unsigned)(a.n * a.nwg)), dim3(256), t9_lds(1), s, a);
+            hipLaunchKernelGGL(wgrad_t9_reduce_kernel<1>, dim3((unsigned)(a.n * (t9_slab(1) / 32))), dim3(256), 0, s, a);
+        }
+        ws += (size_t)a.n * a.nwg * t9_slab(tm);
+        a.n = 0;
+    };
+    a.n = 0;
     for (int i = 0; i < n; ++i) {
         const ossid_wgrad_desc& d = descs[i];
-        if (!ossid_wgrad_t9_takes(&d) || d.batch != a.B || d.height != a.H || d.width != a.W || !d.dw || (d.pre_scale && !d.pre_shift))
+        if (!ossid_wgrad_t9_takes(&d) || t9_tm(d) != tm || d.batch != a.B || d.height != a.H || d.width != a.W || !d.dw ||
+            (d.pre_scale && !d.pre_shift))
             return OSSID_EINVAL;
-        T9Problem& p = a.p[i];
-        p.x = d.x, p.dy = d.dy, p.pre_scale = d.pre_scale, p.pre_shift = d.pre_shift, p.dw = d.dw;
-        p.slabs = (float*)workspace + (size_t)i * a.nwg * T9_SLAB;
-        p.in_cs = d.in_channel_stride > 0 ? d.in_channel_stride : d.cin;
-        p.dy_cs = d.dy_channel_stride > 0 ? d.dy_channel_stride : d.cout;
-        p.pre_relu = d.pre_relu, p.accumulate = d.accumulate;
+        const int in_cs = d.in_channel_stride > 0 ? d.in_channel_stride : d.cin;
+        const int dy_cs = d.dy_channel_stride > 0 ? d.dy_channel_stride : d.cout;
+        for (int co0 = 0; co0 < d.cout; co0 += 32 * tm)
+            for (int ci0 = 0; ci0 < d.cin; ci0 += T9_CIN) {
+                T9Job& j = a.j[a.n++];
+                j.x = d.x + ci0, j.dy = d.dy + co0, j.dw = d.dw + ((size_t)co0 * d.cin + ci0) * 9;
+                j.pre_scale = d.pre_scale ? d.pre_scale + ci0 : nullptr, j.pre_shift = d.pre_shift ? d.pre_shift + ci0 : nullptr;
+                j.cin_total = d.cin, j.cout_w = d.cout - co0 < 32 * tm ? d.cout - co0 : 32 * tm;
+                j.in_cs = in_cs, j.dy_cs = dy_cs, j.pre_relu = d.pre_relu, j.accumulate = d.accumulate;
+                if (a.n == T9_MAX) flush();
+            }
     }
-    hipStream_t s = (hipStream_t)stream;
-    t9_grid();                                             // (sets the dynamic-LDS attribute once)
-    hipLaunchKernelGGL(wgrad_t9_kernel, dim3((unsigned)(n * a.nwg)), dim3(256), T9_LDS, s, a);
-    hipLaunchKernelGGL(wgrad_t9_reduce_kernel, dim3((unsigned)(n * ((T9_SLAB + 31) / 32))), dim3(256), 0, s, a);
+    flush();
     return ossid_launch_status();
 }
 
