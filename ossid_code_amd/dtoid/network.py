@@ -630,7 +630,7 @@ class FusedBackbone:
     # next dense block's buffer
     use_pooled_transitions = os.environ.get("OSSID_POOLED_TRANSITIONS", "1") != "0"
     # a dense block of at most this many pixels (batch x height x width) takes the one-launch-per-layer form
-    DENSE_FUSED_MAX_PIXELS = int(os.environ.get("OSSID_DENSE_FUSED_MAX_PIXELS", "6000"))
+    DENSE_FUSED_MAX_PIXELS = int(os.environ.get("OSSID_DENSE_FUSED_MAX_PIXELS", "20000"))
 
     def __call__(self, image, template_feat, raw_image=False):
         """raw_image: `image` is in [0, 1] and normalizeImageRange is applied inside the stem's gather (D1)."""

@@ -14,7 +14,7 @@ python tools/stats_by_pass.py $O/stats/*/*kernel_trace.csv --steps 20 --warmup 5
 rocprofv3 --kernel-trace -d $O/ft --output-format csv -- python3 tools/bench_finetune.py --reps 3 --no-graph > $O/ft.log 2>&1
 python tools/trace_step.py $O/ft/*/*kernel_trace.csv --top 45 > $O/finetune_step_kernels.txt
 rocprofv3 --kernel-trace -d $O/fw --output-format csv -- python3 tools/bench_dtoid.py --what forward > $O/fw.log 2>&1
-python tools/trace_step.py $O/fw/*/*kernel_trace.csv --marker nms_scan --top 40 > $O/forward_step_kernels.txt
+python tools/trace_step.py $O/fw/*/*kernel_trace.csv --marker detect_emit --top 40 > $O/forward_step_kernels.txt
 python tools/train_layers_bench.py --json $O/train_layers.json > $O/train_layers.txt 2>&1
 python tools/train_layers_bench.py --what fwd,dgrad --wino > $O/train_layers_wino.txt 2>&1
 for k in fwd_x6 fwd_exact; do python tools/train_layers_bench.py --what fwd --fwd-kind $k --only "^b[1-4]|^t[1-3]" > $O/train_layers_$k.txt 2>&1; done
@@ -25,5 +25,12 @@ python tools/stem_bench.py > $O/stem_kernels.txt 2>&1
 python tools/wgrad_group_bench.py > $O/wgrad_group.txt 2>&1
 rocprofv3 --kernel-trace -d $O/ft2 --output-format csv -- python3 tools/bench_finetune.py --reps 3 --no-graph > $O/ft2.log 2>&1
 python tools/step_timeline.py $O/ft2/*/*kernel_trace.csv > $O/finetune_step_timeline.txt
+python tools/step_gaps.py $O/ft2/*/*kernel_trace.csv --min-us 100 > $O/finetune_step_gaps.txt
 rm -rf $O/ft2
+python tools/dense_bench.py --blocks b1,b2,b3,b4 > $O/dense_blocks.txt 2>&1
+python tools/forward_split.py > $O/forward_split.txt 2>&1
+rocprofv3 --kernel-trace -d $O/fw2 --output-format csv -- python3 tools/bench_dtoid.py --what forward > $O/fw2.log 2>&1
+python tools/trace_list.py $O/fw2/*/*kernel_trace.csv --marker detect_emit > $O/forward_step_list.txt
+rm -rf $O/fw2
+python tools/bench_finetune.py --reps 10 --no-graph > $O/finetune_ms.txt 2>&1
 ls -la $O
