@@ -404,6 +404,20 @@ typedef struct ossid_pack_row {
 } ossid_pack_row;
 int ossid_conv_pack_weights_table(const ossid_pack_row* rows_device, int n_rows, long long total_blocks, void* stream);
 
+/* D16  backward of a dense layer's 1x1 convolution (torchvision _DenseLayer.conv1 inside ImageFeatExtract, network.py:164-184)
+ * with the block's gradient accumulation fused in (csrc/dense_bwd.hip): for the first c channels of the gradient buffer G
+ * [n_rows][channel_stride],  G[r][ch] += alpha[ch] * m * (dz[r][:] . W1[:, ch]),  m = (mask_scale[ch] x[r][ch] + mask_shift[ch] > 0)
+ * -- the data gradient of conv1 (c -> 128; wpk_dgrad = ossid_conv_pack_weights_dgrad(w [128][c][1])) through relu(norm1(.)) --
+ * and norm1's column sums as partial rows for ossid_bn_fold_bwd: partials [P][2][c], row 0 = sum of g m, row 1 = sum of g m x
+ * (g = the raw data gradient), P = ossid_dense_dgrad1_acc_partials(n_rows). What ossid_conv_nhwc_fwd (data-gradient weights)
+ * followed by ossid_chan_op (mask_mode 1, accumulate, sum_mode 1) computes, without the [n_rows][c] tensor in between; same
+ * three-product bf16 arithmetic, f32 sums in another order. c % 32 == 0, c <= 1024, n_rows * channel_stride < 2^32; returns
+ * OSSID_EINVAL in a -DOSSID_CONV_F32 build. */
+int ossid_dense_dgrad1_acc_partials(long long n_rows);
+int ossid_dense_dgrad1_acc(const float* dz, const float* wpk_dgrad, const float* x, float* G, long long n_rows, int c,
+                           int channel_stride, const float* alpha, const float* mask_scale, const float* mask_shift, float* partials,
+                           void* stream);
+
 /* D4  nn.AvgPool2d(2, stride) of the DenseNet transitions (stride 2; the third one stride 1, network.py:165),
  * channels-last. backward != 0: x is d out [B][Ho][Wo][C] and out receives d in [B][H][W][C]. */
 int ossid_avgpool2_nhwc(const float* x, int B, int H, int W, int C, int stride, float* out, int backward, void* stream);

@@ -826,6 +826,24 @@ def _dense_forward(buf, table, block, params, C0):
     return saved
 
 
+# The dense layers' 1x1 data gradient with the masked, scaled accumulation onto the block's gradient buffer and norm1's column
+# sums in ONE launch (csrc/dense_bwd.hip) instead of the convolution + a generic pass over a [N][c] tensor in between.
+DENSE_BWD_FUSED = os.environ.get("OSSID_DENSE_BWD_FUSED", "1") != "0"
+
+
+def dense_dgrad1_acc(dz, wpk_dgrad, buf, G, N, c, Ct, alpha, ms, mt):
+    """G[:, :c] += alpha * relu'(ms * buf + mt) * (dz @ W1); returns the (partials, P) pair of norm1's column sums for
+    bn_fold_bwd -- valid until the next call on this stream."""
+    dev = dz.device
+    P = _lib.fn("ossid_dense_dgrad1_acc_partials")(int(N))
+    part = _scratch("dgrad1_acc", P * 2 * c * 4, dev)
+    with _lib.on_device(dev):
+        _lib.check(_lib.fn("ossid_dense_dgrad1_acc")(dz.data_ptr(), wpk_dgrad.data_ptr(), buf.data_ptr(), G.data_ptr(), int(N), int(c),
+                                                     int(Ct), alpha.data_ptr(), ms.data_ptr(), mt.data_ptr(), part.data_ptr(),
+                                                     _lib.stream()), "ossid_dense_dgrad1_acc")
+    return part, P
+
+
 def _dense_backward(G, buf, saved, block, params, C0, side, direct=False):
     """The backward launches of a dense block whose output gradient already sits in G (ours to accumulate into); raw ops
     only. Returns (dx [B,C0,H,W] compact, parameter gradients in `params` order). side: the block's grouped weight-gradient
@@ -840,6 +858,8 @@ def _dense_backward(G, buf, saved, block, params, C0, side, direct=False):
     dz_all = new_buf((L, B, H, W, mid), dev)                      # per layer: the 1x1 wgrad runs at the end
     deferred = []                                                 # the block's 2 L weight gradients: ONE grouped launch below
     da = None
+    fused_bwd = (DENSE_BWD_FUSED and mid == 128 and Ct <= 1024 and N * Ct < (1 << 32) and
+                 bool(_lib.fn("ossid_conv_split_bf16")()))
     c = C0 + L * growth
     for li in range(L - 1, -1, -1):
         c -= growth
@@ -869,11 +889,14 @@ def _dense_backward(G, buf, saved, block, params, C0, side, direct=False):
                              pre_relu=True, in_cs=Ct))
         # ... then one pass that masks with relu(bn1(buf)), scales, ACCUMULATES onto the gradient buffer's channel prefix
         # and sums (d shift, d scale)
-        if da is None:
-            da = new_buf((B, Ct, H, W), dev, channels_last=True)
-        conv_raw(db, _pack(w1, "dgrad"), B, H, W, mid, c, 1, da)
-        s = chan_op(da, N, c, x=buf, out=G, x_cs=Ct, out_cs=Ct, alpha=f1[0], mask_mode=1, mask_scale=f1[0],
-                    mask_shift=f1[1], accumulate=True, sum_mode=1, defer=True)
+        if fused_bwd:
+            s = dense_dgrad1_acc(db, _pack(w1, "dgrad"), buf, G, N, c, Ct, f1[0], f1[0], f1[1])
+        else:
+            if da is None:
+                da = new_buf((B, Ct, H, W), dev, channels_last=True)
+            conv_raw(db, _pack(w1, "dgrad"), B, H, W, mid, c, 1, da)
+            s = chan_op(da, N, c, x=buf, out=G, x_cs=Ct, out_cs=Ct, alpha=f1[0], mask_mode=1, mask_scale=f1[0],
+                        mask_shift=f1[1], accumulate=True, sum_mode=1, defer=True)
         r1 = new_buf((2, c), dev)
         bn_fold_bwd(None, None, g1, f1[2], f1[3], c, N, r1[0], r1[1], coef[0], coef[1], accumulate=True, partials=s)
         grads[6 * li:6 * li + 6] = [r1[0], r1[1], dw1, r2[0], r2[1], dw2]
