@@ -413,6 +413,18 @@ int ossid_conv_pack_weights_table(const ossid_pack_row* rows_device, int n_rows,
  * followed by ossid_chan_op (mask_mode 1, accumulate, sum_mode 1) computes, without the [n_rows][c] tensor in between; same
  * three-product bf16 arithmetic, f32 sums in another order. c % 32 == 0, c <= 1024, n_rows * channel_stride < 2^32; returns
  * OSSID_EINVAL in a -DOSSID_CONV_F32 build. */
+/* ... and its FORWARD with norm2's batch statistics in the epilogue: y1 [n_rows][128] = conv1(relu(pre_scale x + pre_shift)) on
+ * the first c channels of x [n_rows][channel_stride], wpk_x6 = ossid_conv_pack_weights_form(w [128][c][1], exact = 2) (the
+ * three-way split: f32-level accuracy), and P = ossid_dense_fwd1_stats_partials(n_rows) partial rows [P][3][128] = per-channel
+ * (sum of (y1 - p_w), sum of (y1 - p_w)^2, p_w) about each workgroup's OWN pivot p_w (its first output of the channel) with
+ * counts [P] = pixels per row: ossid_conv_nhwc_fwd (exact = 2) followed by ossid_chan_op (sum_mode 3) without the second read of
+ * y1. ossid_bn_fold_fwd_rows is ossid_bn_fold_fwd for such rows (moved to one common pivot in double). c % 32 == 0. */
+int ossid_dense_fwd1_stats_partials(long long n_rows);
+int ossid_dense_fwd1_stats(const float* x, int channel_stride, int c, const float* pre_scale, const float* pre_shift,
+                           const float* wpk_x6, long long n_rows, float* y1, float* partials, float* counts, void* stream);
+int ossid_bn_fold_fwd_rows(const float* partials, const float* counts, int n_partials, int C, double n, const float* gamma,
+                           const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                           float* shift, float* mean_out, float* rstd_out, void* stream);
 int ossid_dense_dgrad1_acc_partials(long long n_rows);
 int ossid_dense_dgrad1_acc(const float* dz, const float* wpk_dgrad, const float* x, float* G, long long n_rows, int c,
                            int channel_stride, const float* alpha, const float* mask_scale, const float* mask_shift, float* partials,

@@ -152,6 +152,240 @@ __global__ __launch_bounds__(256, 2) void dense_dgrad1_acc_kernel(const DenseBwd
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// FORWARD of the same convolution with norm2's batch statistics in its epilogue: y1[px][co] = W1[co][:] . relu(s1 x[px][:] + t1)
+// (c -> 128) and, per output channel, the sums of (y1 - pivot) and (y1 - pivot)^2 as partial rows for ossid_bn_fold_fwd --
+// round 3 ran the convolution (csrc/conv.hip) and then a generic pass that read y1 again just for the two sums (58 launches
+// and 0.9 GB per step). Same transposed scheme: pixels on M (A = the staged activations), output channels on N (B = conv1's
+// FORWARD layout for the three-way split, ossid_conv_pack_weights_form(exact = 2)), so a lane holds one output channel and its
+// sums are register sums. Arithmetic: the three-way split of csrc/conv.hip's FORM 2 (x = p0 + p1 + p2 in bf16, six products:
+// f32-level accuracy -- a ReLU decides on these outputs in training), f32 accumulation.
+// Workgroup = 64 pixels x 128 output channels (wave w = channels 32w ..), the reduction in chunks of 64 input channels through
+// double-buffered LDS (rows [pixel][unit][p0 | p1 | p2 x 2 halves]); persistent over the 64-pixel stages, one partial row each.
+constexpr int DF_KCH = 64;
+constexpr int DF_PSTR = DF_KCH / 16 * 6 + 1;            // float4 per pixel and chunk: 4 units x 3 pieces x 2 halves + 1
+
+struct DenseFwdArgs {
+    const float* x;           // [N][cs], first c channels
+    const float4* wpk;        // conv1, forward layout, three pieces: [4 tiles][c/16][3][64 lanes] x 16 B
+    const float *ps, *pt;     // norm1 as scale / shift [c] (ReLU behind it)
+    float* y1;                // [N][128]
+    float* partials;          // [gridDim.x][3][128]: sums of (y1 - p), (y1 - p)^2, and p = the workgroup's own pivot
+    float* counts;            // [gridDim.x]: pixels the workgroup summed over
+    long long N;
+    int c, cs, nstages;
+};
+
+// PT = 32-pixel tiles per stage: 2 where the pixels make more than ~1.5 stages of 64 per CU, else 1 (more, shorter workgroups)
+template <int PT>
+__global__ __launch_bounds__(256, 2) void dense_fwd1_stats_kernel(const DenseFwdArgs A) {
+    constexpr int PXS = 32 * PT;
+    __shared__ __attribute__((aligned(16))) float4 xl[2][PXS * DF_PSTR];     // 2 x 25 600 B at PT = 2
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, n = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int units = A.c / 16, nchunks = (A.c + DF_KCH - 1) / DF_KCH;
+    const int co = wave * 32 + n;
+    // The sums are taken about a PIVOT (no E[y^2] - E[y]^2 cancellation), and it has to be a value near the channel's mean that
+    // is known before the first sum: each workgroup takes its own first output of the channel (a sample: within a few standard
+    // deviations of the mean); ossid_bn_fold_fwd_rows moves every row's sums to one common pivot, in double. (A fixed pivot --
+    // 0, or BatchNorm's running mean -- was measured: a fresh network's bottleneck outputs have |mean| >> std in some channels and
+    // the statistics came out 1e-3 off.)
+    float pv = 0.0f;
+    bool have_pv = false;
+    float s1 = 0.0f, s2 = 0.0f, npx = 0.0f;
+    // staging map: 32 PT pixels x 16 float4 per chunk, 2 PT per thread
+    const int j = tid & 15;
+    float4 st[2 * PT];
+    auto fetch = [&](long long p0, int ch0) {
+        const bool ok = ch0 + 4 * j < A.c;                                       // (a ragged last chunk: c is a multiple of 32)
+#pragma unroll
+        for (int e = 0; e < 2 * PT; ++e) {
+            const long long p = min(p0 + (tid >> 4) + 16 * e, A.N - 1);
+            st[e] = ok ? *(const float4*)(A.x + (size_t)p * A.cs + ch0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&](int buf, int ch0) {
+        const bool ok = ch0 + 4 * j < A.c;
+        float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pt = ps;
+        if (ok) ps = *(const float4*)(A.ps + ch0 + 4 * j), pt = *(const float4*)(A.pt + ch0 + 4 * j);
+        uint2* p2 = (uint2*)xl[buf];
+        const int u = j >> 2, jj = j & 3;
+#pragma unroll
+        for (int e = 0; e < 2 * PT; ++e) {
+            const int px = (tid >> 4) + 16 * e;
+            float v[4] = {fmaxf(st[e].x * ps.x + pt.x, 0.f), fmaxf(st[e].y * ps.y + pt.y, 0.f), fmaxf(st[e].z * ps.z + pt.z, 0.f),
+                          fmaxf(st[e].w * ps.w + pt.w, 0.f)};
+            union {
+                __bf16 b4[4];
+                uint2 u2;
+            } pc[3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float r = v[i];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    pc[k].b4[i] = (__bf16)r;
+                    r -= (float)pc[k].b4[i];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p2[(px * DF_PSTR + u * 6 + k * 2) * 2 + jj] = pc[k].u2;
+        }
+    };
+    const float4* W4 = A.wpk + (size_t)wave * units * 3 * 64 + lane;
+    for (int stage = blockIdx.x; stage < A.nstages; stage += gridDim.x) {
+        const long long p0 = (long long)stage * PXS;
+        v16f acc[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[pt][r] = 0.0f;
+        fetch(p0, 0);
+        // this wave's weights ride one chunk ahead of their MFMAs in registers (4 units x 3 pieces; units past the last one
+        // re-read the last: never multiplied)
+        float4 wc[4][3], wn[4][3];
+        auto wload = [&](int ch, float4 (&w)[4][3]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4* wq = W4 + (size_t)min(ch * 4 + u, units - 1) * 3 * 64;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) w[u][k] = wq[k * 64];
+            }
+        };
+        wload(0, wc);
+        __syncthreads();                                   // (the previous stage's last chunk has been read)
+        commit(0, 0);
+#pragma unroll 1
+        for (int ch = 0; ch < nchunks; ++ch) {
+            __syncthreads();
+            if (ch + 1 < nchunks) {
+                fetch(p0, (ch + 1) * DF_KCH);              // in flight under this chunk's MFMAs
+                wload(ch + 1, wn);
+            }
+            const int nu = min(4, units - ch * 4);
+            const float4* zb = xl[ch & 1] + (size_t)n * DF_PSTR + h;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u >= nu) break;
+                const v8bf b0 = __builtin_bit_cast(v8bf, wc[u][0]), b1 = __builtin_bit_cast(v8bf, wc[u][1]), b2 = __builtin_bit_cast(v8bf, wc[u][2]);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const float4* zp = zb + (size_t)pt * 32 * DF_PSTR + u * 6;
+                    const v8bf a0 = __builtin_bit_cast(v8bf, zp[0]), a1 = __builtin_bit_cast(v8bf, zp[2]), a2 = __builtin_bit_cast(v8bf, zp[4]);
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[pt], 0, 0, 0);      // smallest terms first
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[pt], 0, 0, 0);
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[pt], 0, 0, 0);
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[pt], 0, 0, 0);
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[pt], 0, 0, 0);
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[pt], 0, 0, 0);
+                }
+            }
+            if (ch + 1 < nchunks) {
+                commit((ch + 1) & 1, (ch + 1) * DF_KCH);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) wc[u][k] = wn[u][k];
+            }
+        }
+        if (!have_pv) {                                    // (uniform: the workgroup's first stage; its row p0 exists)
+            pv = __shfl(acc[0][0], n);                     // lane n (h = 0) holds pixel row p0 of channel co: both halves take it
+            have_pv = true;
+        }
+        npx += (float)min((long long)PXS, A.N - p0);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = p0 + pt * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (row >= A.N) continue;
+                const float v = acc[pt][r];
+                A.y1[(size_t)row * DB_MID + co] = v;
+                const float d = v - pv;
+                s1 += d, s2 += d * d;
+            }
+    }
+    const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
+    if (h == 0) {
+        float* prow = A.partials + (size_t)blockIdx.x * 3 * DB_MID;
+        prow[co] = t1, prow[DB_MID + co] = t2, prow[2 * DB_MID + co] = pv;
+    }
+    if (tid == 0) A.counts[blockIdx.x] = npx;
+}
+
+// Training BatchNorm folded to (scale, shift) from partial rows that each carry their OWN pivot: rows [P][3][C] = (sum (x - p_w),
+// sum (x - p_w)^2, p_w), counts [P] = elements per row. Every row is moved to the common pivot q = p_0 in double --
+// S1' = S1 + n_w d, S2' = S2 + 2 d S1 + n_w d^2 with d = p_w - q -- and the rest is ossid_bn_fold_fwd's arithmetic.
+__global__ __launch_bounds__(256) void bn_fold_fwd_rows_kernel(const float* __restrict__ partials, const float* __restrict__ counts, int P,
+                                                               int C, double n, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, float momentum,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               float* __restrict__ scale, float* __restrict__ shift,
+                                                               float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    // 4 channels x 64 row ranges per block: a thread's <= 8 rows are loaded together (this launch sits on the step's critical
+    // chain 58 times: its time is the number of dependent rounds of loads)
+    __shared__ double red[64][4][2];
+    const int col = threadIdx.x & 3, part = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + col;
+    double a1 = 0.0, a2 = 0.0, q = 0.0;
+    if (c < C) {
+        q = (double)partials[2 * (size_t)C + c];
+        for (int w0 = part; w0 < P; w0 += 64 * 8) {
+            float s1[8], s2[8], pw[8], nw[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int w = w0 + 64 * k;
+                const bool ok = w < P;
+                const float* row = partials + (size_t)(ok ? w : 0) * 3 * C + c;
+                s1[k] = row[0], s2[k] = row[C], pw[k] = row[2 * (size_t)C], nw[k] = ok ? counts[w] : -1.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (nw[k] < 0.0f) continue;
+                const double d = (double)pw[k] - q;
+                a1 += (double)s1[k] + (double)nw[k] * d;
+                a2 += (double)s2[k] + 2.0 * d * (double)s1[k] + (double)nw[k] * d * d;
+            }
+        }
+    }
+    red[part][col][0] = a1, red[part][col][1] = a2;
+    __syncthreads();
+    if (part != 0 || c >= C) return;
+    for (int k = 1; k < 64; ++k) a1 += red[k][col][0], a2 += red[k][col][1];
+    const double dm = a1 / n;
+    const double mean = q + dm;
+    double var = a2 / n - dm * dm;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+    const float sc = (float)((double)g * rstd);
+    scale[c] = sc;
+    shift[c] = (float)((double)b - mean * (double)sc);
+    mean_out[c] = (float)mean;
+    rstd_out[c] = (float)rstd;
+    if (running_mean) {   // torch: running = (1 - momentum) * running + momentum * batch (unbiased variance)
+        const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+    }
+}
+
+int g_df_grid = 0;
+int df_grid() {
+    if (!g_df_grid) {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dense_fwd1_stats_kernel<2>, 256, 0) != hipSuccess || per_cu <= 0)
+            return 512;
+        if (per_cu > 2) per_cu = 2;
+        g_df_grid = per_cu * p.multiProcessorCount;
+    }
+    return g_df_grid;
+}
+// pixels per stage for n_rows: 64, or 32 where 64-pixel stages would leave the chip under ~1.5 workgroups per CU
+int df_pxs(long long n_rows) { return (n_rows + 63) / 64 >= 384 ? 64 : 32; }
+
 int g_db_grid = 0;
 int db_grid() {
     if (!g_db_grid) {
@@ -192,6 +426,43 @@ int ossid_dense_dgrad1_acc(const float* dz, const float* wpk_dgrad, const float*
     a.nstages = (int)stages;
     hipLaunchKernelGGL(dense_dgrad1_acc_kernel, dim3((unsigned)ossid_dense_dgrad1_acc_partials(n_rows)), dim3(256), 0,
                        (hipStream_t)stream, a);
+    return ossid_launch_status();
+}
+
+int ossid_dense_fwd1_stats_partials(long long n_rows) {
+    const int pxs = df_pxs(n_rows);
+    const long long stages = (n_rows + pxs - 1) / pxs;
+    const int g = df_grid();
+    return (int)(stages < g ? stages : g);
+}
+
+int ossid_bn_fold_fwd_rows(const float* partials, const float* counts, int n_partials, int C, double n, const float* gamma,
+                           const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                           float* shift, float* mean_out, float* rstd_out, void* stream) {
+    if (!partials || !counts || n_partials <= 0 || C <= 0 || n <= 0 || !scale || !shift || !mean_out || !rstd_out ||
+        (!running_mean != !running_var))
+        return OSSID_EINVAL;
+    hipLaunchKernelGGL(bn_fold_fwd_rows_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, counts, n_partials, C,
+                       n, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean_out, rstd_out);
+    return ossid_launch_status();
+}
+
+int ossid_dense_fwd1_stats(const float* x, int channel_stride, int c, const float* pre_scale, const float* pre_shift,
+                           const float* wpk_x6, long long n_rows, float* y1, float* partials, float* counts, void* stream) {
+    if (!OSSID_CONV_SB) return OSSID_EINVAL;
+    if (!x || !pre_scale || !pre_shift || !wpk_x6 || !y1 || !partials || !counts || n_rows <= 0 || c < 32 || (c % 32) || channel_stride < c ||
+        (channel_stride % 4) || ((uintptr_t)x & 15) || ((uintptr_t)wpk_x6 & 15) || ((uintptr_t)pre_scale & 15) || ((uintptr_t)pre_shift & 15))
+        return OSSID_EINVAL;
+    DenseFwdArgs a;
+    a.x = x, a.wpk = (const float4*)wpk_x6, a.ps = pre_scale, a.pt = pre_shift, a.y1 = y1, a.partials = partials, a.counts = counts;
+    a.N = n_rows, a.c = c, a.cs = channel_stride;
+    const int pxs = df_pxs(n_rows);
+    const long long stages = (n_rows + pxs - 1) / pxs;
+    if (stages > 0x7fffffff) return OSSID_EINVAL;
+    a.nstages = (int)stages;
+    const unsigned grid = (unsigned)ossid_dense_fwd1_stats_partials(n_rows);
+    if (pxs == 64) hipLaunchKernelGGL(dense_fwd1_stats_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(dense_fwd1_stats_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     return ossid_launch_status();
 }
 

@@ -799,6 +799,37 @@ def _run_seq(seq, dev):
         seq.run((main,))
 
 
+# The dense layers' 1x1 forward with norm2's batch statistics in its epilogue (csrc/dense_bwd.hip) instead of the convolution +
+# a pass that reads its output again for two sums.
+DENSE_FWD_FUSED = os.environ.get("OSSID_DENSE_FWD_FUSED", "1") != "0"
+
+
+def dense_fwd1_stats(buf, wpk_x6, y1, N, c, Ct, ps, pt):
+    """y1 = conv1x1(relu(ps * buf[:, :c] + pt)); returns (rows [P][3][128], counts [P], P) for bn_fold_fwd_rows -- valid until
+    the next call on this stream."""
+    dev = buf.device
+    P = _lib.fn("ossid_dense_fwd1_stats_partials")(int(N))
+    part = _scratch("fwd1_stats", (P * 3 * 128 + P + 64) * 4, dev)
+    counts = part[P * 3 * 128 * 4:]
+    with _lib.on_device(dev):
+        _lib.check(_lib.fn("ossid_dense_fwd1_stats")(buf.data_ptr(), int(Ct), int(c), ps.data_ptr(), pt.data_ptr(), wpk_x6.data_ptr(),
+                                                     int(N), y1.data_ptr(), part.data_ptr(), counts.data_ptr(), _lib.stream()),
+                   "ossid_dense_fwd1_stats")
+    return part, counts, P
+
+
+def bn_fold_fwd_rows(rows, C, n, gamma, beta, eps, momentum, running_mean, running_var):
+    """bn_fold_fwd for partial rows that carry their own pivots (dense_fwd1_stats). Returns [4, C] = scale, shift, mean, rstd."""
+    part, counts, P = rows
+    out = new_buf((4, C), part.device)
+    with _lib.on_device(part.device):
+        rc = _lib.fn("ossid_bn_fold_fwd_rows")(part.data_ptr(), counts.data_ptr(), int(P), C, float(n), _p(gamma), _p(beta), float(eps),
+                                               float(momentum), _p(running_mean), _p(running_var), out[0].data_ptr(),
+                                               out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _lib.stream())
+    _lib.check(rc, "ossid_bn_fold_fwd_rows")
+    return out
+
+
 def _dense_forward(buf, table, block, params, C0):
     """The forward launches of a dense block whose input already sits in buf[:, :C0] (raw ops only: recordable).
     Returns the per-layer (f1, y1, f2) the backward pass needs."""
@@ -807,6 +838,8 @@ def _dense_forward(buf, table, block, params, C0):
     N = B * H * W
     growth = block.growth
     batch_stats(flat(buf), N, C0, cs=Ct, sums=table, sums_row_stride=Ct)
+    fused_fwd = (DENSE_FWD_FUSED and FWD_DECIDING == "fwd_x6" and growth == 32 and bool(_lib.fn("ossid_conv_split_bf16")()) and
+                 all(int(params[6 * li + 2].shape[0]) == 128 for li in range(len(block))))
     saved = []
     c = C0
     for li, layer in enumerate(block.values()):
@@ -815,10 +848,15 @@ def _dense_forward(buf, table, block, params, C0):
                          layer.norm1.running_var, sums_row_stride=Ct, pivot=table[2])
         mid = int(w1.shape[0])
         y1 = new_buf((B, mid, H, W), dev, channels_last=True)
-        conv_raw(buf, _pack(w1, FWD_DECIDING), B, H, W, c, mid, 1, y1, pre=(f1[0], f1[1]), pre_relu=True, in_cs=Ct)
-        s2 = batch_stats(flat(y1), N, mid, defer=True)
-        f2 = bn_fold_fwd(s2, mid, N, g2, b2, layer.norm2.eps, _mom(layer.norm2), layer.norm2.running_mean,
-                         layer.norm2.running_var)
+        if fused_fwd:
+            rows = dense_fwd1_stats(buf, _pack(w1, "fwd_x6"), y1, N, c, Ct, f1[0], f1[1])
+            f2 = bn_fold_fwd_rows(rows, mid, N, g2, b2, layer.norm2.eps, _mom(layer.norm2), layer.norm2.running_mean,
+                                  layer.norm2.running_var)
+        else:
+            conv_raw(buf, _pack(w1, FWD_DECIDING), B, H, W, c, mid, 1, y1, pre=(f1[0], f1[1]), pre_relu=True, in_cs=Ct)
+            s2 = batch_stats(flat(y1), N, mid, defer=True)
+            f2 = bn_fold_fwd(s2, mid, N, g2, b2, layer.norm2.eps, _mom(layer.norm2), layer.norm2.running_mean,
+                             layer.norm2.running_var)
         conv_raw(y1, _pack(w2, FWD_DECIDING), B, H, W, mid, growth, 9, buf, pre=(f2[0], f2[1]), pre_relu=True, out_cs=Ct, out_coff=c)
         batch_stats(flat(buf, c), N, growth, cs=Ct, sums=table.view(-1)[c:], sums_row_stride=Ct)
         saved.append((f1, y1, f2))
