@@ -1183,6 +1183,35 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float4* __res
     const int xx = (int)(p % W), yy = (int)((p / W) % H);
     const size_t b = p / ((size_t)W * H);
     float acc = bias ? bias[0] : 0.0f;
+    if (C4 == 4) {
+        // the decoder's 16 -> 1 layer: all 36 loads of the pixel issued before the first use, from clamped addresses (a load
+        // under a condition is a wait in front of the next one: the branchy form below ran at 0.75 TB/s of its 157 MB input);
+        // a tap outside the image counts with factor 0, in the same tap order
+        float4 v[9][4];
+        float f[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int y = yy + ky - 1, xc = xx + kx - 1;
+                f[ky * 3 + kx] = (y >= 0 && y < H && xc >= 0 && xc < W) ? 1.0f : 0.0f;
+                const float4* px = x + ((b * H + min(max(y, 0), H - 1)) * W + min(max(xc, 0), W - 1)) * 4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[ky * 3 + kx][c] = px[c];
+            }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (f[t] == 0.0f) continue;
+            const float4* wt = (const float4*)(wl + t * C);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 q = wt[c];
+                acc += v[t][c].x * q.x + v[t][c].y * q.y + v[t][c].z * q.z + v[t][c].w * q.w;
+            }
+        }
+        out[p] = acc;
+        return;
+    }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int y = yy + ky - 1;
@@ -1249,6 +1278,30 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float4* __r
         gs += gp;
         const int xx = (int)(p % W), yy = (int)((p / W) % H);
         const size_t b = p / ((size_t)W * H);
+        if (nc4 == 4) {
+            // (all 36 loads of the pixel before the first use, clamped addresses, a tap outside the image with gradient 0: the
+            // accumulators take the same terms in the same order as the branchy form below, plus exact zeros)
+            float4 v[9][4];
+            float gt[9];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int y = yy + ky - 1, xc = xx + kx - 1;
+                    gt[ky * 3 + kx] = (y >= 0 && y < H && xc >= 0 && xc < W) ? gp : 0.0f;
+                    const float4* px = x + ((b * H + min(max(y, 0), H - 1)) * W + min(max(xc, 0), W - 1)) * C4 + c4_0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[ky * 3 + kx][c] = px[c];
+                }
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[t][4 * c + 0] += gt[t] * v[t][c].x, acc[t][4 * c + 1] += gt[t] * v[t][c].y;
+                    acc[t][4 * c + 2] += gt[t] * v[t][c].z, acc[t][4 * c + 3] += gt[t] * v[t][c].w;
+                }
+            continue;
+        }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int y = yy + ky - 1;
