@@ -44,11 +44,17 @@ __global__ __launch_bounds__(256) void chan_op_kernel(const ChanOpArgs A) {
     const int q = blockIdx.x * QX + tx;
     const bool valid = q * 4 < A.C;
     const int c0 = q * 4;
-    auto ld4 = [&](const float* p, float dflt) {
-        return (p && valid) ? *(const float4*)(p + c0) : make_float4(dflt, dflt, dflt, dflt);
-    };
-    const float4 al = ld4(A.alpha, 1.f), be = ld4(A.beta, 0.f), ka = ld4(A.kappa, 0.f), ms = ld4(A.ms, 1.f),
-                 mt = ld4(A.mt, 0.f), pv4 = ld4(A.pivot, 0.f);
+    // The six per-channel vectors with UNCONDITIONAL loads (an absent one reads g's first row -- any valid address -- and is
+    // replaced by its default afterwards): a load under a condition is followed by a wait for it before the next one is issued,
+    // and this launch -- ~390 of them on the step's chains -- began with six memory round trips in a row.
+    const int c0s = valid ? c0 : 0;
+    const float* cp[6] = {A.alpha, A.beta, A.kappa, A.ms, A.mt, A.pivot};
+    float4 cv[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cv[k] = *(const float4*)((cp[k] ? cp[k] : A.g) + c0s);
+    __builtin_amdgcn_sched_barrier(0);                      // (all six issued before the first select waits)
+    auto sel4 = [&](int k, float dflt) { return (cp[k] && valid) ? cv[k] : make_float4(dflt, dflt, dflt, dflt); };
+    const float4 al = sel4(0, 1.f), be = sel4(1, 0.f), ka = sel4(2, 0.f), ms = sel4(3, 1.f), mt = sel4(4, 0.f), pv4 = sel4(5, 0.f);
     const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const long long r0 = (long long)blockIdx.y * A.rows_per_block;
@@ -60,15 +66,24 @@ __global__ __launch_bounds__(256) void chan_op_kernel(const ChanOpArgs A) {
         // few MB (a dense layer at 30 x 40: 9 600 rows), i.e. a handful of rows per thread -- their time is the number of
         // DEPENDENT memory round trips, not bandwidth
         constexpr int U = 4;
+        // (the rows' loads likewise: rows past the block's last re-read it, an absent x / accumulator reads g instead; what is
+        // not there is zeroed by a select behind the load, and rows past the end are neither summed nor stored)
+        const bool has_x = A.x != nullptr, has_o = A.out && A.accumulate;
+        const float* xp = has_x ? A.x : A.g;
+        const int xcs = has_x ? A.x_cs : A.g_cs;
+        const float* op = has_o ? A.out : A.g;
+        const int ocs = has_o ? A.out_cs : A.g_cs;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         for (long long rb = r0 + ty; rb < r1; rb += (long long)RY * U) {
             float4 gv[U], xv[U], ov[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const long long r = rb + (long long)u * RY;
-                const bool live = r < r1;
-                gv[u] = live ? *(const float4*)(A.g + r * A.g_cs + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                xv[u] = (live && A.x) ? *(const float4*)(A.x + r * A.x_cs + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                ov[u] = (live && A.out && A.accumulate) ? *(const float4*)(A.out + r * A.out_cs + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const long long rc = r < r1 ? r : r1 - 1;
+                gv[u] = *(const float4*)(A.g + rc * A.g_cs + c0);
+                const float4 xl = *(const float4*)(xp + rc * xcs + c0), ol = *(const float4*)(op + rc * ocs + c0);
+                xv[u] = has_x ? xl : z4;
+                ov[u] = has_o ? ol : z4;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
