@@ -384,6 +384,15 @@ int ossid_stem_weight_relayout(const float* src, float* dst, int cout, int cin, 
 int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, const float* partials, int n_partials, const float* pivot, int C,
                       double n, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                       float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, void* stream);
+/* ossid_bn_fold_fwd for a dense block's norm1: `table` [3][row_stride] (sums, sums of squares, pivots: what ossid_chan_op sum_mode 3
+ * finalizes) is complete for the first tail_c0 channels; the last C - tail_c0 channels still are the partial rows of a DEFERRED
+ * ossid_chan_op over the slab the previous layer appended (tail_partials [n_partials][2][C - tail_c0], tail_pivot = that launch's
+ * pivot row): they are finalized into the table here and all C channels folded -- one launch instead of finalize + fold.
+ * tail_c0 % 32 == 0. */
+int ossid_bn_fold_fwd_tail(float* table, int row_stride, int tail_c0, const float* tail_partials, int n_partials,
+                           const float* tail_pivot, int C, double n, const float* gamma, const float* beta, float eps, float momentum,
+                           float* running_mean, float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out,
+                           void* stream);
 int ossid_bn_fold_bwd(const float* dscale, const float* dshift, const float* partials, int n_partials, const float* gamma,
                       const float* mean, const float* rstd, int C, double n, float* dgamma, float* dbeta, float* coef_x,
                       float* coef_1, int accumulate, void* stream);

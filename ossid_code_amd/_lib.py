@@ -133,6 +133,7 @@ _PROTOS = {
     "ossid_detect_emit": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, C.c_longlong, _vp, C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_dense_fwd1_stats_partials": (_i, [C.c_longlong]),
     "ossid_dense_fwd1_stats": (_i, [_vp, _i, _i, _vp, _vp, _vp, C.c_longlong, _vp, _vp, _vp, _vp]),
+    "ossid_bn_fold_fwd_tail": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_bn_fold_fwd_rows": (_i, [_vp, _vp, _i, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_dense_dgrad1_acc_partials": (_i, [C.c_longlong]),
     "ossid_dense_dgrad1_acc": (_i, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -230,7 +231,7 @@ RECORDABLE = frozenset((
     "ossid_dw_bwd_k_nhwc", "ossid_im2col_stem", "ossid_conv_pack_weights", "ossid_conv_pack_weights_dgrad", "ossid_conv_pack_weights_form",
     "ossid_conv_pack_weights_wino", "ossid_fill_zero", "ossid_resample_taps_nhwc",
     "ossid_stem_weight_relayout", "ossid_stem_conv_fwd", "ossid_stem_conv_wgrad",
-    "ossid_dw_add_stats_nhwc", "ossid_stem_pool_fwd", "ossid_stem_pool_bwd", "ossid_dense_dgrad1_acc", "ossid_dense_fwd1_stats", "ossid_bn_fold_fwd_rows"))
+    "ossid_dw_add_stats_nhwc", "ossid_stem_pool_fwd", "ossid_stem_pool_bwd", "ossid_dense_dgrad1_acc", "ossid_dense_fwd1_stats", "ossid_bn_fold_fwd_rows", "ossid_bn_fold_fwd_tail"))
 # entry points that only compute sizes / return static data: called through, never stored
 _QUERIES = frozenset((
     "ossid_conv_packed_floats", "ossid_conv_packed_floats_form", "ossid_conv_wino_packed_floats", "ossid_chan_op_partials", "ossid_conv_wgrad_workspace_bytes",

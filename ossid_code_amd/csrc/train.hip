@@ -201,6 +201,53 @@ __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restric
     }
 }
 
+// The same fold for a dense block's norm1, whose statistics table is finished for the first tail_c0 channels while the LAST
+// tail_c channels -- the slab the previous layer just appended -- still are partial rows [P][2][tail_c] of a deferred
+// ossid_chan_op (sum_mode 3, pivot = the slab's first row): this launch finalizes them INTO the table (what
+// colsum_finalize_p_kernel did as a launch of its own, 58 times per step on the critical chain) and folds all channels.
+template <int PARTS>
+__global__ __launch_bounds__(256) void bn_fold_fwd_tail_kernel(float* __restrict__ table, int row_stride, int tail_c0,
+                                                               const float* __restrict__ partials, int P,
+                                                               const float* __restrict__ tail_pivot, int C, double n,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float eps, float momentum, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, float* __restrict__ scale,
+                                                               float* __restrict__ shift, float* __restrict__ mean_out,
+                                                               float* __restrict__ rstd_out) {
+    constexpr int CPB = 256 / PARTS;
+    __shared__ double red[PARTS][CPB][2];
+    const int c = blockIdx.x * CPB + (threadIdx.x % CPB), part = threadIdx.x / CPB;
+    const int first = blockIdx.x * CPB;
+    double s0, s1;
+    if (first + CPB <= tail_c0) {                             // (uniform per block) finished channels: the table as it stands
+        if (part != 0 || c >= C) return;
+        s0 = (double)table[c], s1 = (double)table[row_stride + c];
+    } else {
+        // a block never straddles the boundary: tail_c0 is a multiple of 32 >= CPB (host-checked)
+        column_sums<PARTS>(nullptr, 0, partials, P, C - tail_c0, c - tail_c0, part, red, s0, s1);
+        if (part != 0 || c >= C) return;
+        const float f0 = (float)s0, f1 = (float)s1;
+        table[c] = f0, table[row_stride + c] = f1, table[2 * row_stride + c] = tail_pivot[c - tail_c0];
+        s0 = (double)f0, s1 = (double)f1;                     // (the values every later reader of the table sees)
+    }
+    const double dm = s0 / n;
+    const double mean = (double)table[2 * row_stride + c] + dm;
+    double var = s1 / n - dm * dm;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+    const float s = (float)((double)g * rstd);
+    scale[c] = s;
+    shift[c] = (float)((double)b - mean * (double)s);
+    mean_out[c] = (float)mean;
+    rstd_out[c] = (float)rstd;
+    if (running_mean) {
+        const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+    }
+}
+
 // (d scale, d shift) -> d gamma, d beta and the two per-channel coefficients of the statistics' own gradient:
 //   dx += cb[c] * x + ck[c]     (= d mean / n + 2 (x - mean) d var / n)
 // With P > 0 the pair comes as partial rows: row 0 = d shift (sum of g*m), row 1 = d scale (sum of g*m*x).
@@ -1529,6 +1576,25 @@ int ossid_bn_fold_fwd(const float* sums, int sums_row_stride, const float* parti
         hipLaunchKernelGGL(bn_fold_fwd_kernel<4>, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, sums,
                            sums_row_stride > 0 ? sums_row_stride : C, partials, n_partials, pivot, C, n, gamma, beta, eps,
                            momentum, running_mean, running_var, scale, shift, mean_out, rstd_out);
+    return ossid_launch_status();
+}
+
+int ossid_bn_fold_fwd_tail(float* table, int row_stride, int tail_c0, const float* tail_partials, int n_partials,
+                           const float* tail_pivot, int C, double n, const float* gamma, const float* beta, float eps, float momentum,
+                           float* running_mean, float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out,
+                           void* stream) {
+    if (!table || !tail_partials || !tail_pivot || n_partials <= 0 || C <= 0 || tail_c0 <= 0 || tail_c0 >= C || (tail_c0 % 64) % 32 ||
+        (tail_c0 % 32) || row_stride < C || n <= 0 || !scale || !shift || !mean_out || !rstd_out || (!running_mean != !running_var))
+        return OSSID_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_partials > 128)
+        hipLaunchKernelGGL(bn_fold_fwd_tail_kernel<64>, dim3((C + 3) / 4), dim3(256), 0, s, table, row_stride, tail_c0, tail_partials,
+                           n_partials, tail_pivot, C, n, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean_out,
+                           rstd_out);
+    else
+        hipLaunchKernelGGL(bn_fold_fwd_tail_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, s, table, row_stride, tail_c0, tail_partials,
+                           n_partials, tail_pivot, C, n, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean_out,
+                           rstd_out);
     return ossid_launch_status();
 }
 

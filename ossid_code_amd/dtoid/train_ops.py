@@ -802,6 +802,8 @@ def _run_seq(seq, dev):
 # The dense layers' 1x1 forward with norm2's batch statistics in its epilogue (csrc/dense_bwd.hip) instead of the convolution +
 # a pass that reads its output again for two sums.
 DENSE_FWD_FUSED = os.environ.get("OSSID_DENSE_FWD_FUSED", "1") != "0"
+# ... and the finalize of a layer's slab statistics inside the next layer's norm1 fold (one launch less per layer)
+DENSE_FOLD_TAIL = os.environ.get("OSSID_DENSE_FOLD_TAIL", "1") != "0"
 
 
 def dense_fwd1_stats(buf, wpk_x6, y1, N, c, Ct, ps, pt):
@@ -842,10 +844,24 @@ def _dense_forward(buf, table, block, params, C0):
                  all(int(params[6 * li + 2].shape[0]) == 128 for li in range(len(block))))
     saved = []
     c = C0
+    tail = None                     # the previous layer's slab statistics, still partial rows (finalized by this layer's fold)
+    fold_tail = DENSE_FOLD_TAIL and C0 % 32 == 0 and growth == 32
+    L = len(block)
     for li, layer in enumerate(block.values()):
         g1, b1, w1, g2, b2, w2 = params[6 * li:6 * li + 6]
-        f1 = bn_fold_fwd(table, c, N, g1, b1, layer.norm1.eps, _mom(layer.norm1), layer.norm1.running_mean,
-                         layer.norm1.running_var, sums_row_stride=Ct, pivot=table[2])
+        if tail is not None:
+            part, P, piv = tail
+            f1 = new_buf((4, c), dev)
+            with _lib.on_device(dev):
+                rc = _lib.fn("ossid_bn_fold_fwd_tail")(table.data_ptr(), Ct, c - growth, part.data_ptr(), int(P), piv.data_ptr(), c,
+                                                       float(N), g1.data_ptr(), b1.data_ptr(), float(layer.norm1.eps),
+                                                       float(_mom(layer.norm1)), layer.norm1.running_mean.data_ptr(),
+                                                       layer.norm1.running_var.data_ptr(), f1[0].data_ptr(), f1[1].data_ptr(),
+                                                       f1[2].data_ptr(), f1[3].data_ptr(), _lib.stream())
+            _lib.check(rc, "ossid_bn_fold_fwd_tail")
+        else:
+            f1 = bn_fold_fwd(table, c, N, g1, b1, layer.norm1.eps, _mom(layer.norm1), layer.norm1.running_mean,
+                             layer.norm1.running_var, sums_row_stride=Ct, pivot=table[2])
         mid = int(w1.shape[0])
         y1 = new_buf((B, mid, H, W), dev, channels_last=True)
         if fused_fwd:
@@ -858,7 +874,10 @@ def _dense_forward(buf, table, block, params, C0):
             f2 = bn_fold_fwd(s2, mid, N, g2, b2, layer.norm2.eps, _mom(layer.norm2), layer.norm2.running_mean,
                              layer.norm2.running_var)
         conv_raw(y1, _pack(w2, FWD_DECIDING), B, H, W, mid, growth, 9, buf, pre=(f2[0], f2[1]), pre_relu=True, out_cs=Ct, out_coff=c)
-        batch_stats(flat(buf, c), N, growth, cs=Ct, sums=table.view(-1)[c:], sums_row_stride=Ct)
+        if fold_tail and li + 1 < L:
+            tail = batch_stats(flat(buf, c), N, growth, cs=Ct, defer=True)       # finished by the next layer's fold
+        else:
+            batch_stats(flat(buf, c), N, growth, cs=Ct, sums=table.view(-1)[c:], sums_row_stride=Ct)
         saved.append((f1, y1, f2))
         c += growth
     return saved
