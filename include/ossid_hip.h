@@ -31,8 +31,8 @@ extern "C" {
 #define OSSID_ELAUNCH (-5)
 
 /* The version of the struct layouts and signatures below; bumped whenever one changes (3: ossid_conv_desc gained
- * scratch / scratch_bytes / exact). A binding compares it with ossid_abi_version() when it loads the library. */
-#define OSSID_ABI_VERSION 4
+ * scratch / scratch_bytes / exact; 5: ossid_wgrad_desc gained dy_add / dy_add_scale / dy_add_shift, ossid_dense_dgrad1_acc its dz_add arguments). A binding compares it with ossid_abi_version() when it loads the library. */
+#define OSSID_ABI_VERSION 5
 
 /* library / device probe: returns OSSID_ABI_VERSION of the build; arch_out_host (may be NULL, >=32 bytes)
  * receives the gcnArchName of the current device, e.g. "gfx950:sramecc+:xnack-". */
@@ -291,6 +291,13 @@ typedef struct ossid_wgrad_desc {
     int32_t in_channel_stride, dy_channel_stride;
     int32_t src_height, src_width;   /* > 0 (3x3 only): x is [B][src_h][src_w][..], nearest-neighbour up-sampled to
                                         [height][width] on the fly, as in the forward (ossid_conv_desc) */
+    /* ABI 5. Optional: the output gradient is dy + dy_add_scale[co] * dy_add + dy_add_shift[co], formed while dy is staged
+     * (dy_add [B][H][W][dy_channel_stride] like dy): the statistics term of a training BatchNorm's backward, dz = g + c_x y + c_1,
+     * without a pass that materialises dz. Only the 1x1 problems csrc/wgrad_t9.hip takes (a dense layer's c -> 128) support it;
+     * any other problem with dy_add != NULL is rejected. */
+    const float* dy_add;
+    const float* dy_add_scale;
+    const float* dy_add_shift;
 } ossid_wgrad_desc;
 int ossid_conv_wgrad_split_bf16(void);
 size_t ossid_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps);
@@ -421,7 +428,8 @@ int ossid_conv_pack_weights_table(const ossid_pack_row* rows_device, int n_rows,
  * (g = the raw data gradient), P = ossid_dense_dgrad1_acc_partials(n_rows). What ossid_conv_nhwc_fwd (data-gradient weights)
  * followed by ossid_chan_op (mask_mode 1, accumulate, sum_mode 1) computes, without the [n_rows][c] tensor in between; same
  * three-product bf16 arithmetic, f32 sums in another order. c % 32 == 0, c <= 1024, n_rows * channel_stride < 2^32; returns
- * OSSID_EINVAL in a -DOSSID_CONV_F32 build. */
+ * OSSID_EINVAL in a -DOSSID_CONV_F32 build. dz_add (NULL = none): dz is dz + dz_add_scale[k] * dz_add + dz_add_shift[k], formed
+ * while dz is staged (dz_add [n_rows][128]: see ossid_wgrad_desc.dy_add). */
 /* ... and its FORWARD with norm2's batch statistics in the epilogue: y1 [n_rows][128] = conv1(relu(pre_scale x + pre_shift)) on
  * the first c channels of x [n_rows][channel_stride], wpk_x6 = ossid_conv_pack_weights_form(w [128][c][1], exact = 2) (the
  * three-way split: f32-level accuracy), and P = ossid_dense_fwd1_stats_partials(n_rows) partial rows [P][3][128] = per-channel
@@ -437,7 +445,7 @@ int ossid_bn_fold_fwd_rows(const float* partials, const float* counts, int n_par
 int ossid_dense_dgrad1_acc_partials(long long n_rows);
 int ossid_dense_dgrad1_acc(const float* dz, const float* wpk_dgrad, const float* x, float* G, long long n_rows, int c,
                            int channel_stride, const float* alpha, const float* mask_scale, const float* mask_shift, float* partials,
-                           void* stream);
+                           const float* dz_add, const float* dz_add_scale, const float* dz_add_shift, void* stream);
 
 /* D4  nn.AvgPool2d(2, stride) of the DenseNet transitions (stride 2; the third one stride 1, network.py:165),
  * channels-last. backward != 0: x is d out [B][Ho][Wo][C] and out receives d in [B][H][W][C]. */

@@ -33,7 +33,8 @@ class WgradDesc(C.Structure):
     """struct ossid_wgrad_desc (include/ossid_hip.h)."""
     _fields_ = [(n, _vp) for n in ("x", "dy", "pre_scale", "pre_shift", "dw", "workspace")] + [("workspace_bytes", _sz)] + \
                [(n, C.c_int32) for n in ("batch", "height", "width", "cin", "cout", "taps", "pre_relu", "accumulate",
-                                         "in_channel_stride", "dy_channel_stride", "src_height", "src_width")]
+                                         "in_channel_stride", "dy_channel_stride", "src_height", "src_width")] + \
+               [(n, _vp) for n in ("dy_add", "dy_add_scale", "dy_add_shift")]
 
 
 class ChanOpDesc(C.Structure):
@@ -136,7 +137,7 @@ _PROTOS = {
     "ossid_bn_fold_fwd_tail": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_bn_fold_fwd_rows": (_i, [_vp, _vp, _i, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_dense_dgrad1_acc_partials": (_i, [C.c_longlong]),
-    "ossid_dense_dgrad1_acc": (_i, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ossid_dense_dgrad1_acc": (_i, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_dense_fused_available": (_i, []),
     "ossid_dense_table_bytes": (_sz, [_i]),
     "ossid_dense_entry": (_i, [_vp, _i, _i, C.c_longlong, _i, _vp, _vp, _vp]),
@@ -172,7 +173,7 @@ _PROTOS = {
 }
 
 
-ABI_VERSION = 4      # OSSID_ABI_VERSION of include/ossid_hip.h: the struct layouts below (tests/test_abi.py compares the two)
+ABI_VERSION = 5      # OSSID_ABI_VERSION of include/ossid_hip.h: the struct layouts below (tests/test_abi.py compares the two)
 
 
 def exported_symbols():

@@ -36,6 +36,7 @@ struct DenseBwdArgs {
     float* G;                 // gradient buffer [N][cs]: first c channels accumulated into
     const float *alpha, *ms, *mt;      // [c]
     float* partials;          // [gridDim.x][2][c]
+    const float *za, *zb, *zk;         // optional: dz = dz + zb[k] * za + zk[k] while staging (za [N][128])
     long long N;
     int c, cs, nstages;
 };
@@ -53,13 +54,17 @@ __global__ __launch_bounds__(256, 2) void dense_dgrad1_acc_kernel(const DenseBwd
     for (int k = 0; k < DB_MAXT; ++k) sums[0][(wave * DB_MAXT + k) * 64 + lane] = sums[1][(wave * DB_MAXT + k) * 64 + lane] = 0.0f;
     // staging map: 64 pixels x 32 float4 of dz, 8 per thread; channel quad j of a pixel -> unit j / 4, half-quad in the unit
     const int j = tid & 31;
-    float4 st[8];
+    float4 st[8], sa[8];
+    const bool has_add = A.za != nullptr;                                        // (uniform)
+    float4 zb = make_float4(0.f, 0.f, 0.f, 0.f), zk = zb;
+    if (has_add) zb = *(const float4*)(A.zb + 4 * j), zk = *(const float4*)(A.zk + 4 * j);
     auto fetch = [&](int stage) {
         const long long p0 = (long long)stage * DB_PXS;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const long long p = min(p0 + (tid >> 5) + 8 * e, A.N - 1);           // (clamped: rows past the end are never stored)
             st[e] = *(const float4*)(A.dz + (size_t)p * DB_MID + 4 * j);
+            if (has_add) sa[e] = *(const float4*)(A.za + (size_t)p * DB_MID + 4 * j);
         }
     };
     auto commit = [&]() {
@@ -68,7 +73,11 @@ __global__ __launch_bounds__(256, 2) void dense_dgrad1_acc_kernel(const DenseBwd
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int px = (tid >> 5) + 8 * e;
-            const float v[4] = {st[e].x, st[e].y, st[e].z, st[e].w};
+            float v[4] = {st[e].x, st[e].y, st[e].z, st[e].w};
+            if (has_add) {                                   // (g + c_x y) + c_1: the order of the generic pass this replaces
+                v[0] = (v[0] + zb.x * sa[e].x) + zk.x, v[1] = (v[1] + zb.y * sa[e].y) + zk.y;
+                v[2] = (v[2] + zb.z * sa[e].z) + zk.z, v[3] = (v[3] + zb.w * sa[e].w) + zk.w;
+            }
             union {
                 __bf16 b4[4];
                 uint2 u2;
@@ -413,13 +422,17 @@ int ossid_dense_dgrad1_acc_partials(long long n_rows) {
 
 int ossid_dense_dgrad1_acc(const float* dz, const float* wpk_dgrad, const float* x, float* G, long long n_rows, int c,
                            int channel_stride, const float* alpha, const float* mask_scale, const float* mask_shift, float* partials,
-                           void* stream) {
+                           const float* dz_add, const float* dz_add_scale, const float* dz_add_shift, void* stream) {
     if (!OSSID_CONV_SB) return OSSID_EINVAL;
     if (!dz || !wpk_dgrad || !x || !G || !alpha || !mask_scale || !mask_shift || !partials || n_rows <= 0 || c < 32 || (c % 32) ||
         c > 32 * 4 * DB_MAXT || channel_stride < c || (unsigned long long)n_rows * (unsigned long long)channel_stride >= (1ull << 32) || ((uintptr_t)dz & 15) || ((uintptr_t)wpk_dgrad & 15))
         return OSSID_EINVAL;
     DenseBwdArgs a;
     a.dz = dz, a.wpk = (const float4*)wpk_dgrad, a.x = x, a.G = G, a.alpha = alpha, a.ms = mask_scale, a.mt = mask_shift;
+    if (dz_add && (!dz_add_scale || !dz_add_shift || ((uintptr_t)dz_add & 15) || ((uintptr_t)dz_add_scale & 15) ||
+                   ((uintptr_t)dz_add_shift & 15)))
+        return OSSID_EINVAL;
+    a.za = dz_add, a.zb = dz_add_scale, a.zk = dz_add_shift;
     a.partials = partials, a.N = n_rows, a.c = c, a.cs = channel_stride;
     const long long stages = (n_rows + DB_PXS - 1) / DB_PXS;
     if (stages > 0x7fffffff) return OSSID_EINVAL;

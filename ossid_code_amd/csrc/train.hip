@@ -1698,6 +1698,7 @@ int ossid_conv_wgrad(const ossid_wgrad_desc* d, void* stream) {
     const int B = d->batch, H = d->height, W = d->width, Cin = d->cin, Cout = d->cout, taps = d->taps;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 4) || (Cout % 4)) return OSSID_EINVAL;
     if (!d->x || !d->dy || !d->dw || !d->workspace || (d->pre_scale && !d->pre_shift)) return OSSID_EINVAL;
+    if (d->dy_add) return OSSID_EINVAL;                        // (only csrc/wgrad_t9.hip's 1x1 jobs, reached through the group entry)
     if (OSSID_WGRAD_FEWCH && ossid_wgrad_fewch_takes(Cin, Cout, taps, d->in_channel_stride > 0 ? d->in_channel_stride : Cin,
                                                      d->dy_channel_stride > 0 ? d->dy_channel_stride : Cout) &&
         d->workspace_bytes >= ossid_wgrad_fewch_workspace_bytes(B, H, W, Cin, Cout) && !((uintptr_t)d->x & 15) &&
@@ -1877,7 +1878,7 @@ int ossid_conv_wgrad_group(const ossid_wgrad_desc* descs, int n, void* workspace
     for (int i = 0; i < n; ++i) {
         const ossid_wgrad_desc& d = descs[i];
         if (d.batch <= 0 || d.height <= 0 || d.width <= 0 || d.cin <= 0 || d.cout <= 0 || (d.cin % 4) || (d.cout % 4) || !d.x ||
-            !d.dy || !d.dw || (d.pre_scale && !d.pre_shift))
+            !d.dy || !d.dw || (d.pre_scale && !d.pre_shift) || d.dy_add)
             return OSSID_EINVAL;
         if (!wgrad_plan(d.batch, d.height, d.width, d.cin, d.cout, d.taps, plans[i])) return OSSID_EINVAL;
     }

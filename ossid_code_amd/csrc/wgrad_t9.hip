@@ -249,6 +249,7 @@ constexpr int T1_SLAB = T1_COUT * T1_CIB;
 
 struct T1Job {
     const float *x, *dy, *pre_scale, *pre_shift;       // x / pre_* already offset to the job's first input channel
+    const float *dy_add, *dy_b, *dy_k;                 // optional: dy = dy + dy_b[co] * dy_add + dy_k[co] while staging
     float* dw;                                         // dw + first input channel; rows of cin_total floats
     int cw, cin_total, in_cs, dy_cs, pre_relu, accumulate;    // cw = input channels of this block (<= 256, a multiple of 32)
 };
@@ -284,7 +285,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_t1_kernel(const T1Args A) {
         pt = *(const float4*)(J.pre_shift + 4 * xq);
     }
     const bool has_pre = J.pre_scale != nullptr, relu = J.pre_relu != 0;
-    float4 sx[16], sd[8];
+    float4 sx[16], sd[8], sa[8];
+    const bool has_add = J.dy_add != nullptr;           // (uniform)
+    float4 db4 = make_float4(0.f, 0.f, 0.f, 0.f), dk4 = db4;
+    if (has_add) db4 = *(const float4*)(J.dy_b + 4 * dq), dk4 = *(const float4*)(J.dy_k + 4 * dq);
     auto fetch = [&](int stage) {                       // loads only (see wgrad_t9_kernel)
         const long long p0 = (long long)stage * T1_PXS;
         if (xq_ok) {
@@ -298,6 +302,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_t1_kernel(const T1Args A) {
         for (int e = 0; e < 8; ++e) {
             const long long p = min(p0 + (tid >> 5) + 8 * e, A.npx - 1);
             sd[e] = *(const float4*)(J.dy + (size_t)p * J.dy_cs + 4 * dq);
+            if (has_add) sa[e] = *(const float4*)(J.dy_add + (size_t)p * J.dy_cs + 4 * dq);
         }
     };
     auto split_store = [&](const float4& fv, char* hi_at, int part_stride) {
@@ -332,7 +337,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_t1_kernel(const T1Args A) {
         for (int e = 0; e < 8; ++e) {
             const int px = (tid >> 5) + 8 * e;
             const float f = (p0 + px < A.npx) ? 1.0f : 0.0f;
-            const float4 v = sd[e];
+            float4 v = sd[e];
+            if (has_add)                                 // (g + c_x y) + c_1: the order of the generic pass this replaces
+                v = make_float4((v.x + db4.x * sa[e].x) + dk4.x, (v.y + db4.y * sa[e].y) + dk4.y, (v.z + db4.z * sa[e].z) + dk4.z,
+                                (v.w + db4.w * sa[e].w) + dk4.w);
             split_store(make_float4(f * v.x, f * v.y, f * v.z, f * v.w), dyl + (size_t)px * T1_PD + 8 * dq, T1_DIMG);
         }
     };
@@ -454,7 +462,7 @@ bool ossid_wgrad_t9_takes(const ossid_wgrad_desc* d) {
 #else
     const int in_cs = d->in_channel_stride > 0 ? d->in_channel_stride : d->cin;
     const int dy_cs = d->dy_channel_stride > 0 ? d->dy_channel_stride : d->cout;
-    return d->taps == 9 && d->cin >= T9_CIN && d->cin % T9_CIN == 0 && d->cout >= 32 && d->cout % 4 == 0 &&
+    return !d->dy_add && d->taps == 9 && d->cin >= T9_CIN && d->cin % T9_CIN == 0 && d->cout >= 32 && d->cout % 4 == 0 &&
            (d->src_height <= 0 || d->src_height == d->height) && (d->src_width <= 0 || d->src_width == d->width) &&
            in_cs % 4 == 0 && dy_cs % 4 == 0 && !((uintptr_t)d->x & 15) && !((uintptr_t)d->dy & 15) &&
            (!d->pre_scale || !((uintptr_t)d->pre_scale & 15)) && (!d->pre_shift || !((uintptr_t)d->pre_shift & 15)) &&
@@ -551,6 +559,9 @@ bool ossid_wgrad_t1_takes(const ossid_wgrad_desc* d) {
 #else
     const int in_cs = d->in_channel_stride > 0 ? d->in_channel_stride : d->cin;
     const int dy_cs = d->dy_channel_stride > 0 ? d->dy_channel_stride : d->cout;
+    if (d->dy_add && (!d->dy_add_scale || !d->dy_add_shift || ((uintptr_t)d->dy_add & 15) || ((uintptr_t)d->dy_add_scale & 15) ||
+                      ((uintptr_t)d->dy_add_shift & 15)))
+        return false;
     return d->taps == 1 && d->cout == T1_COUT && d->cin >= 32 && d->cin % 32 == 0 && in_cs % 4 == 0 && dy_cs % 4 == 0 &&
            !((uintptr_t)d->x & 15) && !((uintptr_t)d->dy & 15) && (!d->pre_scale || !((uintptr_t)d->pre_scale & 15)) &&
            (!d->pre_shift || !((uintptr_t)d->pre_shift & 15)) && d->batch > 0 && d->height > 0 && d->width > 0;
@@ -597,6 +608,7 @@ int ossid_wgrad_t1_group(const ossid_wgrad_desc* descs, int n, void* workspace, 
         for (int c0 = 0; c0 < d.cin; c0 += T1_CIB) {
             T1Job& j = a.j[ji++];
             j.x = d.x + c0, j.dy = d.dy, j.dw = d.dw + c0;
+            j.dy_add = d.dy_add, j.dy_b = d.dy_add_scale, j.dy_k = d.dy_add_shift;
             j.pre_scale = d.pre_scale ? d.pre_scale + c0 : nullptr, j.pre_shift = d.pre_shift ? d.pre_shift + c0 : nullptr;
             j.cw = d.cin - c0 < T1_CIB ? d.cin - c0 : T1_CIB, j.cin_total = d.cin;
             j.in_cs = d.in_channel_stride > 0 ? d.in_channel_stride : d.cin;

@@ -376,6 +376,9 @@ def wgrad_group(items):
         d.batch, d.height, d.width, d.cin, d.cout, d.taps = it["B"], it["H"], it["W"], it["cin"], it["cout"], it["taps"]
         d.pre_relu, d.accumulate = 1 if it.get("pre_relu") else 0, 0
         d.in_channel_stride, d.dy_channel_stride = int(it.get("in_cs", 0)), int(it.get("dy_cs", 0))
+        add = it.get("dy_add")
+        if add is not None:                      # dy = dy + scale * add + shift while it is staged (ossid_wgrad_desc.dy_add)
+            d.dy_add, d.dy_add_scale, d.dy_add_shift = add[0].data_ptr(), add[1].data_ptr(), add[2].data_ptr()
     dev = items[0]["dw"].device
     nbytes = _lib.fn("ossid_conv_wgrad_group_workspace_bytes")(arr, n)
     if nbytes == 0:
@@ -888,16 +891,19 @@ def _dense_forward(buf, table, block, params, C0):
 DENSE_BWD_FUSED = os.environ.get("OSSID_DENSE_BWD_FUSED", "1") != "0"
 
 
-def dense_dgrad1_acc(dz, wpk_dgrad, buf, G, N, c, Ct, alpha, ms, mt):
+def dense_dgrad1_acc(dz, wpk_dgrad, buf, G, N, c, Ct, alpha, ms, mt, add=None):
     """G[:, :c] += alpha * relu'(ms * buf + mt) * (dz @ W1); returns the (partials, P) pair of norm1's column sums for
-    bn_fold_bwd -- valid until the next call on this stream."""
+    bn_fold_bwd -- valid until the next call on this stream. add = (y, scale, shift): dz is dz + scale * y + shift."""
     dev = dz.device
     P = _lib.fn("ossid_dense_dgrad1_acc_partials")(int(N))
     part = _scratch("dgrad1_acc", P * 2 * c * 4, dev)
     with _lib.on_device(dev):
         _lib.check(_lib.fn("ossid_dense_dgrad1_acc")(dz.data_ptr(), wpk_dgrad.data_ptr(), buf.data_ptr(), G.data_ptr(), int(N), int(c),
                                                      int(Ct), alpha.data_ptr(), ms.data_ptr(), mt.data_ptr(), part.data_ptr(),
-                                                     _lib.stream()), "ossid_dense_dgrad1_acc")
+                                                     None if add is None else add[0].data_ptr(),
+                                                     None if add is None else add[1].data_ptr(),
+                                                     None if add is None else add[2].data_ptr(), _lib.stream()),
+                   "ossid_dense_dgrad1_acc")
     return part, P
 
 
@@ -939,15 +945,19 @@ def _dense_backward(G, buf, saved, block, params, C0, side, direct=False):
                     sum_mode=1, defer=True)
         r2 = new_buf((4, mid), dev)
         bn_fold_bwd(None, None, g2, f2[2], f2[3], mid, N, r2[0], r2[1], r2[2], r2[3], partials=s)
-        chan_op(db, N, mid, x=y1, out=db, beta=r2[2], kappa=r2[3])          # dz = scale*db*mask + coef_x*y1 + coef_1
+        # dz = scale*db*mask + coef_x*y1 + coef_1: a pass of its own, or -- with the fused 1x1 data gradient -- formed while dz is
+        # staged, there and in the (deferred) 1x1 weight gradient
+        add = (y1, r2[2], r2[3]) if fused_bwd else None
+        if add is None:
+            chan_op(db, N, mid, x=y1, out=db, beta=r2[2], kappa=r2[3])
         # 1x1: weight gradient on relu(bn1(buf[:, :c])) (deferred), data gradient to the c input channels
         dw1 = grad_home(w1, direct)
         deferred.append(dict(x=buf, dy=db, B=B, H=H, W=W, cin=c, cout=mid, taps=1, dw=dw1, pre=(f1[0], f1[1]),
-                             pre_relu=True, in_cs=Ct))
+                             pre_relu=True, in_cs=Ct, dy_add=add))
         # ... then one pass that masks with relu(bn1(buf)), scales, ACCUMULATES onto the gradient buffer's channel prefix
         # and sums (d shift, d scale)
         if fused_bwd:
-            s = dense_dgrad1_acc(db, _pack(w1, "dgrad"), buf, G, N, c, Ct, f1[0], f1[0], f1[1])
+            s = dense_dgrad1_acc(db, _pack(w1, "dgrad"), buf, G, N, c, Ct, f1[0], f1[0], f1[1], add=add)
         else:
             if da is None:
                 da = new_buf((B, Ct, H, W), dev, channels_last=True)
