@@ -442,6 +442,15 @@ int ossid_dense_fwd1_stats(const float* x, int channel_stride, int c, const floa
 int ossid_bn_fold_fwd_rows(const float* partials, const float* counts, int n_partials, int C, double n, const float* gamma,
                            const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
                            float* shift, float* mean_out, float* rstd_out, void* stream);
+/* ... and the layer's 3x3 data gradient (32 -> 128) with norm2 / ReLU's backward in its epilogue: db [B*H*W][128] = alpha m (g * W2'),
+ * m = (mask_scale y1 + mask_shift > 0), g = the gradient of the layer's 32 channels ([B][H][W][g_channel_stride]: a channel slice),
+ * wpk_dgrad = ossid_conv_pack_weights_dgrad(w2 [32][128][9]), and partial rows [P][2][128] (sum g' m, sum g' m y1, g' the raw data
+ * gradient) for ossid_bn_fold_bwd, P = ossid_dense_dgrad3_mask_partials(B, H, W): ossid_conv_nhwc_fwd / ossid_conv3x3_wino_fwd on
+ * the data-gradient weights followed by ossid_chan_op (mask_mode 1, sum_mode 1), without the second pass. */
+int ossid_dense_dgrad3_mask_partials(int B, int H, int W);
+int ossid_dense_dgrad3_mask(const float* g, int g_channel_stride, const float* wpk_dgrad, const float* y1, float* db, int B, int H,
+                            int W, const float* alpha, const float* mask_scale, const float* mask_shift, float* partials,
+                            void* stream);
 int ossid_dense_dgrad1_acc_partials(long long n_rows);
 int ossid_dense_dgrad1_acc(const float* dz, const float* wpk_dgrad, const float* x, float* G, long long n_rows, int c,
                            int channel_stride, const float* alpha, const float* mask_scale, const float* mask_shift, float* partials,

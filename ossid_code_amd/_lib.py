@@ -136,6 +136,8 @@ _PROTOS = {
     "ossid_dense_fwd1_stats": (_i, [_vp, _i, _i, _vp, _vp, _vp, C.c_longlong, _vp, _vp, _vp, _vp]),
     "ossid_bn_fold_fwd_tail": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_bn_fold_fwd_rows": (_i, [_vp, _vp, _i, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ossid_dense_dgrad3_mask_partials": (_i, [_i, _i, _i]),
+    "ossid_dense_dgrad3_mask": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ossid_dense_dgrad1_acc_partials": (_i, [C.c_longlong]),
     "ossid_dense_dgrad1_acc": (_i, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ossid_dense_fused_available": (_i, []),
@@ -232,14 +234,14 @@ RECORDABLE = frozenset((
     "ossid_dw_bwd_k_nhwc", "ossid_im2col_stem", "ossid_conv_pack_weights", "ossid_conv_pack_weights_dgrad", "ossid_conv_pack_weights_form",
     "ossid_conv_pack_weights_wino", "ossid_fill_zero", "ossid_resample_taps_nhwc",
     "ossid_stem_weight_relayout", "ossid_stem_conv_fwd", "ossid_stem_conv_wgrad",
-    "ossid_dw_add_stats_nhwc", "ossid_stem_pool_fwd", "ossid_stem_pool_bwd", "ossid_dense_dgrad1_acc", "ossid_dense_fwd1_stats", "ossid_bn_fold_fwd_rows", "ossid_bn_fold_fwd_tail"))
+    "ossid_dw_add_stats_nhwc", "ossid_stem_pool_fwd", "ossid_stem_pool_bwd", "ossid_dense_dgrad1_acc", "ossid_dense_fwd1_stats", "ossid_bn_fold_fwd_rows", "ossid_bn_fold_fwd_tail", "ossid_dense_dgrad3_mask"))
 # entry points that only compute sizes / return static data: called through, never stored
 _QUERIES = frozenset((
     "ossid_conv_packed_floats", "ossid_conv_packed_floats_form", "ossid_conv_wino_packed_floats", "ossid_chan_op_partials", "ossid_conv_wgrad_workspace_bytes",
     "ossid_conv_wgrad_group_workspace_bytes", "ossid_dw_bwd_k_workspace_floats",
     "ossid_conv3x3_wgrad_splits", "ossid_abi_version", "ossid_conv3x3_wino_workspace_bytes",
     "ossid_conv3x3_wino_pair_workspace_bytes", "ossid_stem_conv_wgrad_workspace_bytes",
-    "ossid_dw_add_stats_partials", "ossid_stem_pool_bwd_partials", "ossid_dense_dgrad1_acc_partials", "ossid_dense_fwd1_stats_partials", "ossid_conv_split_bf16"))
+    "ossid_dw_add_stats_partials", "ossid_stem_pool_bwd_partials", "ossid_dense_dgrad1_acc_partials", "ossid_dense_fwd1_stats_partials", "ossid_dense_dgrad3_mask_partials", "ossid_conv_split_bf16"))
 
 
 class Seq:

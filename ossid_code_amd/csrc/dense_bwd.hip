@@ -395,6 +395,153 @@ int df_grid() {
 // pixels per stage for n_rows: 64, or 32 where 64-pixel stages would leave the chip under ~1.5 workgroups per CU
 int df_pxs(long long n_rows) { return (n_rows + 63) / 64 >= 384 ? 64 : 32; }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The 3x3 data gradient of a dense layer (32 -> 128: the gradient of the layer's own 32 channels back to its bottleneck) with
+// norm2 / ReLU's backward in its epilogue: db[px][ch] = alpha[ch] m (g * W2')[px][ch], m = (ms[ch] y1[px][ch] + mt[ch] > 0), and
+// the column sums (sum g m, sum g m y1) as partial rows for ossid_bn_fold_bwd. Round 3: the convolution (Winograd or direct),
+// then a generic pass reading its output and y1 and writing it again. Transposed product once more: pixels on M (A = the staged
+// gradient patch of a 4 x 8 tile + halo, 32 channels = 2 units, every tap read from it), output channels on N (B = conv2's
+// data-gradient layout, ossid_conv_pack_weights_dgrad: 36 operand quads per wave, loaded ONCE and kept in registers by the
+// persistent workgroup); wave w owns output channels 32w .. 32w+31 of the tile.
+constexpr int D3_TR = 4, D3_TC = 8, D3_PR = D3_TR + 2, D3_PC = D3_TC + 2, D3_NPOS = D3_PR * D3_PC;
+constexpr int D3_PSTR = 2 * 4 + 1;                      // float4 per patch position: 2 units x (hi, lo) x 2 halves + 1
+
+struct DenseBwd3Args {
+    const float* g;           // gradient of the layer's 32 channels: [N][gcs] (a channel slice of the block's gradient buffer)
+    const float4* wpk;        // conv2, data-gradient layout: [4 tiles][2 units][9 taps][2 parts][64 lanes] x 16 B
+    const float* y1;          // [N][128] bottleneck pre-activations
+    float* db;                // [N][128] out
+    const float *alpha, *ms, *mt;      // [128]
+    float* partials;          // [gridDim.x][2][128]
+    int B, H, W, gcs, tiles_x, tiles_y, ntiles;
+};
+
+__global__ __launch_bounds__(256, 2) void dense_dgrad3_mask_kernel(const DenseBwd3Args A) {
+    __shared__ __attribute__((aligned(16))) float4 patch[64 * D3_PSTR];       // 60 positions (+ 4 spare rows for the staging map)
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, n = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = A.H, W = A.W;
+    const int ch = wave * 32 + n;
+    const float al = A.alpha[ch], ms = A.ms[ch], mt = A.mt[ch];
+    float s1 = 0.0f, s2 = 0.0f;
+    float4 w[2][9][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int part = 0; part < 2; ++part) w[u][tap][part] = A.wpk[((((size_t)wave * 2 + u) * 9 + tap) * 2 + part) * 64 + lane];
+    // staging map: 60 positions x 8 float4 = 480 quads, two per thread (the map's last 32 slots fall on the spare rows)
+    const int j = tid & 7;
+    float4 st[2];
+    auto geom = [&](int tile, int& b, int& y0, int& x0) {
+        const int per = A.tiles_x * A.tiles_y;
+        b = tile / per;
+        const int r = tile - b * per;
+        y0 = (r / A.tiles_x) * D3_TR, x0 = (r % A.tiles_x) * D3_TC;
+    };
+    auto fetch = [&](int tile) {
+        int b, y0, x0;
+        geom(tile, b, y0, x0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int pos = min((tid >> 3) + 32 * e, D3_NPOS - 1);
+            const int pr = pos / D3_PC, pc = pos - pr * D3_PC;
+            const int yc = min(max(y0 - 1 + pr, 0), H - 1), xc = min(max(x0 - 1 + pc, 0), W - 1);
+            st[e] = *(const float4*)(A.g + ((size_t)(b * H + yc) * W + xc) * A.gcs + 4 * j);
+        }
+    };
+    auto commit = [&](int tile) {
+        int b, y0, x0;
+        geom(tile, b, y0, x0);
+        uint2* p2 = (uint2*)patch;
+        const int u = j >> 2, jj = j & 3;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int pos = (tid >> 3) + 32 * e;
+            const int pr = pos / D3_PC, pc = pos - pr * D3_PC;
+            const int yy = y0 - 1 + pr, xx = x0 - 1 + pc;
+            const float f = (pos < D3_NPOS && yy >= 0 && yy < H && xx >= 0 && xx < W) ? 1.0f : 0.0f;      // zero padding
+            const float v[4] = {f * st[e].x, f * st[e].y, f * st[e].z, f * st[e].w};
+            union {
+                __bf16 b4[4];
+                uint2 u2;
+            } ph, pl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ph.b4[i] = (__bf16)v[i];
+                pl.b4[i] = (__bf16)(v[i] - (float)ph.b4[i]);
+            }
+            p2[(pos * D3_PSTR + u * 4) * 2 + jj] = ph.u2;
+            p2[(pos * D3_PSTR + u * 4) * 2 + 4 + jj] = pl.u2;
+        }
+    };
+    const int p0 = (n >> 3) * D3_PC + (n & 7);           // patch position of tap (0, 0) for this lane's pixel (as the A operand's row)
+    if ((int)blockIdx.x < A.ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+        __syncthreads();
+        commit(tile);
+        __syncthreads();
+        if (tile + (int)gridDim.x < A.ntiles) fetch(tile + gridDim.x);
+        int b, y0, x0;
+        geom(tile, b, y0, x0);
+        // this lane's channel of the tile's 16 pixel rows of its half: y1 requested before the product
+        float yv[16];
+        unsigned valid = 0;
+        int rowi[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 8 * (r >> 2) + 4 * h + (r & 3);                      // pixel of the tile: row m >> 3, column m & 7
+            const int yy = y0 + (m >> 3), xx = x0 + (m & 7);
+            valid |= (yy < H && xx < W) ? 1u << r : 0u;
+            rowi[r] = (b * H + min(yy, H - 1)) * W + min(xx, W - 1);
+            yv[r] = A.y1[(size_t)rowi[r] * DB_MID + ch];
+        }
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float4* pb = patch + (size_t)p0 * D3_PSTR + h;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float4* px4 = pb + ((tap / 3) * D3_PC + tap % 3) * D3_PSTR + u * 4;
+                const v8bf ah = __builtin_bit_cast(v8bf, px4[0]), alo = __builtin_bit_cast(v8bf, px4[2]);
+                const v8bf bh = __builtin_bit_cast(v8bf, w[u][tap][0]), bl = __builtin_bit_cast(v8bf, w[u][tap][1]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (!(valid >> r & 1)) continue;
+            const float m = (ms * yv[r] + mt > 0.0f) ? 1.0f : 0.0f;
+            const float gm = acc[r] * m;
+            s1 += gm, s2 += gm * yv[r];
+            A.db[(size_t)rowi[r] * DB_MID + ch] = al * acc[r] * m;
+        }
+    }
+    const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
+    if (h == 0) {
+        float* prow = A.partials + (size_t)blockIdx.x * 2 * DB_MID;
+        prow[ch] = t1, prow[DB_MID + ch] = t2;
+    }
+}
+
+int g_d3_grid = 0;
+int d3_grid() {
+    if (!g_d3_grid) {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dense_dgrad3_mask_kernel, 256, 0) != hipSuccess || per_cu <= 0)
+            return 512;
+        if (per_cu > 2) per_cu = 2;
+        g_d3_grid = per_cu * p.multiProcessorCount;
+    }
+    return g_d3_grid;
+}
+
 int g_db_grid = 0;
 int db_grid() {
     if (!g_db_grid) {
@@ -476,6 +623,32 @@ int ossid_dense_fwd1_stats(const float* x, int channel_stride, int c, const floa
     const unsigned grid = (unsigned)ossid_dense_fwd1_stats_partials(n_rows);
     if (pxs == 64) hipLaunchKernelGGL(dense_fwd1_stats_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(dense_fwd1_stats_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    return ossid_launch_status();
+}
+
+static long long d3_tiles(int B, int H, int W) { return (long long)B * ((H + D3_TR - 1) / D3_TR) * ((W + D3_TC - 1) / D3_TC); }
+
+int ossid_dense_dgrad3_mask_partials(int B, int H, int W) {
+    const long long nt = d3_tiles(B, H, W);
+    const int g = d3_grid();
+    return (int)(nt < g ? nt : g);
+}
+
+int ossid_dense_dgrad3_mask(const float* g, int g_channel_stride, const float* wpk_dgrad, const float* y1, float* db, int B, int H,
+                            int W, const float* alpha, const float* mask_scale, const float* mask_shift, float* partials,
+                            void* stream) {
+    if (!OSSID_CONV_SB) return OSSID_EINVAL;
+    if (!g || !wpk_dgrad || !y1 || !db || !alpha || !mask_scale || !mask_shift || !partials || B <= 0 || H <= 0 || W <= 0 ||
+        g_channel_stride < 32 || (g_channel_stride % 4) || ((uintptr_t)g & 15) || ((uintptr_t)wpk_dgrad & 15))
+        return OSSID_EINVAL;
+    const long long nt = d3_tiles(B, H, W);
+    if (nt > 0x7fffffff || (long long)B * H * W * DB_MID >= (1LL << 31)) return OSSID_EINVAL;
+    DenseBwd3Args a;
+    a.g = g, a.wpk = (const float4*)wpk_dgrad, a.y1 = y1, a.db = db, a.alpha = alpha, a.ms = mask_scale, a.mt = mask_shift;
+    a.partials = partials, a.B = B, a.H = H, a.W = W, a.gcs = g_channel_stride;
+    a.tiles_x = (W + D3_TC - 1) / D3_TC, a.tiles_y = (H + D3_TR - 1) / D3_TR, a.ntiles = (int)nt;
+    hipLaunchKernelGGL(dense_dgrad3_mask_kernel, dim3((unsigned)ossid_dense_dgrad3_mask_partials(B, H, W)), dim3(256), 0,
+                       (hipStream_t)stream, a);
     return ossid_launch_status();
 }
 

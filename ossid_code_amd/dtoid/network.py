@@ -963,7 +963,8 @@ class Network(nn.Module):
                 if isinstance(m, DenseBlock):
                     for layer in m.values():
                         kinds[layer.conv1] = (T.FWD_DECIDING, "dgrad")
-                        kinds[layer.conv2] = (T.FWD_DECIDING, "wino_dgrad") if T.USE_WINO else (T.FWD_DECIDING, "dgrad")
+                        kinds[layer.conv2] = (T.FWD_DECIDING, "wino_dgrad") if (T.USE_WINO and not T.dense_bwd3_fused()) else \
+                            (T.FWD_DECIDING, "dgrad")
                 elif isinstance(m, Transition):
                     kinds[m.conv] = (T.FWD_DECIDING, "dgrad")
             if self.use_hip_template_training:

@@ -891,6 +891,15 @@ def _dense_forward(buf, table, block, params, C0):
 DENSE_BWD_FUSED = os.environ.get("OSSID_DENSE_BWD_FUSED", "1") != "0"
 
 
+# ... and the layers' 3x3 data gradient with norm2 / ReLU's backward in its epilogue. (The dense layers' second convolution then
+# needs the DIRECT data-gradient layout, not the Winograd one: Network._train_pack_plan asks this function.)
+DENSE_BWD3_FUSED = os.environ.get("OSSID_DENSE_BWD3_FUSED", "1") != "0"
+
+
+def dense_bwd3_fused():
+    return DENSE_BWD3_FUSED and bool(_lib.fn("ossid_conv_split_bf16")())
+
+
 def dense_dgrad1_acc(dz, wpk_dgrad, buf, G, N, c, Ct, alpha, ms, mt, add=None):
     """G[:, :c] += alpha * relu'(ms * buf + mt) * (dz @ W1); returns the (partials, P) pair of norm1's column sums for
     bn_fold_bwd -- valid until the next call on this stream. add = (y, scale, shift): dz is dz + scale * y + shift."""
@@ -923,6 +932,7 @@ def _dense_backward(G, buf, saved, block, params, C0, side, direct=False):
     da = None
     fused_bwd = (DENSE_BWD_FUSED and mid == 128 and Ct <= 1024 and N * Ct < (1 << 32) and
                  bool(_lib.fn("ossid_conv_split_bf16")()))
+    fused_bwd3 = dense_bwd3_fused() and mid == 128 and growth == 32 and N * mid < (1 << 31)
     c = C0 + L * growth
     for li in range(L - 1, -1, -1):
         c -= growth
@@ -938,11 +948,22 @@ def _dense_backward(G, buf, saved, block, params, C0, side, direct=False):
         dw2 = grad_home(w2, direct)
         deferred.append(dict(x=y1, dy=gs, B=B, H=H, W=W, cin=mid, cout=growth, taps=9, dw=dw2, pre=(f2[0], f2[1]),
                              pre_relu=True, dy_cs=Ct))
-        wino = wino_fits(B, H, W, growth, mid, 9)
-        conv_raw(gs, _pack(w2, "wino_dgrad" if wino else "dgrad"), B, H, W, growth, mid, 9, db, in_cs=Ct, wino=wino)
-        # ... then the ReLU mask of relu(bn2(y1)), the scale and the (d shift, d scale) sums
-        s = chan_op(db, N, mid, x=y1, out=db, alpha=f2[0], mask_mode=1, mask_scale=f2[0], mask_shift=f2[1],
-                    sum_mode=1, defer=True)
+        if fused_bwd3:
+            # ... with the ReLU mask of relu(bn2(y1)), the scale and the (d shift, d scale) sums in its epilogue (csrc/dense_bwd.hip)
+            P3 = _lib.fn("ossid_dense_dgrad3_mask_partials")(B, H, W)
+            part3 = _scratch("dgrad3_mask", P3 * 2 * mid * 4, dev)
+            with _lib.on_device(dev):
+                _lib.check(_lib.fn("ossid_dense_dgrad3_mask")(gs.data_ptr(), Ct, _pack(w2, "dgrad").data_ptr(), y1.data_ptr(),
+                                                              db.data_ptr(), B, H, W, f2[0].data_ptr(), f2[0].data_ptr(),
+                                                              f2[1].data_ptr(), part3.data_ptr(), _lib.stream()),
+                           "ossid_dense_dgrad3_mask")
+            s = (part3, P3)
+        else:
+            wino = wino_fits(B, H, W, growth, mid, 9)
+            conv_raw(gs, _pack(w2, "wino_dgrad" if wino else "dgrad"), B, H, W, growth, mid, 9, db, in_cs=Ct, wino=wino)
+            # ... then the ReLU mask of relu(bn2(y1)), the scale and the (d shift, d scale) sums
+            s = chan_op(db, N, mid, x=y1, out=db, alpha=f2[0], mask_mode=1, mask_scale=f2[0], mask_shift=f2[1],
+                        sum_mode=1, defer=True)
         r2 = new_buf((4, mid), dev)
         bn_fold_bwd(None, None, g2, f2[2], f2[3], mid, N, r2[0], r2[1], r2[2], r2[3], partials=s)
         # dz = scale*db*mask + coef_x*y1 + coef_1: a pass of its own, or -- with the fused 1x1 data gradient -- formed while dz is
