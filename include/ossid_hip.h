@@ -31,8 +31,8 @@ extern "C" {
 #define OSSID_ELAUNCH (-5)
 
 /* The version of the struct layouts and signatures below; bumped whenever one changes (3: ossid_conv_desc gained
- * scratch / scratch_bytes / exact; 5: ossid_wgrad_desc gained dy_add / dy_add_scale / dy_add_shift, ossid_dense_dgrad1_acc its dz_add arguments). A binding compares it with ossid_abi_version() when it loads the library. */
-#define OSSID_ABI_VERSION 5
+ * scratch / scratch_bytes / exact; 5: ossid_wgrad_desc gained dy_add / dy_add_scale / dy_add_shift, ossid_dense_dgrad1_acc its dz_add arguments; 6: ossid_seq_replay / ossid_seq_op). A binding compares it with ossid_abi_version() when it loads the library. */
+#define OSSID_ABI_VERSION 6
 
 /* library / device probe: returns OSSID_ABI_VERSION of the build; arch_out_host (may be NULL, >=32 bytes)
  * receives the gcnArchName of the current device, e.g. "gfx950:sramecc+:xnack-". */
@@ -353,6 +353,37 @@ int ossid_chan_op(const ossid_chan_op_desc* desc_host, void* stream);
 /* Zero `bytes` bytes at `ptr` on `stream` (an accumulator a recorded launch sequence must clear on every replay: the
  * coefficient table of a dense block's backward pass; replaces torch.zeros inside such a sequence). */
 int ossid_fill_zero(void* ptr, size_t bytes, void* stream);
+
+/* Replay of a recorded launch sequence. The finetune step (scripts/online_learning.py:650-679) is ~1 800 small launches
+ * of fixed shape from one host thread; a binding records the launches one fixed-shape piece makes (a DenseNet block's
+ * forward, a template encoder's backward: models/dtoid/network.py:160-279) ONCE, as calls of this library's own
+ * stream-taking entry points with their argument values, and hands the list back here every step: the loop below re-issues
+ * them with the current stream handles, so a recorded launch costs the host its hipLaunchKernel and nothing else.
+ *   fn        one of this library's entry points of the form int f(..., void* stream) (every argument an integer, a
+ *             pointer, a size_t, a float or a double; the stream LAST), or NULL for a stream-order op: streams[slot]
+ *             waits for everything streams[wait_for] holds when the op is reached (an event owned by the op, created at
+ *             its first replay; ossid_seq_release destroys it);
+ *   iarg      the integer-class arguments in order, WITHOUT the stream (pointers and sign-extended integers);
+ *   fparg     the floating-point arguments in order: a float's bits in the low 32, a double's in all 64;
+ *   slot      index into the replay's stream table of the stream the call gets.
+ * Descriptor structs a call points to (ossid_conv_desc ...) are read at every replay: they, and all device memory they
+ * name, must stay alive and at the same addresses for as long as the sequence is replayed. Returns the first non-zero
+ * status (failed_at_host, may be NULL, then holds the op's index; -1 after a clean replay). x86-64 System V hosts only. */
+#define OSSID_SEQ_MAX_INT 24
+#define OSSID_SEQ_MAX_FP 8
+typedef struct ossid_seq_op {
+    void* fn;
+    void* event;
+    int32_t slot, wait_for, n_int, n_fp;
+    uint64_t iarg[OSSID_SEQ_MAX_INT];
+    uint64_t fparg[OSSID_SEQ_MAX_FP];
+} ossid_seq_op;
+int ossid_seq_replay(ossid_seq_op* ops_host, int n, void* const* streams_host, int n_streams, int* failed_at_host);
+int ossid_seq_release(ossid_seq_op* ops_host, int n);
+/* Calling-convention probe for the tests of ossid_seq_replay (no device work): writes its 14 arguments and the stream
+ * handle, each converted to double, to out_host[0..14]. */
+int ossid_seq_probe(int32_t i0, float f0, const void* p1, double d1, int64_t l2, int32_t i3, float f2, size_t s4, int32_t i5,
+                    int32_t i6, int32_t i7, double d3, int32_t i8, int64_t l9, double* out_host, void* stream);
 
 /* Segmentation term of DtoidNet.forward's loss and its metric (models/dtoid/__init__.py:210-232) in one pass:
  *   prob = sigmoid(logit) [B][hw];  out[0] = BCELoss(prob, mask) (mean over B*hw, torch's clamps: log terms >= -100);

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("OSSID_HIP_LIB") or os.path.join(_HERE, "libossid_hip.so")
 OBJ_DIR = os.path.join(_HERE, "build")
-SOURCES = ["zephyr.hip", "pn2.hip", "dtoid.hip", "conv.hip", "segtail.hip", "pipeline.hip", "train.hip", "wino.hip", "stem.hip", "wgrad_fc.hip", "dense.hip", "wgrad_t9.hip", "dense_bwd.hip"]
+SOURCES = ["zephyr.hip", "pn2.hip", "dtoid.hip", "conv.hip", "segtail.hip", "pipeline.hip", "train.hip", "wino.hip", "stem.hip", "wgrad_fc.hip", "dense.hip", "wgrad_t9.hip", "dense_bwd.hip", "seq.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
 

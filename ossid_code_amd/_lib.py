@@ -51,6 +51,15 @@ class PackRow(C.Structure):
                 ("taps", C.c_int32), ("kind", C.c_int32)]
 
 
+SEQ_MAX_INT, SEQ_MAX_FP = 24, 8
+
+
+class SeqOp(C.Structure):
+    """struct ossid_seq_op (include/ossid_hip.h)."""
+    _fields_ = [("fn", _vp), ("event", _vp), ("slot", C.c_int32), ("wait_for", C.c_int32), ("n_int", C.c_int32),
+                ("n_fp", C.c_int32), ("iarg", C.c_uint64 * SEQ_MAX_INT), ("fparg", C.c_uint64 * SEQ_MAX_FP)]
+
+
 _PROTOS = {
     "ossid_abi_version": (_i, [C.c_char_p, _i]),
     "ossid_conv_wino_split_bf16": (_i, []),
@@ -172,10 +181,14 @@ _PROTOS = {
     "ossid_bias_elu_affine_slice": (_i, [_vp, C.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ossid_bcast_sub_epilogue": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "ossid_amsgrad_step": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp]),
+    "ossid_seq_replay": (_i, [C.POINTER(SeqOp), _i, C.POINTER(_vp), _i, C.POINTER(_i)]),
+    "ossid_seq_release": (_i, [C.POINTER(SeqOp), _i]),
+    "ossid_seq_probe": (_i, [C.c_int32, _f, _vp, C.c_double, C.c_int64, C.c_int32, _f, _sz, C.c_int32, C.c_int32, C.c_int32,
+                             C.c_double, C.c_int32, C.c_int64, C.POINTER(C.c_double), _vp]),
 }
 
 
-ABI_VERSION = 5      # OSSID_ABI_VERSION of include/ossid_hip.h: the struct layouts below (tests/test_abi.py compares the two)
+ABI_VERSION = 6      # OSSID_ABI_VERSION of include/ossid_hip.h: the struct layouts below (tests/test_abi.py compares the two)
 
 
 def exported_symbols():
@@ -244,20 +257,36 @@ _QUERIES = frozenset((
     "ossid_dw_add_stats_partials", "ossid_stem_pool_bwd_partials", "ossid_dense_dgrad1_acc_partials", "ossid_dense_fwd1_stats_partials", "ossid_dense_dgrad3_mask_partials", "ossid_conv_split_bf16"))
 
 
+SEQ_C = os.environ.get("OSSID_SEQ_C", "1") != "0"      # replay through ossid_seq_replay (0: the Python loop, for A/B runs)
+_U32 = C.c_uint32
+
+
 class Seq:
     """A recorded launch sequence (see above). ops: (callable, args without the stream, slot, name) or ("wait", waiter, signal)."""
 
     def __init__(self):
         self.ops, self.keep, self.uses_side = [], [], False
+        self._compiled, self._compiled_len = None, -1
         self.scratch = {}          # (purpose, device, stream slot) -> the sequence's OWN scratch buffer (record.scratch)
 
     def __len__(self):
         return len(self.ops)
 
     def run(self, streams):
-        """streams: torch.cuda.Stream per slot (slot 0 first). Enqueues every recorded launch."""
+        """streams: torch.cuda.Stream per slot (slot 0 first). Enqueues every recorded launch: through the C-side loop
+        (ossid_seq_replay, csrc/seq.hip) unless bench's flop counter is listening or OSSID_SEQ_C=0."""
         raw = [st.cuda_stream for st in streams]
         cnt = _MFMA_COUNT
+        if cnt is None and SEQ_C:
+            c = self._compiled if self._compiled_len == len(self.ops) else self._compile()
+            if c is not None:
+                ns = len(raw)
+                rc = c[2](c[0], c[1], (_vp * ns)(*raw), ns, c[3])
+                if rc:
+                    k = c[3][0]
+                    raise RuntimeError("%s failed with status %d (replayed sequence, op %d)"
+                                       % (self.ops[k][3] if 0 <= k < len(self.ops) and self.ops[k][0] != "wait" else "stream wait", rc, k))
+                return
         for op in self.ops:
             f = op[0]
             if f == "wait":
@@ -268,6 +297,67 @@ class Seq:
                 raise RuntimeError("%s failed with status %d (replayed sequence)" % (op[3], rc))
             if cnt is not None and op[3] in _MFMA_RULES:
                 cnt._add(op[3], _MFMA_RULES[op[3]](op[1]), op[1])
+
+    def _compile(self):
+        """The ops as an ossid_seq_op array (built at the first replay, again if launches were recorded since). The recorded
+        argument objects stay referenced by self.ops: descriptor structs are read through their addresses at every replay.
+        None if a launch does not fit the C-side call shape (the Python loop replays it)."""
+        self._release()
+        n = len(self.ops)
+        arr = (SeqOp * max(n, 1))()
+        ok = True
+        for k, op in enumerate(self.ops):
+            o = arr[k]
+            if op[0] == "wait":
+                o.fn, o.slot, o.wait_for = None, op[1], op[2]
+                continue
+            types = _PROTOS[op[3]][1][:-1]
+            if len(types) != len(op[1]):
+                ok = False
+                break
+            ni = nf = 0
+            for a, t in zip(op[1], types):
+                if t is _f or t is C.c_double:
+                    if nf >= SEQ_MAX_FP:
+                        ok = False
+                        break
+                    o.fparg[nf] = (_U32.from_buffer_copy(C.c_float(a)).value if t is _f
+                                   else C.c_uint64.from_buffer_copy(C.c_double(a)).value)
+                    nf += 1
+                else:
+                    if ni >= SEQ_MAX_INT:
+                        ok = False
+                        break
+                    if isinstance(a, int):
+                        v = a
+                    elif a is None:
+                        v = 0
+                    else:
+                        v = C.cast(a, _vp).value or 0
+                    o.iarg[ni] = v & 0xFFFFFFFFFFFFFFFF
+                    ni += 1
+            if not ok:
+                break
+            o.fn = C.cast(op[0], _vp).value
+            o.slot, o.n_int, o.n_fp = op[2], ni, nf
+        self._compiled_len = n
+        if not ok:
+            self._compiled = None
+            return None
+        h = lib()
+        self._compiled = (arr, n, h.ossid_seq_replay, (_i * 1)(-1), h.ossid_seq_release)
+        return self._compiled
+
+    def _release(self):
+        c, self._compiled = self._compiled, None
+        if c is not None:
+            c[4](c[0], c[1])       # the stream-order ops' events
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
 
 
 class record:

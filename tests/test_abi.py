@@ -88,3 +88,43 @@ def test_compat_install_resolves_reference_import_paths():
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "ok ossid_code_amd.dtoid.model ossid_code_amd.scoring" in out.stdout
+
+
+def test_seq_replay_passes_every_argument_class_through_the_c_loop(hiplib):
+    """ossid_seq_replay (csrc/seq.hip) re-issues recorded calls through ONE call shape: integer-class arguments beyond the
+    sixth and the stream on the stack, floats and doubles in xmm registers, negative 32-bit values, NULL. The probe entry
+    point writes back what it received; the same ops through the Python loop must agree."""
+    import ctypes as C
+    lib = hiplib.lib()
+
+    class FakeStream:
+        def __init__(self, h):
+            self.cuda_stream = h
+
+        def wait_stream(self, other):
+            pass
+    out = [(C.c_double * 15)(), (C.c_double * 15)()]
+    anchor = C.create_string_buffer(64)
+    args = lambda o: (-7, 0.1, anchor, 1e300, -(1 << 40), 2 ** 31 - 1, -2.5, (1 << 63) + 5, -1, -123456, 77, -3.25e-7, 0, 1 << 50, o)
+    for use_c, o in ((True, out[0]), (False, out[1])):
+        seq = hiplib.Seq()
+        seq.ops.append((lib.ossid_seq_probe, args(o), 1, "ossid_seq_probe"))
+        seq.ops.append(("wait", 0, 0))                     # same stream on both sides: nothing to do, no HIP call
+        seq.ops.append((lib.ossid_fill_zero, (None, 0), 0, "ossid_fill_zero"))     # zero bytes: returns before any HIP call
+        old = hiplib.SEQ_C
+        hiplib.SEQ_C = use_c
+        try:
+            seq.run((FakeStream(0x1000), FakeStream(0xABCDEF0123)))
+            assert (seq._compiled is not None) == use_c
+        finally:
+            hiplib.SEQ_C = old
+    want = [-7, float(C.c_float(0.1).value), C.addressof(anchor), 1e300, -(1 << 40), 2 ** 31 - 1, -2.5, float((1 << 63) + 5), -1,
+            -123456, 77, -3.25e-7, 0, float(1 << 50), float(0xABCDEF0123)]
+    assert list(out[0]) == want
+    assert list(out[1]) == want
+    # a failing op reports its status and index
+    seq = hiplib.Seq()
+    seq.ops.append((lib.ossid_fill_zero, (None, 0), 0, "ossid_fill_zero"))
+    seq.ops.append((lib.ossid_fill_zero, (None, 8), 0, "ossid_fill_zero"))          # NULL with bytes: OSSID_EINVAL
+    with pytest.raises(RuntimeError, match="ossid_fill_zero failed with status -22 .*op 1"):
+        seq.run((FakeStream(0),))
