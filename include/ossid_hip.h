@@ -31,7 +31,7 @@ extern "C" {
 #define OSSID_ELAUNCH (-5)
 
 /* The version of the struct layouts and signatures below; bumped whenever one changes (3: ossid_conv_desc gained
- * scratch / scratch_bytes / exact; 5: ossid_wgrad_desc gained dy_add / dy_add_scale / dy_add_shift, ossid_dense_dgrad1_acc its dz_add arguments; 6: ossid_seq_replay / ossid_seq_op). A binding compares it with ossid_abi_version() when it loads the library. */
+ * scratch / scratch_bytes / exact; 5: ossid_wgrad_desc gained dy_add / dy_add_scale / dy_add_shift, ossid_dense_dgrad1_acc its dz_add arguments; 6: ossid_seq_replay / ossid_seq_op, ossid_bn_fold_bwd's zero_row). A binding compares it with ossid_abi_version() when it loads the library. */
 #define OSSID_ABI_VERSION 6
 
 /* library / device probe: returns OSSID_ABI_VERSION of the build; arch_out_host (may be NULL, >=32 bytes)
@@ -431,9 +431,11 @@ int ossid_bn_fold_fwd_tail(float* table, int row_stride, int tail_c0, const floa
                            const float* tail_pivot, int C, double n, const float* gamma, const float* beta, float eps, float momentum,
                            float* running_mean, float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out,
                            void* stream);
+/* zero_row (may be NULL): C floats set to 0 by the same launch -- the unused third row of the [3][C] gradient a caller hands
+ * back for the statistics (constant term, coefficient of x, pivot: the pivot has no gradient). */
 int ossid_bn_fold_bwd(const float* dscale, const float* dshift, const float* partials, int n_partials, const float* gamma,
                       const float* mean, const float* rstd, int C, double n, float* dgamma, float* dbeta, float* coef_x,
-                      float* coef_1, int accumulate, void* stream);
+                      float* coef_1, int accumulate, float* zero_row, void* stream);
 
 /* sums[c], sums[sums_row_stride + c] = the column sums left as n_partials partial rows [n][2][C] by ossid_chan_op
  * (defer_finalize), combined in a fixed order in double. */

@@ -124,7 +124,7 @@ _PROTOS = {
     "ossid_chan_op_partials": (_i, [C.c_longlong, _i]),
     "ossid_chan_op": (_i, [_vp, _vp]),
     "ossid_bn_fold_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ossid_bn_fold_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, C.c_double, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ossid_bn_fold_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, C.c_double, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ossid_conv_pack_weights_table": (_i, [_vp, _i, C.c_longlong, _vp]),
     "ossid_colsum_finalize": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "ossid_avgpool2_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),

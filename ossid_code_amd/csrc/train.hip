@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, int C, double n,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                          float* __restrict__ cb, float* __restrict__ ck, int accumulate) {
+                                                          float* __restrict__ cb, float* __restrict__ ck, int accumulate,
+                                                          float* __restrict__ zero_row) {
     constexpr int CPB = 256 / PARTS;
     __shared__ double red[PARTS][CPB][2];
     const int c = blockIdx.x * CPB + (threadIdx.x % CPB), part = threadIdx.x / CPB;
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const float* __restric
     if (dgamma) dgamma[c] = (float)(ds * r);
     if (dbeta) dbeta[c] = (float)dt;
     const double b = 2.0 * dvar / n, k = dmean / n - 2.0 * mu * dvar / n;
+    if (zero_row) zero_row[c] = 0.0f;
     if (accumulate) {
         cb[c] += (float)b;
         ck[c] += (float)k;
@@ -1600,19 +1602,19 @@ int ossid_bn_fold_fwd_tail(float* table, int row_stride, int tail_c0, const floa
 
 int ossid_bn_fold_bwd(const float* dscale, const float* dshift, const float* partials, int n_partials, const float* gamma,
                       const float* mean, const float* rstd, int C, double n, float* dgamma, float* dbeta, float* coef_x,
-                      float* coef_1, int accumulate, void* stream) {
+                      float* coef_1, int accumulate, float* zero_row, void* stream) {
     if (((!dscale || !dshift) && n_partials <= 0) || (n_partials > 0 && !partials) || !mean || !rstd || C <= 0 || n <= 0 ||
         !coef_x || !coef_1)
         return OSSID_EINVAL;
     if (n_partials > 128)
         hipLaunchKernelGGL(bn_fold_bwd_kernel<64>, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, dscale, dshift,
-                           partials, n_partials, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate);
+                           partials, n_partials, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate, zero_row);
     else if (n_partials > 16)
         hipLaunchKernelGGL(bn_fold_bwd_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, dscale, dshift,
-                           partials, n_partials, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate);
+                           partials, n_partials, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate, zero_row);
     else
         hipLaunchKernelGGL(bn_fold_bwd_kernel<4>, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, dscale, dshift,
-                           partials, n_partials, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate);
+                           partials, n_partials, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate, zero_row);
     return ossid_launch_status();
 
 }

@@ -74,9 +74,38 @@ class FlatParams:
     # With p.grad preset to a view of the flat buffer autograd ACCUMULATES (p.grad += g): one add kernel per parameter
     # per step (~600 launches, 2.6 ms of the 57 ms step). With p.grad = None it hands over the freshly computed tensor
     # at no cost, and torch._foreach_copy_ packs all of them into the flat buffer in a handful of launches.
-    def detach_grads(self):
+    def detach_grads(self, collect=False):
+        """collect=True: post-accumulate hooks note, WHILE backward runs, which gradients need a copy into the flat buffer
+        (gather_grads then has no loop over the ~700 parameters left to do at the end of the step, where the device has
+        run dry and every host microsecond in front of the optimizer launch is step time: 0.9 ms of idle device in
+        profiles/r04_finetune_step_list.txt before this)."""
         for _, p in self.entries:
             p.grad = None
+        if collect:
+            self._install_hooks()
+            self._c_dst, self._c_src, self._c_seen = [], [], set()
+        self._collecting = bool(collect)
+
+    def _install_hooks(self):
+        if self.__dict__.get("_hooks_installed"):
+            return
+        self._hooks_installed = True
+        self._collecting = False
+
+        def make(i, v, vp):
+            def hook(p):
+                if self._collecting:
+                    g = p.grad
+                    if g is not None:
+                        self._c_seen.add(i)
+                        if g.data_ptr() != vp:
+                            self._c_dst.append(v)
+                            self._c_src.append(g)
+            return hook
+        for i, ((_, p), v) in enumerate(zip(self.entries, self._views)):
+            p.register_post_accumulate_grad_hook(make(i, v, v.data_ptr()))
+        n_used_entries = sum(1 for name, _ in self.entries if self.offsets[name][0] < self.n_used)
+        self._used_idx = frozenset(range(n_used_entries))
 
     def gather_grads(self, reattach=True):
         """After backward with p.grad = None: every gradient into its slice of the flat buffer (multi-tensor copies; nothing
@@ -86,6 +115,19 @@ class FlatParams:
         reattach=False: leave `p.grad = view` to a later reattach_grads() -- 700 attribute writes that nothing on the device
         waits for; finetune_step does them AFTER it has launched the optimizer (the device is idle at the end of a step:
         every host microsecond in front of that launch is step time)."""
+        if self.__dict__.get("_collecting"):
+            # the hooks did the walk during backward; a USED parameter no hook fired for got no gradient this step
+            self._collecting = False
+            dst, src = self._c_dst, self._c_src
+            zero = [self._views[i] for i in self._used_idx - self._c_seen]
+            self._c_dst = self._c_src = self._c_seen = None
+            if zero:
+                torch._foreach_zero_(zero)
+            if dst:
+                torch._foreach_copy_(dst, src)
+            if reattach:
+                self.reattach_grads()
+            return
         dst, src, zero = [], [], []
         n_used_entries = self.__dict__.get("_n_used_entries")
         if n_used_entries is None:
@@ -466,7 +508,7 @@ def _finetune_step_eager(model, batch, optimizer, sync=None):
     if flat is None and sync is not None:
         flat = sync.flat               # a torch optimizer over FlatParams views: same gather protocol
     if flat is not None:               # gradients gathered into the flat buffer by multi-tensor copies
-        flat.detach_grads()
+        flat.detach_grads(collect=sync is None and hasattr(optimizer, "flat"))
         if sync is not None and sync.overlap:
             sync.begin()               # per-bucket gather + all-reduce from autograd hooks, under the backward pass
             loss.backward()

@@ -296,6 +296,11 @@ class _PadOne:
 # 41.9 ms either way. (GPU_MAX_HW_QUEUES=8 made it 79 ms; left alone.)
 ENC_G_STREAM = int(os.environ.get("OSSID_ENC_G_STREAM", "0"))
 ENC_L_STREAM = int(os.environ.get("OSSID_ENC_L_STREAM", "1"))
+# The global template encoder's node created BEFORE the stem convolution's (1) or behind it (0). Autograd runs ready nodes in
+# reverse order of creation: created first, the encoder's backward -- a chain of ~110 small launches on its side stream that
+# needs the stem's kernel gradient and ends the step -- is enqueued AFTER the stem convolution's weight gradient instead of in
+# front of it (where that launch and its host work became a tail of their own behind the chain).
+ENC_G_FIRST = os.environ.get("OSSID_ENC_G_FIRST", "1") != "0"
 
 
 class _CatConv:
@@ -871,9 +876,12 @@ class Network(nn.Module):
         seq = list(ife.backdense_1) + list(ife.backdense_2)      # norm0 relu0 pool0 block1 | trans1 block2 ... norm5
         if self.use_hip_stem_training:
             # stem on this repo's kernels, channels-last from the first one
+            if lazy_g is not None and ENC_G_FIRST:
+                g, s_g = lazy_g()
             x0 = T.stem_conv(image, ife.backdense_0[0])           # implicit-im2col 7x7 / 2 kernel, exact f32 (csrc/stem.hip)
             if lazy_g is not None:
-                g, s_g = lazy_g()
+                if not ENC_G_FIRST:
+                    g, s_g = lazy_g()
                 self._join(s_g, [g])
             self.__dict__["_pack_event"] = pack_event            # (later forks -- the local encoder -- wait for the first big part)
             x = T.stem_tail(x0, g, seq[0])                        # modulation + norm0 + ReLU + pool0: three passes
@@ -923,10 +931,9 @@ class Network(nn.Module):
         torch._foreach_add_(ts, 1)
         return out
 
-    def _train_pack_plan(self):
-        """The PackPlan over every convolution the hip training path runs (DenseNet blocks and transitions, c1, the head's
-        3x3 convolutions), rebuilt when a weight tensor was re-homed."""
-        from . import train_ops as T
+    def _train_pack_convs(self):
+        """(convolutions in packing order, end of the first launch's part, end of the second's): the module structure is fixed,
+        so _train_pack_plan walks it once, not every step (the step's first launch waits for this host work)."""
         from .backbones import DenseBlock, Transition
         ife, corr = self.image_feature_extractor, self.correlation_model
         convs = []
@@ -948,7 +955,27 @@ class Network(nn.Module):
             [getattr(corr, "s%d" % i) for i in (1, 2, 3, 4, 5)]
         for mod in (self.classification, self.regression):
             convs += [getattr(mod, "conv%d" % i) for i in (1, 2, 3, 4)] + [mod.output]
+        return convs, n_global, n_first
+
+    def _train_pack_plan(self):
+        """The PackPlan over every convolution the hip training path runs (DenseNet blocks and transitions, c1, the head's
+        3x3 convolutions), rebuilt when a weight tensor was re-homed."""
+        from . import train_ops as T
+        from .backbones import DenseBlock, Transition
+        ife, corr = self.image_feature_extractor, self.correlation_model
+        cached = self.__dict__.get("_pack_convs")
+        if cached is not None and cached[0] == (self.use_hip_template_training,):
+            convs, n_global, n_first = cached[1]
+        else:
+            convs, n_global, n_first = self._train_pack_convs()
+            self.__dict__["_pack_convs"] = ((self.use_hip_template_training,), (convs, n_global, n_first))
         plan = self.__dict__.get("_pack_plan")
+        if plan is not None and plan.misses:
+            # layouts a layer had to pack by itself last step (a launch on the critical chain): the decoder layers' data gradient
+            # runs on the UP-SAMPLED grid, where the Winograd form applies although their forward (fused up-sampling) is direct.
+            # The plan learns them: rebuilt once with those layouts in, the direct data-gradient layout they replace out
+            self.__dict__.setdefault("_pack_learned", set()).update(plan.misses)
+            plan = None
         if plan is None or not plan.valid_for(convs):
             # which layouts the step asks for at finetune batch sizes (train_ops.wino_fits): the head's plain 3x3 layers run
             # forward and data gradient on the Winograd kernel, the dense blocks' 3x3 only the data gradient; everything
@@ -968,10 +995,23 @@ class Network(nn.Module):
                 elif isinstance(m, Transition):
                     kinds[m.conv] = (T.FWD_DECIDING, "dgrad")
             if self.use_hip_template_training:
+                from .train_encoders import encoder_convs
                 for enc in (self.template_feature_extractor_global, self.template_feature_extractor):
                     for cv in encoder_convs(enc):
                         final = any(cv is getattr(enc, n, None) for n in ("final_conv_1", "final_conv_2"))
                         kinds[cv] = ("fwd_exact", "dgrad_exact") if final else (T.FWD_ENCODER, "dgrad")
+            learned = self.__dict__.get("_pack_learned")
+            if learned:
+                by_ptr = {cv.weight.data_ptr(): cv for cv in convs}
+                for ptr, kind in learned:
+                    cv = by_ptr.get(ptr)
+                    if cv is None:
+                        continue
+                    have = tuple(kinds.get(cv, ("fwd", "dgrad")))
+                    if kind == "wino_dgrad":
+                        have = tuple(k for k in have if k != "dgrad" or (ptr, "dgrad") in learned)
+                    if kind not in have:
+                        kinds[cv] = have + (kind,)
             plan = self.__dict__["_pack_plan"] = T.PackPlan(convs, kinds, split_at=([n_global] if n_global else []) + [n_first])
         return plan
 

@@ -215,6 +215,8 @@ def _pack(w, kind):
     key = (w.data_ptr(), tuple(w.shape), kind)
     if plan is not None and plan.fresh.get(key) == w._version and plan.buf_ptr.get(key) == buf.data_ptr():
         return buf
+    if plan is not None and key[0] in plan.weight_ptrs:
+        plan.misses.add((key[0], kind))          # a layout the plan did not foresee: whoever owns the plan adds it (next step)
     with _lib.on_device(w.device):
         if kind in ("wino_fwd", "wino_dgrad"):
             name = "ossid_conv_pack_weights_wino"
@@ -275,6 +277,8 @@ class PackPlan:
         self.keys = keys
         self.weights = [c.weight for c in convs]
         self.sig = tuple(w.data_ptr() for w in self.weights)
+        self.weight_ptrs = frozenset(self.sig)
+        self.misses = set()                    # (weight address, layout) a layer packed by itself while this plan was active
         self.fresh = {}
 
     def valid_for(self, convs):
@@ -410,13 +414,15 @@ def bn_fold_fwd(sums, C, n, gamma, beta, eps, momentum, running_mean, running_va
     return out
 
 
-def bn_fold_bwd(dscale, dshift, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate=False, partials=None):
-    """partials = (scratch, P) of a deferred chan_op (row 0 = d shift, row 1 = d scale) instead of dscale / dshift."""
+def bn_fold_bwd(dscale, dshift, gamma, mean, rstd, C, n, dgamma, dbeta, coef_x, coef_1, accumulate=False, partials=None,
+                zero_row=None):
+    """partials = (scratch, P) of a deferred chan_op (row 0 = d shift, row 1 = d scale) instead of dscale / dshift.
+    zero_row: C floats the same launch clears."""
     part, P = partials if partials is not None else (None, 0)
     with _lib.on_device(coef_x.device):
         rc = _lib.fn("ossid_bn_fold_bwd")(_p(dscale), _p(dshift), _p(part), int(P), _p(gamma), mean.data_ptr(), rstd.data_ptr(),
                                           C, float(n), _p(dgamma), _p(dbeta), coef_x.data_ptr(), coef_1.data_ptr(),
-                                          1 if accumulate else 0, _lib.stream())
+                                          1 if accumulate else 0, _p(zero_row), _lib.stream())
     _lib.check(rc, "ossid_bn_fold_bwd")
 
 
@@ -492,7 +498,9 @@ class ColStats(torch.autograd.Function):
 class BNFold(torch.autograd.Function):
     """Training-mode BatchNorm2d as a per-channel (scale, shift): forward(sums, gamma, beta) with the module's running
     buffers updated in place (momentum, unbiased variance) exactly as nn.BatchNorm2d.train() does. Returns
-    stacked [2, C] = (scale, shift)."""
+    (scale, shift), each [C] -- two outputs, so that their gradients arrive as two tensors: as rows of ONE [2, C] output they
+    came back through two select-backward nodes (a fill and a copy each) and an add, five launches per BatchNorm on the
+    backward pass's critical chain, and the [3, C] gradient of the sums was stacked by two more."""
 
     @staticmethod
     def forward(ctx, sums, gamma, beta, n, bn):
@@ -502,23 +510,26 @@ class BNFold(torch.autograd.Function):
                           bn.running_var if bn.track_running_stats else None)
         ctx.save_for_backward(gamma, out)
         ctx.n = n
-        return out[:2]
+        ctx.set_materialize_grads(False)
+        return out[0], out[1]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g_scale, g_shift):
         gamma, out = ctx.saved_tensors
         C = int(out.shape[1])
-        g = g.contiguous()
-        res = torch.empty((4, C), dtype=torch.float32, device=out.device)      # dgamma, dbeta, coef_x, coef_1
-        bn_fold_bwd(g[0], g[1], gamma, out[2], out[3], C, ctx.n, res[0], res[1], res[2], res[3])
-        dsums = torch.stack([res[3], res[2], torch.zeros_like(res[2])])      # ColStats convention: [constant, x coefficient, -]
-        return dsums, res[0], res[1], None, None
+        dev = out.device
+        g_scale = _zeros(C, dev) if g_scale is None else g_scale.contiguous()
+        g_shift = _zeros(C, dev) if g_shift is None else g_shift.contiguous()
+        # rows 0..2 = the gradient of the sums in ColStats' convention [constant, x coefficient, - (cleared by the launch)],
+        # rows 3, 4 = dgamma, dbeta
+        res = torch.empty((5, C), dtype=torch.float32, device=dev)
+        bn_fold_bwd(g_scale, g_shift, gamma, out[2], out[3], C, ctx.n, res[3], res[4], res[1], res[0], zero_row=res[2])
+        return res[:3], res[3], res[4], None, None
 
 
 def bn_fold(sums, n, bn):
     """(scale, shift) of a training-mode nn.BatchNorm2d given the column sums of its input."""
-    st = BNFold.apply(sums, bn.weight, bn.bias, n, bn)
-    return st[0], st[1]
+    return BNFold.apply(sums, bn.weight, bn.bias, n, bn)
 
 
 # Weight gradients on a second HIP stream. A convolution's weight gradient feeds nothing but the optimizer, while its data
