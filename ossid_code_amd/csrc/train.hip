@@ -1216,20 +1216,25 @@ __global__ __launch_bounds__(256) void seg_bce_iou_kernel(const float* __restric
 }
 
 // out[0] = mean BCE over all B * hw elements, out[1 + b] = IoU of image b (0 when the union is empty)
-__global__ void seg_bce_iou_finalize_kernel(const double* __restrict__ partials, int B, int blocks_per_image, long long hw,
-                                            float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one wave: lane l takes blocks l, l + 64, ... of an image, then a fixed-order butterfly in double (deterministic; a single
+// thread walking all B x blocks_per_image partials took 58 us on the step's critical chain)
+__global__ __launch_bounds__(64) void seg_bce_iou_finalize_kernel(const double* __restrict__ partials, int B, int blocks_per_image,
+                                                                  long long hw, float* __restrict__ out) {
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
     double total = 0.0;
     for (int b = 0; b < B; ++b) {
         double l = 0.0, in = 0.0, un = 0.0;
-        for (int k = 0; k < blocks_per_image; ++k) {
+        for (int k = lane; k < blocks_per_image; k += 64) {
             const double* o = partials + ((size_t)b * blocks_per_image + k) * 3;
             l += o[0], in += o[1], un += o[2];
         }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) l += __shfl_xor(l, m), in += __shfl_xor(in, m), un += __shfl_xor(un, m);
         total += l;
-        out[1 + b] = un > 0.0 ? (float)(in / un) : 0.0f;
+        if (lane == 0) out[1 + b] = un > 0.0 ? (float)(in / un) : 0.0f;
     }
-    out[0] = (float)(total / ((double)B * (double)hw));
+    if (lane == 0) out[0] = (float)(total / ((double)B * (double)hw));
 }
 
 // =====================================================================================================================

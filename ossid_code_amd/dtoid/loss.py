@@ -29,13 +29,18 @@ class _FusedDetectionLoss(torch.autograd.Function):
                                                           ws.data_ptr(), losses.data_ptr(), scales.data_ptr(), _lib.stream())
         _lib.check(rc, "ossid_focal_smoothl1_loss_fwd")
         ctx.save_for_backward(dcls, dreg, scales)
-        return losses
+        ctx.set_materialize_grads(False)
+        # two outputs (not two slices of one: their gradients came back through two slice-backward fills, two copies and an add)
+        return losses[0:1], losses[1:2]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g_cls, g_reg):
         dcls_raw, dreg_raw, scales = ctx.saved_tensors
         B, A, C = dcls_raw.shape
-        g = g.float().contiguous()
+        zero = None
+        if g_cls is None or g_reg is None:
+            zero = torch.zeros(1, dtype=torch.float32, device=dcls_raw.device)
+        g = torch.cat([(zero if g_cls is None else g_cls).float().reshape(1), (zero if g_reg is None else g_reg).float().reshape(1)])
         dcls, dreg = torch.empty_like(dcls_raw), torch.empty_like(dreg_raw)
         with torch.cuda.device(g.device):
             rc = _lib.fn("ossid_focal_smoothl1_loss_bwd")(dcls_raw.data_ptr(), dreg_raw.data_ptr(), scales.data_ptr(), g.data_ptr(),
@@ -68,8 +73,7 @@ class DetectionLoss(nn.Module):
         B, A, C = classifications.shape
         dev = classifications.device
         if classifications.is_cuda and self.use_fused and annotations.shape[1] <= 16 and C <= 64:
-            losses = _FusedDetectionLoss.apply(classifications, regressions, anchors, annotations.to(dev), alpha, gamma)
-            return losses[0:1], losses[1:2]
+            return _FusedDetectionLoss.apply(classifications, regressions, anchors, annotations.to(dev), alpha, gamma)
         annotations = annotations.to(dev)
         anchor = anchors[0]
         aw, ah = anchor[:, 2] - anchor[:, 0], anchor[:, 3] - anchor[:, 1]
@@ -140,9 +144,12 @@ class SegBceIou(torch.autograd.Function):
         ctx.n = x.numel()
         iou = out[1:]
         ctx.mark_non_differentiable(prob, iou)
+        ctx.set_materialize_grads(False)         # (no zero tensors for the two outputs nothing differentiates)
         return prob, out[0], iou
 
     @staticmethod
     def backward(ctx, _gprob, gloss, _giou):
         (dsum,) = ctx.saved_tensors
+        if gloss is None:
+            return None, None
         return dsum * (gloss / ctx.n), None

@@ -704,7 +704,7 @@ class FusedConv(torch.autograd.Function):
             if dv is None:
                 dv = du
             if sums is not None:
-                db = sums[0].clone()
+                db = sums[0]                     # (a row of a fresh [2, C] tensor: AccumulateGrad takes it over as it is)
         else:
             dv = du
         pre = None if ps is None else (ps, pt)

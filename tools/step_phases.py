@@ -1,0 +1,127 @@
+"""Where the finetune step's time goes on the DEVICE, without a profiler attached: HIP events recorded on the main stream at
+the step's phase boundaries (forward: from wrappers around the phase functions; backward: from tensor hooks, which fire when
+the autograd engine reaches that point), averaged over a few steps. rocprofv3 slows the host down by ~30 %, which opens gaps
+on the device that an ordinary run does not have; this shows which phases really wait.
+  python tools/step_phases.py [--reps 5]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ossid_code_amd import dtoid  # noqa: E402
+from ossid_code_amd.dtoid import finetune, train_ops as T  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8)
+    a = ap.parse_args()
+    cfg = dtoid.DtoidConfig()
+    torch.manual_seed(0)
+    m = dtoid.DtoidNet(cfg).cuda().train()
+    flat = finetune.FlatParams(m)
+    opt = finetune.FusedAMSGrad(flat, lr=1e-4, weight_decay=1e-6)
+    g = torch.Generator().manual_seed(1)
+    B = a.batch
+    mask = torch.zeros(B, 1, 480, 640)
+    mask[:, :, 120:240, 160:320] = 1
+    batch = {"img": torch.rand(B, 3, 480, 640, generator=g), "limg": torch.rand(B, 3, 124, 124, generator=g),
+             "lmask": (torch.rand(B, 1, 124, 124, generator=g) > 0.5).float(),
+             "gimg": torch.rand(B, 3, 124, 124, generator=g),
+             "gmask": (torch.rand(B, 1, 124, 124, generator=g) > 0.5).float(),
+             "bbox_gt": torch.tensor([[[160.0, 120.0, 320.0, 240.0, 1.0]]]).repeat(B, 1, 1),
+             "heatmap": torch.rand(B, 1, 29, 39, generator=g).double(), "mask": mask}
+    batch = {k: v.cuda() for k, v in batch.items()}
+    marks = []          # (label, event) of the current step, in host order
+
+    def mark(label):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        marks.append((label, ev, time.perf_counter()))
+
+    def hook(t, label):
+        if t.requires_grad:
+            t.register_hook(lambda _g: mark(label))
+        return t
+    net = m.model
+    orig = {"stem_conv": T.stem_conv, "stem_tail": T.stem_tail, "dense": T.dense_block_train, "head": net._head_train_hip}
+    nblk = [0]
+
+    def stem_conv(img, conv):
+        mark("fwd: start -> stem conv")
+        out = orig["stem_conv"](img, conv)
+        return hook(out, "bwd: stem tail -> stem conv")
+
+    def stem_tail(x0, k, bn, **kw):
+        mark("fwd: stem conv (+ global encoder) -> stem tail")
+        out = orig["stem_tail"](x0, k, bn, **kw)
+        return hook(out, "bwd: block 1 -> stem tail")
+
+    def dense(x, block):
+        nblk[0] += 1
+        i = nblk[0]
+        mark("fwd: -> block %d" % i)
+        hook(x, "bwd: block %d done" % i)
+        out = orig["dense"](x, block)
+        mark("fwd: block %d done" % i)
+        return hook(out, "bwd: -> block %d" % i)
+
+    def head(feat, local):
+        mark("fwd: c1 / n1 -> head")
+        hook(feat, "bwd: head done")
+        out = orig["head"](feat, local)
+        mark("fwd: head done")
+        return out
+    T.stem_conv, T.stem_tail, T.dense_block_train = stem_conv, stem_tail, dense
+    net._head_train_hip = head
+    real_model_call = m.forward
+
+    def fwd(b):
+        out = real_model_call(b)
+        mark("fwd: losses done")
+        hook(out["loss"], "bwd: start")
+        return out
+    m.forward = fwd
+    real_step = opt.step
+
+    def step():
+        mark("backward returned + gradients gathered -> optimizer")
+        real_step()
+        mark("optimizer done")
+    opt.step = step
+    totals, counts, order, lead = {}, {}, [], {}
+    for it in range(3 + a.reps):
+        marks.clear()
+        nblk[0] = 0
+        torch.cuda.synchronize()
+        mark("step start")
+        finetune.finetune_step(m, batch, opt)
+        torch.cuda.synchronize()
+        if it < 3:
+            continue
+        evs = sorted(((marks[0][1].elapsed_time(e), lbl, (th - marks[0][2]) * 1e3) for lbl, e, th in marks), key=lambda x: x[0])
+        if not order:
+            order = [lbl for _, lbl, _ in evs]
+        prev = 0.0
+        for t, lbl, th in evs:
+            totals[lbl] = totals.get(lbl, 0.0) + (t - prev)
+            counts[lbl] = counts.get(lbl, 0) + 1
+            lead[lbl] = lead.get(lbl, 0.0) + (t - th)
+            prev = t
+        totals["_span"] = totals.get("_span", 0.0) + evs[-1][0]
+    print("phase boundaries on the main stream, mean over %d steps: ms since the previous boundary | cumulative | how far the host was\n"
+          "ahead when it enqueued the boundary (device time of the event - host time of its record; ~0 = the device was waiting for the host)" % a.reps)
+    cum = 0.0
+    for lbl in order:
+        d = totals[lbl] / max(counts[lbl], 1)
+        cum += d
+        print("%8.3f %8.3f %8.3f  %s" % (d, cum, lead[lbl] / max(counts[lbl], 1), lbl))
+    print("span %.3f ms" % (totals["_span"] / a.reps))
+
+
+if __name__ == "__main__":
+    main()
