@@ -145,7 +145,7 @@ def dtoid_leg(a, dev, dist, world):
     test = {"img": torch.rand(1, 3, 480, 640, generator=g).to(dev), "obj_id": torch.tensor([1]),
             "limg": torch.rand(1, nt, 3, 124, 124, generator=g).to(dev),
             "lmask": (torch.rand(1, nt, 1, 124, 124, generator=g) > 0.5).float().to(dev)}
-    t_fwd = timed(lambda: m.forwardTestTime(test), 3, 10)
+    t_fwd = timed(lambda: m.forwardTestTime(test), 5, 40)      # (40 frames: 10 were 40 ms of wall, at the mercy of one slow frame)
     # BASELINE configs[2] as stated: batch = 32 images x 21 templates. (i) forward_all_templates semantics per image
     # through the additive batched API (backbone once on the batch, head graph per image); (ii) Network.forward on 32
     # (image, template) pairs

@@ -33,4 +33,13 @@ rocprofv3 --kernel-trace -d $O/fw2 --output-format csv -- python3 tools/bench_dt
 python tools/trace_list.py $O/fw2/*/*kernel_trace.csv --marker detect_emit > $O/forward_step_list.txt
 rm -rf $O/fw2
 python tools/bench_finetune.py --reps 10 --no-graph > $O/finetune_ms.txt 2>&1
+python tools/step_phases.py > $O/finetune_step_phases.txt 2>&1
+rocprofv3 --kernel-trace -d $O/ft3 --output-format csv -- python3 tools/bench_finetune.py --reps 3 --no-graph > $O/ft3.log 2>&1
+python tools/trace_list.py $O/ft3/*/*kernel_trace.csv > $O/finetune_step_list.txt
+rm -rf $O/ft3
+# traffic beyond L2 + launches of the finetune leg (steady state: the third call)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc/finetune_f -- python3 tools/dtoid_leg.py --leg finetune --calls 3 > $O/pmc_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc/finetune_w -- python3 tools/dtoid_leg.py --leg finetune --calls 3 > $O/pmc_w.log 2>&1
+python tools/pmc_dtoid_traffic.py $O/pmc $O/finetune_traffic.json > $O/finetune_traffic.txt 2>&1
+rm -rf $O/pmc
 ls -la $O
