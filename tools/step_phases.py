@@ -76,6 +76,21 @@ def main():
         out = orig["head"](feat, local)
         mark("fwd: head done")
         return out
+    # forked branches (template encoders, correlation branches, detection trunks): when does each branch's BACKWARD start on the
+    # device (hook on its outputs: fires in front of the branch's last node, on the branch's stream)
+    real_fork = net._fork
+    nfork = [0]
+
+    def fork(k, inputs, fn):
+        nfork[0] += 1
+        i = nfork[0]
+        out, side = real_fork(k, inputs, fn)
+        for t in (out if isinstance(out, (tuple, list)) else (out,)):
+            if torch.is_tensor(t) and t.requires_grad:
+                t.register_hook(lambda _g, i=i, k=k: mark("   [side] bwd of fork %d (slot %d) starts" % (i, k)))
+                break
+        return out, side
+    net._fork = fork
     T.stem_conv, T.stem_tail, T.dense_block_train = stem_conv, stem_tail, dense
     net._head_train_hip = head
     real_model_call = m.forward
@@ -97,6 +112,7 @@ def main():
     for it in range(3 + a.reps):
         marks.clear()
         nblk[0] = 0
+        nfork[0] = 0
         torch.cuda.synchronize()
         mark("step start")
         finetune.finetune_step(m, batch, opt)
