@@ -589,3 +589,38 @@ def test_grouped_weight_gradients_of_a_dense_block_match_torch(hiplib, B, H, W, 
     torch.cuda.synchronize()
     for it, f in zip(items, first):
         assert torch.equal(it["dw"], f)
+
+
+def test_c_side_replay_of_a_dense_block_equals_the_python_loop_bit_for_bit(hiplib, monkeypatch):
+    """ossid_seq_replay (csrc/seq.hip) re-issues a dense block's recorded forward and backward launches -- descriptor pointers,
+    integers beyond the sixth on the stack, floats and doubles in xmm registers, the stream-order ops between the main and the
+    weight-gradient stream as library-owned events -- exactly as the Python loop over ctypes calls does: two blocks with the same
+    weights, one replayed by each, must agree in every bit of the output, the input gradient and every parameter gradient."""
+    import copy
+    from ossid_code_amd import _lib
+    monkeypatch.setattr(T, "SEQ_REPLAY", True)
+    torch.manual_seed(5)
+    blk_c = backbones.DenseBlock(4, 64).cuda().train()
+    blk_p = copy.deepcopy(blk_c)
+    res = {}
+    for name, blk, use_c in (("c", blk_c, True), ("py", blk_p, False)):
+        monkeypatch.setattr(_lib, "SEQ_C", use_c)
+        outs = []
+        for rnd in range(3):                      # round 0 records, rounds 1 and 2 replay
+            g = torch.Generator(device="cuda").manual_seed(10 + rnd)
+            x = torch.randn(2, 64, 14, 18, device="cuda", generator=g).requires_grad_(True)
+            go = torch.randn(2, 64 + 32 * 4, 14, 18, device="cuda", generator=g)
+            for p in blk.parameters():
+                p.grad = None
+            y = T.dense_block_train(x, blk)
+            y.backward(go)
+            T.join_wgrad_stream()
+            torch.cuda.synchronize()
+            outs.append([y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blk.parameters()] +
+                        [b.clone() for b in blk.buffers() if b.dtype.is_floating_point])
+        res[name] = outs
+        (plan,) = blk.__dict__["_train_plans"].values()
+        assert (plan.fwd._compiled is not None) == use_c and (plan.bwd._compiled is not None) == use_c
+    for rnd in range(3):
+        for a, b in zip(res["c"][rnd], res["py"][rnd]):
+            assert torch.equal(a, b), rnd
