@@ -210,6 +210,10 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
                 const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0);
                 st[r][cc] = __builtin_bit_cast(v4f, v);
             }
+    };
+    // (the loads ONLY above: the input's affine is applied where the patch is consumed -- applied right behind the loads it was a
+    // wait for them in front of the chunk's MFMAs, the latency the prefetch is there to hide)
+    auto stage_affine = [&](int ci0) {
         if (psb) {      // affine (+ReLU) of the INPUT on real pixels only: the zero padding stays zero (x validity, 0 or 1)
             const v4f ps = *(const v4f*)(psb + ci0 + 4 * j), pt = *(const v4f*)(ptb + ci0 + 4 * j);
             const float lo1 = A.pre_relu ? 0.0f : -__builtin_inff();        // ReLU or nothing as ONE max (no per-word select)
@@ -225,7 +229,8 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
         }
     };
     // rows of B^T d for this half (loaded patch rows p, q, s = rows ih, ih+1, ih+2 of d), then the column transform
-    auto transform_write = [&](int buf) {
+    auto transform_write = [&](int buf, int ci0) {
+        stage_affine(ci0);
         v4f* o = (v4f*)(vb + (size_t)buf * VBUF + (size_t)tl * F4 + j);
         // a - b as fma(b, -1, a): exact, and one v_pk_fma_f32 per two floats where a plain subtraction is scalarised
         const v4f m1 = {-1.f, -1.f, -1.f, -1.f};
@@ -271,6 +276,16 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
             o[(size_t)(i * 4 + 3) * 32 * F4] = sub(R[1], R[3]);
         };
 #endif
+#ifdef OSSID_WINO_ABL_RAWTF      // ablation (wrong results, timing only): the staged patch stored as it is -- the loads and their
+        {                        // waits stay, the transform's vector-ALU work goes: what does the LATENCY of the patch cost?
+            for (int k = 0; k < 8; ++k) {
+                const v4f v = st[k % 3][k & 3];
+                *(uint2*)(ob + (size_t)((2 * ih) * 4 + k) * 32 * F4 * 16) = make_uint2(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]));
+                *(uint2*)(ob + (size_t)((2 * ih) * 4 + k) * 32 * F4 * 16 + lo_delta) = make_uint2(__builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
+            }
+            return;
+        }
+#endif
         v4f Ra[4], Rb[4];
         if (ih == 0) {            // (two code paths, not selects: ih is wave-uniform)
             asm volatile("" ::: "memory");
@@ -300,9 +315,29 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
 
     const int nchunks = A.Cin / KCH;
     const int ch0 = (int)((long long)slice * nchunks / ks), ch1 = (int)((long long)(slice + 1) * nchunks / ks);
-    if (stager) {
+    // CT = 4 (split-bf16 build): the two groups of four waves take turns at the input transform. The group whose turn it is
+    // transforms chunk ch + 1 at the START of iteration ch -- vector-ALU work that runs beside the OTHER group's MFMAs -- and
+    // multiplies afterwards; the other group requests the patch of chunk ch + 2 (one more iteration of cover for those loads)
+    // and multiplies at once. With waves 0-3 transforming behind everybody's MFMAs, the matrix pipe stood still for that
+    // phase: 47 % of the kernel (profiles/r03_wino_ct4.txt). CT = 2: four waves, all of them stage (two workgroups per CU run
+    // out of phase by themselves).
+#if !defined(OSSID_WINO_F32) && !defined(OSSID_WINO_NO_TURNS)      // (-DOSSID_WINO_NO_TURNS: the A/B switch, round 3's schedule)
+    constexpr bool TURNS = CT == 4;
+#else
+    constexpr bool TURNS = false;
+#endif
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);                  // 0: waves 0-3, 1: waves 4-7 (CT = 4 only)
+    if (TURNS) {
+        if (grp == (ch0 & 1)) {
+            stage_load(ch0 * KCH);
+            transform_write(ch0 & 1, ch0 * KCH);
+            if (ch0 + 2 < ch1) stage_load((ch0 + 2) * KCH);        // (its registers are free again)
+        } else if (ch0 + 1 < ch1) {
+            stage_load((ch0 + 1) * KCH);
+        }
+    } else if (stager) {
         stage_load(ch0 * KCH);
-        transform_write(ch0 & 1);
+        transform_write(ch0 & 1, ch0 * KCH);
     }
 #ifndef OSSID_WINO_F32
     // ---- split-bf16 core: per 16-channel chunk and transform position ONE v_mfma_f32_32x32x16_bf16 triple
@@ -328,7 +363,16 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
     int p0 = 8 * ch0;
 #pragma unroll 1
     for (int ch = ch0; ch < ch1; ++ch) {
-        if (stager && ch + 1 < ch1) stage_load((ch + 1) * KCH);   // in flight under this chunk's MFMAs
+        if (TURNS) {
+            if (grp == ((ch + 1) & 1)) {
+                if (ch + 1 < ch1) transform_write((ch + 1) & 1, (ch + 1) * KCH);    // beside the other group's MFMAs of this chunk
+#ifndef OSSID_WINO_LATE_STAGE
+                if (ch + 3 < ch1) stage_load((ch + 3) * KCH);                   // this group's next chunk: two iterations of cover
+#endif
+            }
+        } else if (stager && ch + 1 < ch1) {
+            stage_load((ch + 1) * KCH);   // in flight under this chunk's MFMAs
+        }
         const int sh = h ^ ((c >> 2) & 3), sl = sh ^ 2;          // swizzled slots of this lane's hi / lo operand (transform_write)
         const float4* pb = vb + (size_t)(ch & 1) * VBUF + (size_t)(8 * wx * 32 + c) * F4;
         float4 bh = pb[sh], bl = pb[sl];
@@ -349,7 +393,10 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
         }
         p0 += 8;
 #ifndef OSSID_WINO_ABL_NOTF         // ... and without the input transform of the next chunk)
-        if (stager && ch + 1 < ch1) transform_write((ch + 1) & 1);
+        if (!TURNS && stager && ch + 1 < ch1) transform_write((ch + 1) & 1, (ch + 1) * KCH);
+#endif
+#ifdef OSSID_WINO_LATE_STAGE     // (A/B: the patch requested BEHIND the chunk's MFMAs -- loads return in order, and a wait for a weight quad
+        if (TURNS && grp == ((ch + 1) & 1) && ch + 3 < ch1) stage_load((ch + 3) * KCH);     // issued behind the patch waits for the patch too)
 #endif
         __syncthreads();
     }
@@ -396,7 +443,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoArgs& A, const int bloc
             }
             ++gi;
         }
-        if (stager && ch + 1 < ch1) transform_write((ch + 1) & 1);
+        if (stager && ch + 1 < ch1) transform_write((ch + 1) & 1, (ch + 1) * KCH);
         __syncthreads();
     }
 #endif
