@@ -335,7 +335,7 @@ def conv_raw(x, wpk, B, H, W, cin, cout, taps, out, bias=None, pre=None, pre_rel
         d.post_scale, d.post_shift = post[0].data_ptr(), post[1].data_ptr()
     name = "ossid_conv3x3_wino_fwd" if wino else "ossid_conv_nhwc_fwd"       # wino: wpk is the Winograd layout
     with _lib.on_device(out.device):
-        if wino and d.scratch is None:
+        if wino and d.scratch is None and WINO_TAIL_SPLIT:
             from .ops import wino_workspace
             wino_workspace((d,), out.device)                                  # scratch for the launch's tail split
         _lib.check(_lib.fn(name)(_byref(d), _lib.stream()), name)
@@ -616,6 +616,11 @@ def _wgrad_async(tensors, fn, device, weights=(), side=None):
 
 
 USE_WINO = os.environ.get("OSSID_TRAIN_WINO", "1") != "0"
+# The Winograd launch's tail split (its last, partial round of workgroups cut along the reduction + a finishing launch: fills an
+# otherwise idle chip) in the training step: OFF -- three or four streams keep the chip busy there, and the split's partial sums and
+# finishing launches (27 per step, 0.8 ms of kernel time, most of them on the two detection trunks' streams) are then only work:
+# step 23.55 -> 23.40 ms with it off (same box, two runs each). The test-time head keeps it (one stream: ops.FusedConv).
+WINO_TAIL_SPLIT = os.environ.get("OSSID_TRAIN_WINO_TAIL", "0") != "0"
 WINO_MIN_WGS = int(os.environ.get("OSSID_TRAIN_WINO_MIN_WGS", "128"))
 
 
