@@ -11,6 +11,28 @@ static inline int ossid_launch_status() {
     return e == hipSuccess ? OSSID_OK : OSSID_ELAUNCH;
 }
 
+// ELU(alpha = 1) without libm's expm1f (~40 vector instructions per value -- 160 M of them per test-time frame in the head's
+// convolution epilogues: ~0.13 ms of vector-ALU time): a degree-7 Taylor polynomial near zero, where exp(x) - 1 would cancel,
+// and the hardware exponential elsewhere; relative error < 1e-6 (tests/test_dtoid_gpu.py holds it against torch's ELU).
+#ifdef __HIPCC__
+__device__ __forceinline__ float elu_fast(float x) {
+#ifdef OSSID_ELU_LIBM            // (A/B and reference build: libm's expm1f)
+    return x > 0.0f ? x : expm1f(x);
+#endif
+    const float xm = fminf(x, 0.0f);
+    float p = 1.0f / 5040.0f;
+    p = fmaf(p, xm, 1.0f / 720.0f);
+    p = fmaf(p, xm, 1.0f / 120.0f);
+    p = fmaf(p, xm, 1.0f / 24.0f);
+    p = fmaf(p, xm, 1.0f / 6.0f);
+    p = fmaf(p, xm, 0.5f);
+    p = fmaf(p, xm, 1.0f);
+    const float near0 = p * xm, far = __expf(xm) - 1.0f;
+    const float neg = xm > -0.35f ? near0 : far;
+    return x > 0.0f ? x : neg;
+}
+#endif
+
 // csrc/wgrad_fc.hip: the decoder's few-channel 3x3 weight gradients from 2-D pixel tiles (internal: reached through
 // ossid_conv_wgrad / ossid_conv_wgrad_workspace_bytes of csrc/train.hip)
 bool ossid_wgrad_fewch_takes(int Cin, int Cout, int taps, int in_cs, int dy_cs);

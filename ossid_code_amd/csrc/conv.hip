@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float u = acc[t][4 * q + i];
-                if (A.act == 1) u = u > 0.0f ? u : expm1f(u);
+                if (A.act == 1) u = elu_fast(u);
                 else if (A.act == 2) u = fmaxf(u, 0.0f);
                 v[i] = u * sc[i] + sh[i];
             }

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void bcast_sub_epilogue_kernel(const float4* _
     const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float u = v[k] > 0.0f ? v[k] : expm1f(v[k]);
+        const float u = elu_fast(v[k]);
         v[k] = u * av[k] + bv[k];
     }
     *(float4*)(out + ((size_t)t * H * W + px) * out_cs + out_coff + 4 * o4) = make_float4(v[0], v[1], v[2], v[3]);
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void bias_elu_affine_slice_kernel(const float4
     const float av[4] = {a.x, a.y, a.z, a.w}, sv[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float u = v[k] > 0.0f ? v[k] : expm1f(v[k]);
+        const float u = elu_fast(v[k]);
         v[k] = u * av[k] + sv[k];
     }
     *(float4*)(out + r * out_cs + out_coff + 4 * o4) = make_float4(v[0], v[1], v[2], v[3]);

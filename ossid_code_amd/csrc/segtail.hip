@@ -48,22 +48,7 @@ struct SegTailArgs {
     float scale_h, scale_w;
 };
 
-// ELU(alpha = 1) without libm's expm1f (~40 instructions, four per lane per 72 MFMAs here): a degree-7 Taylor polynomial
-// near zero, where exp(x) - 1 would cancel, and the hardware exponential elsewhere; relative error < 1e-6.
-__device__ __forceinline__ float elu_fast(float x) {
-    const float xm = fminf(x, 0.0f);
-    float p = 1.0f / 5040.0f;
-    p = fmaf(p, xm, 1.0f / 720.0f);
-    p = fmaf(p, xm, 1.0f / 120.0f);
-    p = fmaf(p, xm, 1.0f / 24.0f);
-    p = fmaf(p, xm, 1.0f / 6.0f);
-    p = fmaf(p, xm, 0.5f);
-    p = fmaf(p, xm, 1.0f);
-    const float near0 = p * xm, far = __expf(xm) - 1.0f;
-    const float neg = xm > -0.35f ? near0 : far;
-    return x > 0.0f ? x : neg;
-}
-
+// (elu_fast: csrc/common.h)
 __device__ __forceinline__ int src_index(int dst, float scale, int n_src) {
     return min((int)floorf((float)dst * scale), n_src - 1);   // F.interpolate(mode="nearest")
 }

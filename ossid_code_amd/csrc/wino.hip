@@ -118,7 +118,7 @@ __device__ __forceinline__ void wino_epilogue(const WinoArgs& A, const int bx, c
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float u = keep[b2][4 * q + i] + bi[i];
-                if (A.act == 1) u = u > 0.0f ? u : expm1f(u);
+                if (A.act == 1) u = elu_fast(u);
                 else if (A.act == 2) u = fmaxf(u, 0.0f);
                 v[i] = u * sc[i] + sh[i];
             }
