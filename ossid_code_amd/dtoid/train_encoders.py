@@ -327,7 +327,14 @@ def _encoder_backward(mod, gout, sv, side, direct=False):
     grads[stem.bias] = sums[0]
     dw_cols = wgrad_later(None, cols, g, B, H0, W0, STEM_KPAD, 64, 1, key="stem")
     dw_stem = T.grad_home(stem.weight, direct)
-    touched = [it["dw"] for it in deferred] + [dw_stem]
+    # everything the side stream reads or writes (the caching allocator must not hand an operand's memory to the next
+    # allocation on THIS stream while the grouped launch is still reading it: outside a recorded sequence -- whose buffers
+    # are persistent -- the intermediate gradients die when this function returns; recording only the outputs left
+    # tests/test_dtoid_gpu.py::test_template_encoder_training_node_matches_module_path[False-*] with one layer's weight
+    # gradient a few 1e-3 off once in a few full-suite runs)
+    touched = [it["dw"] for it in deferred] + [dw_stem, dw_cols]
+    for it in deferred:
+        touched += [it["x"], it["dy"]] + (list(it["pre"]) if it.get("pre") is not None else [])
 
     def weight_gradients():            # one grouped launch, then the stem's from im2col column order back to [64, 4, 3, 3]
         T.wgrad_group(deferred)

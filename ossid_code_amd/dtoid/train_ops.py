@@ -945,6 +945,7 @@ def _dense_backward(G, buf, saved, block, params, C0, side, direct=False):
     mid = int(params[2].shape[0])
     dz_all = new_buf((L, B, H, W, mid), dev)                      # per layer: the 1x1 wgrad runs at the end
     deferred = []                                                 # the block's 2 L weight gradients: ONE grouped launch below
+    side_reads = []                                               # small tensors of this function the grouped launch reads
     da = None
     fused_bwd = (DENSE_BWD_FUSED and mid == 128 and Ct <= 1024 and N * Ct < (1 << 32) and
                  bool(_lib.fn("ossid_conv_split_bf16")()))
@@ -985,6 +986,7 @@ def _dense_backward(G, buf, saved, block, params, C0, side, direct=False):
         # dz = scale*db*mask + coef_x*y1 + coef_1: a pass of its own, or -- with the fused 1x1 data gradient -- formed while dz is
         # staged, there and in the (deferred) 1x1 weight gradient
         add = (y1, r2[2], r2[3]) if fused_bwd else None
+        side_reads.append(r2)                                     # (the deferred 1x1 weight gradient reads r2[2], r2[3] on the side stream)
         if add is None:
             chan_op(db, N, mid, x=y1, out=db, beta=r2[2], kappa=r2[3])
         # 1x1: weight gradient on relu(bn1(buf[:, :c])) (deferred), data gradient to the c input channels
@@ -1005,7 +1007,7 @@ def _dense_backward(G, buf, saved, block, params, C0, side, direct=False):
         bn_fold_bwd(None, None, g1, f1[2], f1[3], c, N, r1[0], r1[1], coef[0], coef[1], accumulate=True, partials=s)
         grads[6 * li:6 * li + 6] = [r1[0], r1[1], dw1, r2[0], r2[1], dw2]
     touched = [G, buf, dz_all] + [t for sv in saved for t in (sv[1], sv[0][0], sv[0][1], sv[2][0], sv[2][1])] + \
-        [it["dw"] for it in deferred]
+        [it["dw"] for it in deferred] + side_reads
     _wgrad_async(touched, lambda: wgrad_group(deferred), dev, side=side)
     # the block's input channels, written compactly
     dx = new_buf((B, C0, H, W), dev, channels_last=True)
