@@ -160,7 +160,7 @@ def dtoid_leg(a, dev, dist, world):
     def run_pairs():
         with torch.no_grad():
             m.model(*pairs)
-    t_pairs = timed(run_pairs, 1, 3)
+    t_pairs = timed(run_pairs, 2, 10)
     # matrix-core work each leg actually issues (ossid_code_amd._lib.count_mfma: summed at the launch sites over ONE eager,
     # graph-free pass -- a graph replay makes no host calls): Winograd layers count their 16 multiplies per tile, the
     # reassociated layers what they run. Layers still on MIOpen (7x7 stem in training, the 1-channel output convs) are not in it.
