@@ -239,7 +239,7 @@ def dtoid_leg(a, dev, dist, world):
     # the product path: eager launches, weight gradients and the independent branches of the head on side HIP streams
     # (train_ops.WGRAD_SIDE, Network.use_train_streams). (The one-stream hipGraph replay of the same step -- slower, not the
     # product path -- is timed by tools/bench_finetune.py, not here.)
-    t_ft = timed(lambda: finetune.finetune_step(m, batch, opt, sync), 3, 10)
+    t_ft = timed(lambda: finetune.finetune_step(m, batch, opt, sync), 5, 20)
     with oslib.count_mfma() as c_ft:
         finetune.finetune_step(m, batch, opt, sync)
     torch.cuda.synchronize()
