@@ -395,7 +395,7 @@ def make_line(names, stage_ms, feat_ms, elapsed, world, steps, warmup, n_streams
                                  "on the chip: a second pass over the timed region's frames with one frame in flight (the timed "
                                  "region keeps %d in flight, whose kernels share the chip: rocprofv3's per-kernel average over the whole "
                                  "command mixes both passes, tools/stats_by_pass.py splits the trace -- "
-                                 "profiles/r03_kernel_stats_by_pass.txt)" % (N_HYP, n_streams),
+                                 "profiles/r04_kernel_stats_by_pass.txt)" % (N_HYP, n_streams),
                      "whole_step_frac": sum(STAGE_FLOPS.values()) * N_HYP / (elapsed / steps) / 1e12 / PEAK_F32_MATRIX_TFLOPS},
         "stage_ms": {n: round(float(v), 4) for n, v in zip(names, stage_ms)},
         "stage_ms_sum": round(float(sum(stage_ms)), 4),
