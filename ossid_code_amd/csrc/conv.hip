@@ -104,8 +104,11 @@ struct ConvArgs {
 // source pixels (i+a-1, i+a) x (j+b-1, j+b), so each of the four phases (a,b) is a 2x2 convolution of the SOURCE with
 // row/column-merged weights -- 4/9 of the multiply-adds of convolving the up-sampled image (network.py:354-356). Geometry
 // (H, W, pixel tiles, patch) is the source's; a block's group index carries the phase; outputs go to [2H][2W].
-template <int FORM, int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
-__global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
+// NPH (TAPS == 4 only) = phases per workgroup: 1 (the phase rides on the group index: four workgroups stage the same source patch)
+// or 4 (ONE workgroup stages the patch once per chunk and runs all four phases off it, 4 NT accumulator tiles per wave: the
+// decoder's few-channel layers are staging / set-up bound -- K = 4 taps x 64 or 128 channels -- not matrix-pipe bound).
+template <int FORM, int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH, int NPH = 1>
+__device__ __forceinline__ void conv_nhwc_body(const ConvArgs& A) {
     constexpr bool SB = FORM != 0;              // operands as bf16 pieces (FORM = number of pieces - 1), 16-channel units
     constexpr int WN = 4 / (WM * WK);
     constexpr int BPX = WN * NT * 32;
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     constexpr int GQ = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : (NKB >= 2 ? 2 : 1));   // weight quads per prefetch group
     constexpr int GPC = TAPS == 9 ? NKB * 3 : (TAPS == 4 ? NKB * 2 : NKB / GQ);   // groups per chunk per wave
     static_assert(WM * WK * WN == 4 && KCH % (UNIT * WK) == 0 && 256 % F4 == 0, "bad tiling");
+    static_assert(NPH == 1 || (NPH == 4 && TAPS == 4 && WK == 1), "all-phases form: phase convolutions without split-K only");
     extern __shared__ __attribute__((aligned(16))) float4 patch[];   // [2][buf_pos][F4P]
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     // the wave id is uniform, and the compiler must KNOW it: the weight-quad index (channel tile, chunk, tap) is then scalar
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         b = pt / A.gx;
     }
     int ph_a = 0, ph_b = 0, phase = 0;              // TAPS == 4: the phase (a, b) rides on the group index
-    if (TAPS == 4) {
+    if (TAPS == 4 && NPH == 1) {
         const int groups = A.gy >> 2;
         phase = by / groups;
         by -= phase * groups;
@@ -265,8 +269,9 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
     const bool active = co_tile < A.n_cotiles;
     const int nq = (A.Cin / UNIT) * TAPS;                       // weight units per channel tile
     const float4* W4 = A.wpk + ((size_t)phase * A.n_cotiles + (active ? co_tile : 0)) * nq * WPQ * 64;     // (+ lane at the load)
+    const int ph_units = A.n_cotiles * nq;                       // weight units between two phases (NPH == 4)
 
-    v16f acc[NT];
+    v16f acc[NPH * NT];
     {
         const int cb = (active ? co_tile : 0) * 32 + 4 * h;
 #pragma unroll
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
             for (int i = 0; i < 4; ++i) {
                 const float bv = (A.bias && wk == 0 && co + i < A.Cout) ? A.bias[co + i] : 0.0f;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t][4 * q + i] = bv;
+                for (int t = 0; t < NPH * NT; ++t) acc[t][4 * q + i] = bv;
             }
         }
     }
@@ -346,8 +351,10 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
             const int ky = gi % 3, kbl = (gi / 3) % NKB, ch = gi / (3 * NKB);
             q = ((ch * (KCH / UNIT) + wk * NKB + kbl) * 9) + ky * 3 + i;
         } else if (TAPS == 4) {
-            const int r = gi % 2, kbl = (gi / 2) % NKB, ch = gi / (2 * NKB);
+            const int gl = NPH == 4 ? gi % GPC + GPC * (gi / (GPC * NPH)) : gi;      // (chunk, group) without the phase
+            const int r = gl % 2, kbl = (gl / 2) % NKB, ch = gl / (2 * NKB);
             q = ((ch * (KCH / UNIT) + wk * NKB + kbl) * 4) + r * 2 + i;
+            if (NPH == 4) return (q < nq ? q : nq - 1) + ((gi / GPC) % NPH) * ph_units;
         } else {
             const int g = gi % GPC, ch = gi / GPC;
             q = ch * (KCH / UNIT) + wk * NKB + g * GQ + i;
@@ -383,7 +390,9 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
         if (ch + 1 < nchunks) stage_load((ch + 1) * KCH);     // in flight under this chunk's MFMAs
         const float4* pb = patch + (size_t)(ch & 1) * A.buf_pos * F4P + h;
 #pragma unroll
-        for (int g = 0; g < GPC; ++g) {
+        for (int g2 = 0; g2 < GPC * NPH; ++g2) {
+            const int g = g2 % GPC, ph = g2 / GPC;                // (compile-time: the loop is unrolled)
+            const int pa = NPH == 4 ? (ph >> 1) : ph_a, pb2 = NPH == 4 ? (ph & 1) : ph_b;
 #pragma unroll
             for (int i = 0; i < GQ; ++i)
 #pragma unroll
@@ -395,23 +404,23 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
                 // store nothing: a per-wave branch here would put the accumulators through VGPR<->AGPR copies and a
                 // matrix-pipe drain around every group)
                 const int kb = wk * NKB + (TAPS == 9 ? g / 3 : (TAPS == 4 ? g / 2 : g * GQ + i));   // unit inside the chunk
-                const int toff = TAPS == 9 ? (g % 3) * PW + i : (TAPS == 4 ? (ph_a + g % 2) * PW + ph_b + i : 0);
+                const int toff = TAPS == 9 ? (g % 3) * PW + i : (TAPS == 4 ? (pa + g % 2) * PW + pb2 + i : 0);
                 if constexpr (SB) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const float4* px = pb + (size_t)(pos0[t] + toff) * F4P + 2 * kb;      // (+ h in pb: 16 bytes = 8 channels)
-                        if constexpr (FORM == 2) acc[t] = mfma6(wq[0][i], px[0], px[F4 / 2], px[F4], acc[t]);
-                        else acc[t] = mfma3(wq[0][i][0], wq[0][i][WPQ - 1], px[0], px[F4 / 2], acc[t]);
+                        if constexpr (FORM == 2) acc[ph * NT + t] = mfma6(wq[0][i], px[0], px[F4 / 2], px[F4], acc[ph * NT + t]);
+                        else acc[ph * NT + t] = mfma3(wq[0][i][0], wq[0][i][WPQ - 1], px[0], px[F4 / 2], acc[ph * NT + t]);
                     }
                 } else {
                     const float4 a = wq[0][i][0];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const float4 bq = pb[(size_t)(pos0[t] + toff) * F4P + 2 * kb];
-                        acc[t] = mfma(a.x, bq.x, acc[t]);
-                        acc[t] = mfma(a.y, bq.y, acc[t]);
-                        acc[t] = mfma(a.z, bq.z, acc[t]);
-                        acc[t] = mfma(a.w, bq.w, acc[t]);
+                        acc[ph * NT + t] = mfma(a.x, bq.x, acc[ph * NT + t]);
+                        acc[ph * NT + t] = mfma(a.y, bq.y, acc[ph * NT + t]);
+                        acc[ph * NT + t] = mfma(a.z, bq.z, acc[ph * NT + t]);
+                        acc[ph * NT + t] = mfma(a.w, bq.w, acc[ph * NT + t]);
                     }
                 }
             }
@@ -471,17 +480,19 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
             sh[i] = (A.bn_shift && in) ? A.bn_shift[co + i] : 0.0f;
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        for (int t2 = 0; t2 < NPH * NT; ++t2) {
+            const int t = t2 % NT, ph = t2 / NT;
             if (opx[t] < 0) continue;
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float u = acc[t][4 * q + i];
+                float u = acc[t2][4 * q + i];
                 if (A.act == 1) u = elu_fast(u);
                 else if (A.act == 2) u = fmaxf(u, 0.0f);
                 v[i] = u * sc[i] + sh[i];
             }
-            float* o = A.out + (size_t)opx[t] * A.out_cs + A.out_coff + co;
+            // (NPH == 4: opx is phase (0, 0)'s pixel (2y, 2x) of the [2H][2W] output; phase (a, b) sits a rows and b columns further)
+            float* o = A.out + ((size_t)opx[t] + (NPH == 4 ? (ph >> 1) * 2 * W + (ph & 1) : 0)) * A.out_cs + A.out_coff + co;
             const bool full = co + 3 < A.Cout;
             if (full) {
                 *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
@@ -499,6 +510,17 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
 #endif
 }
 
+template <int FORM, int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH, int NPH = 1>
+__global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs A) {
+    conv_nhwc_body<FORM, WM, WK, NT, ROWSEG, NLD, TAPS, KCH, NPH>(A);
+}
+// ... and with two waves per SIMD asked of the register allocator (the all-phases form: 4 NT accumulator tiles per wave would
+// otherwise leave one wave per SIMD to hide the staging latency behind)
+template <int FORM, int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH, int NPH = 1>
+__global__ __launch_bounds__(256, 2) void conv_nhwc_kernel_w2(const ConvArgs A) {
+    conv_nhwc_body<FORM, WM, WK, NT, ROWSEG, NLD, TAPS, KCH, NPH>(A);
+}
+
 // weight repack on the device: w [Cout][Cin][taps] (torch layout, taps = kh*kw) -> wpk (see the file header)
 __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, int dgrad,
                                                         int exact, float4* __restrict__ wpk, size_t total) {
@@ -507,7 +529,7 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
     wpk[i] = ossid_conv_pack_quad(w, Cout, Cin, taps, dgrad, exact, i);
 }
 
-template <int FORM, int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
+template <int FORM, int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH, int NPH = 1>
 int launch_conv_form(ConvArgs a, int B, hipStream_t s) {
     constexpr int WN = 4 / (WM * WK), BPX = WN * NT * 32, F4 = KCH / 4;
     // a ragged last chunk (Cin no multiple of KCH) stages zeros past Cin and clamps the weight quads: any variant, Cin % 8 == 0
@@ -536,9 +558,12 @@ int launch_conv_form(ConvArgs a, int B, hipStream_t s) {
     size_t lds = (size_t)2 * a.buf_pos * ((FORM == 2 ? KCH / 16 * 6 : F4) + OSSID_LDS_PAD) * 16;
     const size_t red = WK > 1 ? (size_t)WK * (WM * WN) * NT * 16 * 64 * 4 : 0;
     if (red > lds) lds = red;
-    auto kern0 = conv_nhwc_kernel<FORM, WM, WK, NT, ROWSEG, NLD, TAPS, KCH>;
+    auto kern0 = [] {        // (if constexpr: only the wrapper a tiling uses is instantiated)
+        if constexpr (NPH == 4) return &conv_nhwc_kernel_w2<FORM, WM, WK, NT, ROWSEG, NLD, TAPS, KCH, NPH>;
+        else return &conv_nhwc_kernel<FORM, WM, WK, NT, ROWSEG, NLD, TAPS, KCH, NPH>;
+    }();
     OSSID_ENSURE_LDS(kern0, lds);
-    a.gx = nblk, a.gy = (a.n_cotiles + WM - 1) / WM * (TAPS == 4 ? 4 : 1), a.gz = B;
+    a.gx = nblk, a.gy = (a.n_cotiles + WM - 1) / WM * ((TAPS == 4 && NPH == 1) ? 4 : 1), a.gz = B;
     const long P = (long)a.gx * a.gz;
     long nwg;
     if (a.gy <= 8 && 8 % a.gy == 0)
@@ -552,13 +577,13 @@ int launch_conv_form(ConvArgs a, int B, hipStream_t s) {
 
 // a.split picks the arithmetic; every tiling exists in both forms except where a wave's share of a chunk would be half a
 // 16-channel unit (KCH / WK == 8: the caller names the split form's tiling separately)
-template <int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH>
+template <int WM, int WK, int NT, int ROWSEG, int NLD, int TAPS, int KCH, int NPH = 1>
 int launch_conv(const ConvArgs& a, int B, hipStream_t s) {
     if constexpr (KCH % (16 * WK) == 0) {
-        if (a.split == 1) return launch_conv_form<1, WM, WK, NT, ROWSEG, NLD, TAPS, KCH>(a, B, s);
-        if (a.split == 2) return launch_conv_form<2, WM, WK, NT, ROWSEG, NLD, TAPS, KCH>(a, B, s);
+        if (a.split == 1) return launch_conv_form<1, WM, WK, NT, ROWSEG, NLD, TAPS, KCH, NPH>(a, B, s);
+        if (a.split == 2) return launch_conv_form<2, WM, WK, NT, ROWSEG, NLD, TAPS, KCH, NPH>(a, B, s);
     }
-    return launch_conv_form<0, WM, WK, NT, ROWSEG, NLD, TAPS, KCH>(a, B, s);
+    return launch_conv_form<0, WM, WK, NT, ROWSEG, NLD, TAPS, KCH, NPH>(a, B, s);
 }
 
 }  // namespace
@@ -659,6 +684,14 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
             }
         }
         (void)per128;
+#ifndef OSSID_PHASE_SPLIT      // (-DOSSID_PHASE_SPLIT: one phase per workgroup everywhere, the A/B build)
+        // the decoder's few-channel layers on wide images (128 -> 64 at 116 x 156, 64 -> 32 at 232 x 312): all four phases
+        // per workgroup off ONE staged patch
+        if (a.split == 1) {
+            if (wide) return tiles >= 2 ? launch_conv<2, 1, 2, 2, 8, 4, 16, 4>(a, B, s) : launch_conv<1, 1, 2, 2, 8, 4, 16, 4>(a, B, s);
+            // (the narrow layers -- 128 -> 64 at 58 x 78, 256 -> 128 at 29 x 39 -- measured slower in this form: graph 3.656 vs 3.596 ms)
+        }
+#endif
         if (tiles >= 2) return wide ? launch_conv<2, 1, 2, 2, 8, 4, 16>(a, B, s) : launch_conv<2, 1, 2, 0, 8, 4, 16>(a, B, s);
         return wide ? launch_conv<1, 1, 2, 2, 8, 4, 16>(a, B, s) : launch_conv<1, 1, 1, 0, 8, 4, 16>(a, B, s);
     }
