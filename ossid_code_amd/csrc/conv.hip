@@ -688,7 +688,9 @@ int ossid_conv_nhwc_fwd(const ossid_conv_desc* d, void* stream) {
         // the decoder's few-channel layers on wide images (128 -> 64 at 116 x 156, 64 -> 32 at 232 x 312): all four phases
         // per workgroup off ONE staged patch
         if (a.split == 1) {
-            if (wide) return tiles >= 2 ? launch_conv<2, 1, 2, 2, 8, 4, 16, 4>(a, B, s) : launch_conv<1, 1, 2, 2, 8, 4, 16, 4>(a, B, s);
+            // (one 32-pixel tile per wave and phase: 3.601 vs 3.624 ms with two)
+            if (wide) return tiles >= 2 ? launch_conv<2, 1, 1, 2, 8, 4, 16, 4>(a, B, s) : launch_conv<1, 1, 1, 2, 8, 4, 16, 4>(a, B, s);
+            // (... and a tie with one tile per wave: 3.611 vs 3.608)
             // (the narrow layers -- 128 -> 64 at 58 x 78, 256 -> 128 at 29 x 39 -- measured slower in this form: graph 3.656 vs 3.596 ms)
         }
 #endif
