@@ -3,7 +3,7 @@
 #   tools/collect_dtoid_traffic.sh gpurun_out/r04/pmc   ->  <dir>/dtoid_traffic.json (copy to profiles/r04_dtoid_traffic.json)
 set -e
 O=${1:-gpurun_out/r04/pmc}
-CALLS=1
+CALLS=${2:-1}
 mkdir -p $O
 R=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $R
